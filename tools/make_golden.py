@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (CPU).
+
+Runs only in the build container where /root/reference exists:
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+
+The reference is imported unmodified.  Two modules it imports but never uses on this
+path (torchaudio, progressbar) are absent from the image and are registered as empty
+stubs; `torch.ones(..., device='cuda')` at criterion.py:340 is redirected to the CPU
+(arithmetic untouched).  Only inputs and outputs are written -- no reference code.
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+for _m in ("torchaudio", "progressbar"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+
+import cpc.model as ref_model                      # noqa: E402
+import cpc.criterion.criterion as ref_crit          # noqa: E402
+import cpc.transformers as ref_tr                   # noqa: E402
+
+from oracle import synth                            # noqa: E402
+
+_real_ones = torch.ones
+
+
+def _ones_cpu(*a, **kw):
+    if kw.get("device") == "cuda":
+        kw["device"] = "cpu"
+    return _real_ones(*a, **kw)
+
+
+torch.ones = _ones_cpu
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def npy(d):
+    return {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    arrays["torch_version"] = np.array(torch.__version__)
+    arrays = npy(arrays)
+    np.savez_compressed(os.path.join(OUT, name), **arrays)
+    print("wrote", name, sum(v.nbytes for v in arrays.values()), "bytes (raw)")
+
+
+def strip(p, prefix):
+    return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+# ------------------------------------------------------------------ G1 indices
+def ref_indices(seed, b, t_len, k_steps, n_neg):
+    """Runs the reference's sampleClean and recovers its index tensors by replaying
+    torch.randint on the same generator state (the reference does not return them)."""
+    w = t_len - k_steps
+    crit = ref_crit.CPCUnsupersivedCriterion(k_steps, 8, 8, n_neg, rnnMode="linear", sizeInputSeq=t_len)
+    # z rows carry their own flat index so the gathered negatives reveal extIdx exactly
+    z = torch.arange(b * t_len, dtype=torch.float32).view(b, t_len, 1).repeat(1, 1, 8)
+    torch.manual_seed(seed)
+    outs, _ = crit.sampleClean(z, w)
+    ext = outs[0][:, 1:, :, 0].reshape(-1).to(torch.int64)       # [b, n_neg, W] flat
+    torch.manual_seed(seed)
+    n = n_neg * w * b
+    batch_idx = torch.randint(0, b, (n,))
+    seq_idx = torch.randint(1, t_len, (n,))
+    return batch_idx, seq_idx, ext
+
+
+def g1():
+    out = {}
+    for tag, (seed, b, t_len, k, nn) in {"tiny": (1234, 2, 8, 4, 3), "mid": (7, 4, 32, 4, 16)}.items():
+        bi, si, ext = ref_indices(seed, b, t_len, k, nn)
+        out[f"{tag}_cfg"] = np.array([seed, b, t_len, k, nn])
+        out[f"{tag}_batchIdx"], out[f"{tag}_seqIdx"], out[f"{tag}_extIdx"] = bi, si, ext
+    seed, b, t_len, k, nn = 1234, 64, 128, 12, 128
+    bi, si, ext = ref_indices(seed, b, t_len, k, nn)
+    out["full_cfg"] = np.array([seed, b, t_len, k, nn])
+    out["full_ext_sha256"] = np.array(hashlib.sha256(ext.numpy().astype("<i8").tobytes()).hexdigest())
+    out["full_ext_head"], out["full_ext_tail"] = ext[:64], ext[-64:]
+    # second call on the SAME generator (stream continuity across steps)
+    crit = ref_crit.CPCUnsupersivedCriterion(k, 8, 8, nn, rnnMode="linear", sizeInputSeq=t_len)
+    z = torch.arange(b * t_len, dtype=torch.float32).view(b, t_len, 1).repeat(1, 1, 8)
+    torch.manual_seed(seed)          # seed AFTER construction: module init draws from the same generator
+    crit.sampleClean(z, t_len - k)
+    outs, _ = crit.sampleClean(z, t_len - k)
+    ext2 = outs[0][:, 1:, :, 0].reshape(-1).to(torch.int64)
+    out["full_ext2_sha256"] = np.array(hashlib.sha256(ext2.numpy().astype("<i8").tobytes()).hexdigest())
+    out["full_ext2_head"] = ext2[:64]
+    save("g1_negidx.npz", **out)
+
+
+# ------------------------------------------------------------------ G2/G3 encoder, ChannelNorm
+def g2():
+    hidden = 32
+    p = synth.encoder_params(hidden, seed=11)
+    enc = ref_model.CPCEncoder(hidden, "layerNorm")
+    enc.load_state_dict(strip(p, "gEncoder."))
+    x = synth.audio_windows(2, 20480, seed=12)
+    gout = synth.features((2, hidden, 128), seed=13)
+    # per-layer activations through the reference's own modules
+    acts, h = [], x
+    for i in range(5):
+        h = torch.relu(getattr(enc, f"batchNorm{i}")(getattr(enc, f"conv{i}")(h)))
+        acts.append(h)
+    out = enc(x)
+    assert torch.equal(out, acts[-1])
+    (out * gout).sum().backward()
+    d = {"hidden": hidden, "param_seed": 11, "x_seed": 12, "gout_seed": 13, "out": out}
+    for i, a in enumerate(acts):
+        d[f"act{i}_sum"] = a.double().sum()
+        d[f"act{i}_abs"] = a.double().abs().sum()
+        d[f"act{i}_head"] = a[:, :, :4]
+        d[f"act{i}_tail"] = a[:, :, -4:]
+    for k, v in enc.named_parameters():
+        d["grad." + k] = v.grad
+    save("g2_encoder_h32.npz", **d)
+
+
+def g3():
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.standard_normal((3, 16, 50)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((1 + 0.2 * rs.standard_normal((1, 16, 1))).astype(np.float32))
+    b = torch.from_numpy((0.2 * rs.standard_normal((1, 16, 1))).astype(np.float32))
+    g = torch.from_numpy(rs.standard_normal((3, 16, 50)).astype(np.float32))
+    cn = ref_model.ChannelNorm(16)
+    cn.weight.data.copy_(w)
+    cn.bias.data.copy_(b)
+    y = cn(x)
+    (y * g).sum().backward()
+    save("g3_channelnorm.npz", x=x, w=w, b=b, g=g, y=y, dx=x.grad, dw=cn.weight.grad, db=cn.bias.grad)
+
+
+# ------------------------------------------------------------------ G4 GRU
+def g4():
+    d = {}
+    for tag, (hin, hid, layers, n, t_len) in {"l1": (32, 32, 1, 3, 20), "l2": (24, 32, 2, 2, 16)}.items():
+        p = synth.gru_params(hin, hid, layers, seed=41)
+        ar = ref_model.CPCAR(hin, hid, False, layers, mode="GRU", reverse=False)
+        ar.load_state_dict(strip(p, "gAR."))
+        x = synth.features((n, t_len, hin), seed=42, relu=True).requires_grad_(True)
+        g = synth.features((n, t_len, hid), seed=43)
+        out = ar(x)
+        (out * g).sum().backward()
+        d[f"{tag}_cfg"] = np.array([hin, hid, layers, n, t_len])
+        d[f"{tag}_out"], d[f"{tag}_dx"] = out, x.grad
+        for k, v in ar.named_parameters():
+            d[f"{tag}_grad." + k] = v.grad
+    # reverse mode (model.py:190-191,205-206)
+    p = synth.gru_params(32, 32, 1, seed=41)
+    ar = ref_model.CPCAR(32, 32, False, 1, mode="GRU", reverse=True)
+    ar.load_state_dict(strip(p, "gAR."))
+    x = synth.features((3, 20, 32), seed=42, relu=True)
+    d["rev_out"] = ar(x)
+    save("g4_gru.npz", **d)
+
+
+# ------------------------------------------------------------------ G5 criterion
+def run_criterion(b, t_len, har, henc, k, nn, seed, pseed, mode=None, n_skipped=0, quality=None,
+                  growth=None, infl=None):
+    p = synth.predictor_params(k, har, henc, seed=pseed, scale=4.0)
+    crit = ref_crit.CPCUnsupersivedCriterion(k, har, henc, nn, mode=mode, rnnMode="linear",
+                                             sizeInputSeq=t_len, n_skipped=n_skipped,
+                                             growth_rate=growth, inflection_point_x=infl)
+    crit.load_state_dict(p)
+    c = synth.features((b, t_len, har), seed=pseed + 1).requires_grad_(True)
+    z = synth.features((b, t_len, henc), seed=pseed + 2, relu=True).requires_grad_(True)
+    torch.manual_seed(seed)
+    losses, acc = crit(c, z, None, quality)
+    losses.sum().backward()
+    grads = {}
+    for i in range(k):      # a skipped step receives no gradient at all (None) -> store zeros
+        w = crit.wPrediction.predictors[i].weight
+        grads[f"dW{i}"] = w.grad if w.grad is not None else torch.zeros_like(w)
+    return losses, acc, c.grad, z.grad, grads
+
+
+def g5():
+    d = {}
+    base = dict(b=4, t_len=32, har=32, henc=32, k=4, nn=16, seed=99, pseed=50)
+    quality = synth.features((4, 12), seed=77)
+    variants = {
+        "plain": {},
+        "skip": {"n_skipped": 1},
+        "reverse": {"mode": "reverse"},
+        "quality": {"quality": quality, "growth": 2.0, "infl": 0.1},
+        "rect": {"har": 24},          # dimOutputEncoder > dimOutputAR
+    }
+    for tag, kw in variants.items():
+        cfg = dict(base, **kw)
+        losses, acc, dc, dz, gw = run_criterion(**cfg)
+        d[f"{tag}_losses"], d[f"{tag}_acc"], d[f"{tag}_dc"], d[f"{tag}_dz"] = losses, acc, dc, dz
+        for k, v in gw.items():
+            d[f"{tag}_{k}"] = v
+    d["quality_signal"] = quality
+    save("g5_criterion_small.npz", **d)
+
+    # full-size shapes of config C2 at b=8 (fits memory); store outputs + gradient digests
+    losses, acc, dc, dz, gw = run_criterion(b=8, t_len=128, har=256, henc=256, k=12, nn=128, seed=1234, pseed=60)
+    f = {"losses": losses, "acc": acc,
+         "dc_sum": dc.double().sum(), "dc_abs": dc.double().abs().sum(), "dc_head": dc[:, :3, :8],
+         "dz_sum": dz.double().sum(), "dz_abs": dz.double().abs().sum(), "dz_head": dz[:, :3, :8],
+         "dz_tail": dz[:, -3:, :8]}
+    for k, v in gw.items():
+        f[f"{k}_abs"] = v.double().abs().sum()
+        f[f"{k}_head"] = v[:4, :8]
+    save("g5_criterion_full.npz", **f)
+
+
+# ------------------------------------------------------------------ G6 train steps (loss-curve anchor)
+def g6():
+    hidden, b, k, nn, steps, seed = 64, 4, 12, 128, 20, 1234
+    mp = synth.encoder_params(hidden, seed=21)
+    mp.update(synth.gru_params(hidden, hidden, 1, seed=22))
+    cp = synth.predictor_params(k, hidden, hidden, seed=23)
+    enc = ref_model.CPCEncoder(hidden, "layerNorm")
+    ar = ref_model.CPCAR(hidden, hidden, False, 1, mode="GRU", reverse=False)
+    model = ref_model.CPCModel(enc, ar)
+    model.load_state_dict(mp)
+    crit = ref_crit.CPCUnsupersivedCriterion(k, hidden, hidden, nn, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(cp)
+    # train.py:472-479 -- criterion parameters first, Adam(lr=2e-4, betas=(0.9,0.999), eps=1e-8)
+    opt = torch.optim.Adam(list(crit.parameters()) + list(model.parameters()), lr=2e-4,
+                           betas=(0.9, 0.999), eps=1e-8)
+    x = synth.audio_windows(b, 20480, seed=24)
+    label = torch.zeros(b, dtype=torch.long)
+    torch.manual_seed(seed)
+    model.train()
+    crit.train()
+    curve, accs = [], []
+    for _ in range(steps):
+        # train.py:95-113
+        past, future = x, x
+        combined = torch.cat([past, future], dim=0)
+        lab = torch.cat([label, label])
+        c_feature, encoded, lab = model(combined, lab)
+        c_feature, encoded = c_feature[:b], encoded[b:]
+        all_losses, all_acc = crit(c_feature, encoded, lab[:b], None)
+        all_losses.sum().backward()
+        opt.step()
+        opt.zero_grad()
+        curve.append(all_losses.detach().clone())
+        accs.append(all_acc.detach().clone())
+    d = {"cfg": np.array([hidden, b, k, nn, steps, seed]), "curve": torch.cat(curve), "acc": torch.cat(accs)}
+    for name, v in list(model.state_dict().items()) + list(crit.state_dict().items()):
+        d["final_abs." + name] = v.double().abs().sum()
+    d["final.gEncoder.conv0.weight"] = model.state_dict()["gEncoder.conv0.weight"]
+    d["final.wPrediction.predictors.0.weight_head"] = crit.state_dict()["wPrediction.predictors.0.weight"][:4, :8]
+    save("g6_trainsteps.npz", **d)
+
+    # default-init digests under torch.manual_seed(0) (module construction order of train.py:442-462)
+    torch.manual_seed(0)
+    enc = ref_model.CPCEncoder(64, "layerNorm")
+    ar = ref_model.CPCAR(64, 64, False, 1, mode="GRU", reverse=False)
+    model = ref_model.CPCModel(enc, ar)
+    crit = ref_crit.CPCUnsupersivedCriterion(12, 64, 64, 128, rnnMode="linear", sizeInputSeq=128)
+    i = {}
+    for name, v in list(model.state_dict().items()) + list(crit.state_dict().items()):
+        i["abs." + name] = v.double().abs().sum()
+        i["shape." + name] = np.array(v.shape)
+    save("g6_init_seed0_h64.npz", **i)
+
+
+# ------------------------------------------------------------------ G7 transformer AR
+def g7():
+    d_model, s, n = 32, 16, 2
+    p = synth.transformer_params(d_model, d_model, s, seed=71, dff=2048)
+    net = ref_tr.buildTransformerAR(d_model, d_model, 1, s, False)
+    sd = strip(p, "gAR.")
+    sd.update({k: v for k, v in net.state_dict().items() if k.endswith(".z") or k.endswith(".mask")})
+    net.load_state_dict(sd)
+    net.eval()
+    x = synth.features((n, s, d_model), seed=72, relu=True).requires_grad_(True)
+    g = synth.features((n, s, d_model), seed=73)
+    out = net(x)
+    (out * g).sum().backward()
+    d = {"cfg": np.array([d_model, s, n]), "out": out, "dx": x.grad}
+    for k, v in net.named_parameters():
+        d["grad." + k] = v.grad
+    save("g7_transformer.npz", **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for name in which:
+        globals()[name]()
