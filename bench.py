@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds/sec of CPC training (1.28 s windows @16 kHz, 128 negatives).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one optimisation step of the reference's trainStep (train.py:95-113) on one batch of
+synthetic windows already resident in HBM: model on cat([past, future]) (reference semantics: 2b
+windows through encoder + GRU), InfoNCE criterion, backward, gradient all-reduce (N > 1), fused Adam.
+Workload at every N: BASELINE.json configs[1] per GPU -- CPC-small (hiddenEncoder = hiddenGar = 256,
+GRU x1, nPredicts = 12, 128 negatives, linear predictors), 64 windows of 20480 samples per GPU
+(weak scaling; N = 8 is configs[2]).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WINDOW = 20480
+SECONDS_PER_WINDOW = WINDOW / 16000.0
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CONFIGS = {
+    "small": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU"),
+    "large": dict(hidden=512, layers=2, npred=12, nneg=256, ar="GRU"),
+}
+CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
+
+
+def gemm_nt_algorithmic_flops(b, cfg):
+    """Algorithmic FLOPs (2 per MAC) of everything that runs on gemm_nt_kernel in ONE step, and the
+    number of launches: conv1..4 forward + backward-data (s phase launches each), GRU input projection
+    + its dX, predictor GEMM + its dC.  Padding / junk virtual rows are NOT counted."""
+    h, n = cfg["hidden"], 2 * b
+    lens = [WINDOW]
+    for k, s, p in CONV:
+        lens.append((lens[-1] + 2 * p - k) // s + 1)
+    flops, launches = 0.0, 0
+    for i in range(1, 5):
+        k, s, _p = CONV[i]
+        conv = 2.0 * n * lens[i + 1] * k * h * h
+        flops += 2 * conv                       # forward + backward-data
+        launches += 1 + s
+    t_len = lens[5]
+    din = h
+    for _layer in range(cfg["layers"]):
+        flops += 2 * (2.0 * n * t_len * din * 3 * h)   # GI and dX
+        launches += 2
+        din = h
+    w = t_len - cfg["npred"]
+    flops += 2 * (2.0 * b * w * cfg["npred"] * h * h)   # P and dC
+    launches += 2
+    return flops, launches
+
+
+def build(cfg, device):
+    import cpc2_amd
+    from cpc2_amd.train import buildOptimizer
+    torch.manual_seed(0)                                   # identical init on every rank
+    enc = cpc2_amd.CPCEncoder(cfg["hidden"], "layerNorm")
+    ar = cpc2_amd.CPCAR(cfg["hidden"], cfg["hidden"], False, cfg["layers"], mode=cfg["ar"])
+    model = cpc2_amd.CPCModel(enc, ar).to(device)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(cfg["npred"], cfg["hidden"], cfg["hidden"], cfg["nneg"],
+                                             rnnMode="linear", sizeInputSeq=WINDOW // 160).to(device)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    return model, crit, opt
+
+
+def cpu_baseline(cfg, seconds_budget):
+    """The oracle's train step (CPU restatement of the reference, fp32 torch-CPU ops) timed on this
+    host's cores on a bounded sample of the same workload."""
+    from oracle import cpc_oracle as O, synth
+    from oracle.mt19937 import MT19937
+    torch.set_num_threads(os.cpu_count() or 1)
+    b, h = 8, cfg["hidden"]
+    mp = synth.encoder_params(h, 1)
+    mp.update(synth.gru_params(h, h, cfg["layers"], 2))
+    cp = synth.predictor_params(cfg["npred"], h, h, 3)
+    x = synth.audio_windows(b, WINDOW, 4)
+    params = {k: v.clone().requires_grad_(True) for k, v in list(cp.items()) + list(mp.items())}
+    opt = O.Adam({k: v.data for k, v in params.items()})
+    mt = MT19937(1234)
+
+    def step():
+        tot, _l, _a = O.train_step_loss(x, x, {k: params[k] for k in mp}, {k: params[k] for k in cp}, mt,
+                                        cfg["npred"], cfg["nneg"], cfg["layers"])
+        grads = torch.autograd.grad(tot, list(params.values()))
+        opt.step(dict(zip(params, grads)))
+
+    step()                                                  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(b * SECONDS_PER_WINDOW / dt, 3), "unit": "audio-seconds/sec",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle train step (fwd+bwd+Adam, reference semantics), b={b} windows, {n} steps, "
+                      f"{dt:.2f} s/step, fp32 torch-CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
+    ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="skip the in-situ kernel timing")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from cpc2_amd import _lib
+    from cpc2_amd.train import DataParallelContext, cpcStep
+    lib = _lib.load()
+    model, crit, opt = build(cfg, device)
+    dp = DataParallelContext(opt)
+    crit.seed(1234 + rank)                                  # per-rank negative stream
+    g = torch.Generator().manual_seed(1000 + rank)          # per-rank shard of the synthetic utterances
+    x = (0.05 * torch.randn(args.batch, 1, WINDOW, generator=g)).to(device)
+    label = torch.zeros(args.batch, dtype=torch.long, device=device)
+
+    def step():
+        tot, losses, _acc = cpcStep(x, x, label, model, crit)
+        tot.backward()
+        dp.reduce_and_step()
+        opt.zero_grad()
+        return losses
+
+    for _ in range(args.warmup):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    prof = not args.no_prof
+    if prof:
+        lib.cpc_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.cpc_prof_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = [round(float(v), 4) for v in losses.detach().cpu().view(-1)]
+
+    kernels = {}
+    if prof:
+        for name in ("gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd"):
+            tot, cnt = ctypes.c_double(0), ctypes.c_long(0)
+            lib.cpc_prof_read(name.encode(), ctypes.byref(tot), ctypes.byref(cnt))
+            if cnt.value:
+                kernels[name] = {"ms_per_step": round(tot.value / args.steps, 4), "launches_per_step": cnt.value / args.steps,
+                                 "avg_launch_us": round(1e3 * tot.value / cnt.value, 2)}
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * args.batch * SECONDS_PER_WINDOW * args.steps / elapsed
+        out = {
+            "metric": "audio-seconds/sec CPC training (1.28 s @16 kHz, 128 neg)",
+            "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, GRU x{cfg['layers']}, nPredicts "
+                                   f"{cfg['npred']}, {cfg['nneg']} negatives, linear predictors), {args.batch} x 1.28 s "
+                                   f"windows per GPU, reference trainStep semantics (encoder+AR on 2b windows), "
+                                   f"fwd+bwd+allreduce+Adam",
+                       "windows_per_gpu": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}", "final_losses": final_loss},
+        }
+        if "gemm_nt" in kernels:
+            flops, launches = gemm_nt_algorithmic_flops(args.batch, cfg)
+            k = kernels["gemm_nt"]
+            achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (conv1-4 fwd + bwd-data, GRU/predictor projections)",
+                               "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                               "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
+        out["kernels"] = kernels
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

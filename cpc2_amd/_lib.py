@@ -1,0 +1,119 @@
+"""ctypes binding of libcpc2_hip.so (the C ABI declared in include/cpc2_hip.h).
+
+No fallback: if the library is missing the import of cpc2_amd fails loudly with build
+instructions.  Every call goes through `check()` which raises with cpc_last_error().
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpc2_hip.so")
+
+c_float_p = ctypes.c_void_p      # raw device / host addresses (tensor.data_ptr())
+c_ptr = ctypes.c_void_p
+c_int = ctypes.c_int
+c_long = ctypes.c_long
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/cpc2_hip.h
+SIGNATURES = {
+    "cpc_version": (c_int, []),
+    "cpc_last_error": (ctypes.c_char_p, []),
+    "cpc_prof_enable": (c_int, [c_int]),
+    "cpc_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_long)]),
+    "cpc_gemm_nt": (c_int, [c_ptr, c_long, c_ptr, c_long, c_ptr, c_long, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "cpc_gemm_tn_scratch_bytes": (c_size_t, [c_int, c_int, c_long]),
+    "cpc_gemm_tn": (c_int, [c_ptr, c_long, c_ptr, c_long, c_ptr, c_long, c_int, c_int, c_long, c_ptr, c_size_t, c_ptr]),
+    "cpc_channelnorm_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_channelnorm_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_encoder_frames": (c_int, [c_int]),
+    "cpc_encoder_saved_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cpc_encoder_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cpc_encoder_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_encoder_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_gru_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cpc_gru_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cpc_gru_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_gru_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_mt_create": (c_ptr, [ctypes.c_uint32]),
+    "cpc_mt_destroy": (None, [c_ptr]),
+    "cpc_mt_seed": (c_int, [c_ptr, ctypes.c_uint32]),
+    "cpc_mt_get_state": (c_int, [c_ptr, c_ptr, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "cpc_mt_set_state": (c_int, [c_ptr, c_ptr, c_int, c_int]),
+    "cpc_negidx_sample_host": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "cpc_infonce_saved_bytes": (c_size_t, [c_int] * 6),
+    "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),
+    "cpc_infonce_forward": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),
+    "cpc_infonce_backward": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
+    "cpc_adam_step": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_long, c_int, c_float, c_float, c_float, c_float, c_float, c_ptr]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built and cpc2_amd has no fallback. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python cpc2_amd/build.py`).")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().cpc_last_error().decode(errors="replace")
+        kind = ValueError if status == -1 else RuntimeError
+        raise kind(f"libcpc2_hip {what} failed ({status}): {msg}")
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cpc2_amd runs only on a GPU (HIP) device: got a tensor on "
+                               f"'{t.device}'. There is no CPU fallback.")
+
+
+def f32c(t):
+    """contiguous fp32 view/copy of t (no copy when already so)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"cpc2_amd kernels are fp32 only (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+# grow-only scratch arena per device; every kernel is enqueued on the current stream in program
+# order, so one buffer serves all calls
+_scratch = {}
+
+
+def scratch(nbytes, device):
+    key = (device.type, device.index)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            del _scratch[key]
+        buf = torch.empty(int(nbytes) + 4096, dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf

@@ -1,0 +1,257 @@
+"""Drop-in counterpart of the reference's unsupervised CPC criterion.
+
+Mirrors /root/reference/cpc/criterion/criterion.py: PredictionNetwork (:97-173, linear branch
+:144-150), BaseCriterion (:176-183), NoneCriterion (:185-191), CPCUnsupersivedCriterion (:193-363)
+-- same constructor/forward signatures, attribute names and state-dict keys
+(`wPrediction.predictors.{k}.weight`).  The K candidate tensors of sampleClean (:237-286) are never
+materialised: the fused HIP kernel gathers negatives on the fly from the index stream.
+
+Negative indices are drawn on the HOST with the same MT19937 stream torch's CPU generator would
+produce (the reference's CPU path); by default the criterion consumes -- and advances -- torch's
+global CPU generator, so `torch.manual_seed(s)` gives bit-identical indices to the reference.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, f32c, ptr, require_gpu, scratch, stream_ptr
+
+
+# --------------------------------------------------------------------------- index sampler
+class NegativeSampler:
+    """Host MT19937 sampler (cpc_negidx_sample_host) + pinned staging ring for the H2D copy."""
+
+    RING = 4
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p(self._lib.cpc_mt_create(5489))
+        if not self._h:
+            raise MemoryError("cpc_mt_create failed")
+        self.follow_torch = True      # consume torch's global CPU generator (reference semantics)
+        self._ring, self._events, self._slot = {}, {}, 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.cpc_mt_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def seed(self, seed):
+        """Private stream seeded like torch.manual_seed(seed); stops following the global generator."""
+        check(self._lib.cpc_mt_seed(self._h, ctypes.c_uint32(int(seed) & 0xFFFFFFFF)), "mt_seed")
+        self.follow_torch = False
+
+    # torch CPU generator legacy state: u64 seed, i32 left, i32 seeded, u64 next, u64 mt[624], ...
+    def _pull_torch_state(self):
+        st = torch.get_rng_state().numpy()
+        left = int(st[8:12].view(np.int32)[0])
+        nxt = int(st[16:24].view(np.uint64)[0])
+        mt = np.ascontiguousarray(st[24:24 + 624 * 8].view(np.uint64).astype(np.uint32))
+        check(self._lib.cpc_mt_set_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), left, nxt), "mt_set_state")
+        return st
+
+    def _push_torch_state(self, st):
+        mt = np.empty(624, dtype=np.uint32)
+        left, nxt = ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.cpc_mt_get_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), ctypes.byref(left),
+                                         ctypes.byref(nxt)), "mt_get_state")
+        st = st.copy()
+        st[8:12].view(np.int32)[0] = left.value
+        st[16:24].view(np.uint64)[0] = nxt.value
+        st[24:24 + 624 * 8].view(np.uint64)[:] = mt.astype(np.uint64)
+        torch.set_rng_state(torch.from_numpy(st))
+
+    def sample_host(self, batch, seq_len, window, n_neg, out=None, want_parts=False):
+        """int32 extIdx [batch, n_neg, window] on the host (criterion.py:247-266)."""
+        n = batch * n_neg * window
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32)
+        bidx = torch.empty(n, dtype=torch.int64) if want_parts else None
+        sidx = torch.empty(n, dtype=torch.int64) if want_parts else None
+        st = self._pull_torch_state() if self.follow_torch else None
+        check(self._lib.cpc_negidx_sample_host(self._h, batch, seq_len, window, n_neg, ptr(out), ptr(bidx), ptr(sidx)),
+              "negidx_sample_host")
+        if st is not None:
+            self._push_torch_state(st)
+        return (out, bidx, sidx) if want_parts else out
+
+    def sample(self, batch, seq_len, window, n_neg, device):
+        """Device int32 extIdx; staged through a small ring of pinned buffers (async copy)."""
+        n = batch * n_neg * window
+        key = (n, str(device))
+        if key not in self._ring:
+            self._ring[key] = [torch.empty(n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+            self._events[key] = [None] * self.RING
+        slot = self._slot % self.RING
+        self._slot += 1
+        ev = self._events[key][slot]
+        if ev is not None:
+            ev.synchronize()          # the copy that last used this staging buffer has finished
+        host = self._ring[key][slot]
+        self.sample_host(batch, seq_len, window, n_neg, out=host)
+        dev = host.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._events[key][slot] = ev
+        return dev
+
+
+# --------------------------------------------------------------------------- fused InfoNCE
+class _InfoNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, z, wpred, ext_idx, weights, n_neg):
+        require_gpu(c, z, wpred, ext_idx)
+        lib = _lib.load()
+        c, z, wpred = f32c(c), f32c(z), f32c(wpred)
+        b, t, dim_ar = c.shape
+        k, dim_enc, _ = wpred.shape
+        if z.shape != (b, t, dim_enc) or wpred.shape[2] != dim_ar:
+            raise ValueError(f"shape mismatch c={tuple(c.shape)} z={tuple(z.shape)} W={tuple(wpred.shape)}")
+        if ext_idx.dtype != torch.int32 or ext_idx.numel() != b * n_neg * (t - k):
+            raise ValueError("ext_idx must be int32 [b, n_neg, W]")
+        w = f32c(weights) if weights is not None else None
+        nsaved = lib.cpc_infonce_saved_bytes(b, t, k, dim_ar, dim_enc, n_neg)
+        nscratch = lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg)
+        if nsaved == 0:
+            check(-1, "infonce shape query")
+        losses = torch.empty(k, dtype=torch.float32, device=c.device)
+        acc = torch.empty(k, dtype=torch.float32, device=c.device)
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=c.device)
+        sc = scratch(nscratch, c.device)
+        check(lib.cpc_infonce_forward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(losses), ptr(acc),
+                                      ptr(saved), ptr(sc), b, t, k, dim_ar, dim_enc, n_neg, stream_ptr(c.device)),
+              "infonce_forward")
+        ctx.save_for_backward(c, z, wpred, ext_idx, w, saved)
+        ctx.dims = (b, t, k, dim_ar, dim_enc, n_neg)
+        ctx.mark_non_differentiable(acc)
+        return losses, acc
+
+    @staticmethod
+    def backward(ctx, dlosses, _dacc):
+        lib = _lib.load()
+        c, z, wpred, ext_idx, w, saved = ctx.saved_tensors
+        b, t, k, dim_ar, dim_enc, n_neg = ctx.dims
+        dlosses = f32c(dlosses)
+        dc, dz, dw = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wpred)
+        sc = scratch(lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg), c.device)
+        check(lib.cpc_infonce_backward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                       ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
+                                       stream_ptr(c.device)), "infonce_backward")
+        return dc, dz, dw, None, None, None
+
+
+# --------------------------------------------------------------------------- modules
+class PredictionNetwork(nn.Module):
+    """criterion.py:97-173, linear predictors (the `else` branch :144-150).  Holds the K
+    nn.Linear(dimOutputAR, dimOutputEncoder, bias=False) under `predictors` (same keys/init)."""
+
+    def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=None, dropout=False,
+                 sizeInputSeq=116, transformer_pruning=0):
+        super(PredictionNetwork, self).__init__()
+        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12", "transformer"):
+            raise NotImplementedError(
+                f"rnnMode={rnnMode!r}: only linear predictors (rnnMode='linear') have an MI355X kernel path")
+        if dropout:
+            raise NotImplementedError("predictor dropout is not supported by the MI355X hot path")
+        self.predictors = nn.ModuleList()
+        self.RESIDUAL_STD = 0.01
+        self.dimOutputAR = dimOutputAR
+        self.dropout = None
+        for _ in range(nPredicts):
+            self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
+            if dimOutputEncoder > dimOutputAR:
+                residual = dimOutputEncoder - dimOutputAR
+                self.predictors[-1].weight.data.copy_(torch.cat([
+                    torch.randn(dimOutputAR, dimOutputAR),
+                    self.RESIDUAL_STD * torch.randn(residual, dimOutputAR)], dim=0))
+
+    def packed_weight(self):
+        """[K, dimOutputEncoder, dimOutputAR]; autograd splits the gradient back per predictor."""
+        return torch.stack([p.weight for p in self.predictors], dim=0)
+
+
+class BaseCriterion(nn.Module):
+
+    def warmUp(self):
+        return False
+
+    def update(self):
+        return
+
+
+class NoneCriterion(BaseCriterion):
+    def __init__(self):
+        super(NoneCriterion, self).__init__()
+
+    def forward(self, cFeature, encodedData, label):
+        return torch.zeros(1, 1, device=cFeature.device), torch.zeros(1, 1, device=cFeature.device)
+
+
+class CPCUnsupersivedCriterion(BaseCriterion):
+    """criterion.py:193-363."""
+
+    def __init__(self,
+                 nPredicts,             # Number of steps
+                 dimOutputAR,           # Dimension of G_ar
+                 dimOutputEncoder,      # Dimension of the convolutional net
+                 negativeSamplingExt,   # Number of negative samples to draw
+                 mode=None,
+                 rnnMode=False,
+                 dropout=False,
+                 nSpeakers=0,
+                 sizeInputSeq=116,
+                 multihead_rnn=False,
+                 transformer_pruning=0,
+                 n_skipped=0,
+                 growth_rate=None,
+                 inflection_point_x=None):
+        super(CPCUnsupersivedCriterion, self).__init__()
+        if multihead_rnn:
+            raise NotImplementedError("multihead_rnn predictors are not on the MI355X hot path")
+        self.wPrediction = PredictionNetwork(nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=rnnMode,
+                                             dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts)
+        self.nSkipped = n_skipped
+        self.nPredicts = nPredicts
+        self.negativeSamplingExt = negativeSamplingExt
+        self.growth_rate = growth_rate
+        self.inflection_point_x = inflection_point_x
+        self.weighting_function = lambda x: 0.00001 + 1 / (1 + torch.exp(-growth_rate * (x - inflection_point_x)))
+        if mode not in [None, "reverse"]:
+            raise ValueError("Invalid mode")
+        self.mode = mode
+        self.sampler = NegativeSampler()
+
+    def seed(self, seed):
+        """Use a private negative-index stream (e.g. one per data-parallel rank)."""
+        self.sampler.seed(seed)
+
+    def _prepare(self, cFeature, encodedData):
+        if self.mode == "reverse":                      # criterion.py:292-294
+            encodedData = torch.flip(encodedData, [1])
+            cFeature = torch.flip(cFeature, [1])
+        return cFeature, encodedData
+
+    def sampleIndices(self, batchSize, nNegativeExt, windowSize, device):
+        """Device int32 extIdx [batchSize, negativeSamplingExt, windowSize] (criterion.py:247-266)."""
+        return self.sampler.sample(batchSize, nNegativeExt, windowSize, self.negativeSamplingExt, device)
+
+    def forward(self, cFeature, encodedData, label, signal_quality=None):
+        batchSize, seqSize, _ = cFeature.size()
+        windowSize = seqSize - self.nPredicts
+        cFeature, encodedData = self._prepare(cFeature, encodedData)
+        if signal_quality is not None:                  # criterion.py:334-338
+            quality_weighting = self.weighting_function(signal_quality.mean(dim=1))
+            quality_weighting = quality_weighting.unsqueeze(1).repeat(1, windowSize).contiguous().view(-1).float()
+        else:
+            quality_weighting = None                    # ones (criterion.py:340)
+        extIdx = self.sampleIndices(batchSize, seqSize, windowSize, cFeature.device)
+        losses, acc = _InfoNCEFn.apply(cFeature, encodedData, self.wPrediction.packed_weight(), extIdx,
+                                       quality_weighting, self.negativeSamplingExt)
+        losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
+        return losses.view(1, -1), acc.view(1, -1)

@@ -1,0 +1,110 @@
+// Internal helpers shared by the HIP translation units of libcpc2_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/cpc2_hip.h"
+
+namespace cpc {
+
+void set_error(const char *fmt, ...);
+
+#define CPC_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            cpc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return CPC_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define CPC_CHECK_LAUNCH(name)                                                           \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            cpc::set_error("launch of %s failed: %s", name, hipGetErrorString(_e));      \
+            return CPC_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define CPC_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            cpc::set_error(__VA_ARGS__);                                                 \
+            return CPC_ERR_INVALID;                                                      \
+        }                                                                                \
+    } while (0)
+
+#define CPC_TRY(expr)                                                                    \
+    do {                                                                                 \
+        int _s = (expr);                                                                 \
+        if (_s != CPC_OK) return _s;                                                     \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// Bump allocator over a caller-provided buffer (256-byte aligned carves).
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+    template <typename T> T *take(size_t count) {
+        off = align_up(off, 256);
+        T *p = reinterpret_cast<T *>(base ? base + off : nullptr);
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t used() const { return align_up(off, 256); }
+};
+
+// ---- optional in-situ kernel timing (see cpc_prof_* in cpc2_hip.h) ----
+enum ProfSlot { PROF_GEMM_NT = 0, PROF_GEMM_TN, PROF_NCE_FWD, PROF_NCE_BWD, PROF_GRU_FWD, PROF_GRU_BWD, PROF_CONV0_FWD,
+                PROF_CONV0_BWD, PROF_SLOTS };
+class ProfScope {
+public:
+    ProfScope(int slot, hipStream_t st);
+    ~ProfScope();
+private:
+    int slot_;
+    hipStream_t st_;
+    hipEvent_t a_, b_;
+    bool active_;
+};
+
+// ---- encoder geometry (model.py:85-94) ----
+struct ConvGeom { int k, s, p; };
+static const ConvGeom kConv[5] = {{10, 5, 3}, {8, 4, 2}, {4, 2, 1}, {4, 2, 1}, {4, 2, 1}};
+
+// ---- row mapping of a GEMM epilogue: virtual row m -> output row (or skip) ----
+struct RowMap {
+    int enabled;      // 0: crow = m
+    int rv;           // virtual rows per group (sample)
+    int out_stride;   // l = t*out_stride + out_off
+    int out_off;
+    int l_max;        // valid l in [0, l_max)
+    int rows_out;     // output rows per group
+};
+
+// ---- internal launchers (defined in gemm_f32.hip / rowops.hip) ----
+int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
+            long M, int N, int K, const RowMap &map, hipStream_t st);
+size_t gemm_tn_scratch_bytes(int M, int N, long R);
+// conv_cin > 0: C is a Conv1d weight [M][conv_cin][conv_k] and column j*conv_cin+ci goes to [ci][j]
+int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, long R,
+            void *scratch, size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st);
+
+// out[c] = sum_r part[r*ld + c]
+int colsum(const float *part, long rows, long ld, int width, float *out, hipStream_t st);
+// column sums of a [rows][width] matrix with row stride ld (two-stage; scratch >= colsum_scratch_bytes)
+size_t colsum_rows_scratch_bytes(int width);
+int colsum_rows(const float *a, long ld, long rows, int width, float *out, void *scratch, hipStream_t st);
+
+// weight re-layouts
+int permute_conv_fwd(const float *w, float *wr, int cout, int cin, int k, hipStream_t st);          // [co][j*cin+ci]
+int permute_conv_dgrad(const float *w, float *bd, int cout, int cin, int k, int s, hipStream_t st); // [j][ci][2*cout]
+int transpose2d(const float *a, float *at, int rows, int cols, hipStream_t st);                      // at[c][r]=a[r][c]
+
+}  // namespace cpc

@@ -1,0 +1,634 @@
+// CPCEncoder on gfx950: conv0 + ChannelNorm + ReLU fused (HBM-bound), conv1..4 as implicit GEMMs on
+// the f32 MFMA over channel-last activations, ChannelNorm(+ReLU) row kernels, and the matching backward.
+//
+// Reference: /root/reference/cpc/model.py:63-108 (CPCEncoder), :27-60 (ChannelNorm).
+//
+// Layouts (H = hidden, N = windows, L[i] = length after layer i-1, L[0] = samples):
+//   Y_i  (i=0..3)  output of layer i = input of layer i+1:  [N][R_i][H], R_i = s_{i+1} * (L[i+2] + 2);
+//                  data row of position l is row l + p_{i+1}; the other rows are zero (conv padding).
+//                  Output frame t of layer i+1 then reads the k*H CONTIGUOUS floats at row t*s, so the
+//                  conv is a GEMM whose A rows overlap: A(m) = Y_i + m*s*H, m = n*Rv + t, Rv = L[i+2]+2
+//                  (rows t >= L[i+2] of a sample are junk and ignored downstream).
+//   Xh_i (i=1..4)  normalised pre-activation xhat: [N*Rv_i][H] (conv output, normalised in place)
+//   dU_i           gradient wrt conv output, SHIFTED by one row: row n*Rv + t + 1; rows 0 and > L of every
+//                  sample are zero.  Backward-data (k == 2s) then is, per phase j in [0,s), a GEMM with
+//                  A(m) = dU + m*H (rows t_hi-1 and t_hi, 2H contiguous floats) and weight-gradient a TN
+//                  GEMM over m with A(m) = dU + (m+1)*H, B(m) = Y_{i-1} + m*s*H.
+#include "common.h"
+
+#include <algorithm>
+
+namespace cpc {
+
+// ------------------------------------------------------------------------------------------------
+// Row kernels: a row of H channels is owned by a group of G lanes, 4*VPL channels per lane, as float4s
+// v*G + gl (v < VPL) so that a group's accesses are contiguous.
+template <int H> struct RowCfg {
+    static_assert(H % 32 == 0, "hidden size must be a multiple of 32");
+    static constexpr int G = (H / 4 < 64) ? H / 4 : 64;
+    static constexpr int VPL = H / (4 * G);
+    static constexpr int RPW = 64 / G;   // rows per wave pass
+};
+
+template <int G> __device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+constexpr int C0_TB = 64;     // conv0: output rows per block tile
+constexpr int C0_K = 10, C0_S = 5, C0_P = 3;
+
+struct Conv0Args {
+    const float *x;        // [N][L0]
+    const float *w;        // [H][10]
+    const float *b;        // [H]
+    const float *gamma;    // [H]
+    const float *beta;     // [H]
+    float *y;              // Y0 [N][R0][H]
+    float *stats;          // [N*L1][2] mean, rstd
+    int N, L0, L1, R0, halo;
+    float eps;
+    // backward only
+    const float *dy;       // [N][L1][H]
+    float *part;           // [slots][13][H]
+    int tiles_per_sample, n_tiles;
+};
+
+template <int H> __device__ __forceinline__ void conv0_load_segment(float *xs, const Conv0Args &a, int n, int t0)
+{
+    // xs[i] = x[n][5*t0 - 3 + i], i < 5*TB + 5, zero outside [0, L0)
+    const float *xn = a.x + (long)n * a.L0;
+    for (int i = threadIdx.x; i < C0_S * C0_TB + C0_K - C0_S; i += blockDim.x) {
+        const int pos = C0_S * t0 - C0_P + i;
+        xs[i] = (pos >= 0 && pos < a.L0) ? xn[pos] : 0.f;
+    }
+}
+
+template <int H> __global__ __launch_bounds__(256) void conv0_fwd_kernel(Conv0Args a)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL, RPW = Cfg::RPW;
+    __shared__ float xs[C0_S * C0_TB + 8];
+
+    const int tile = blockIdx.x;
+    const int n = tile / a.tiles_per_sample;
+    const int t0 = (tile - n * a.tiles_per_sample) * C0_TB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gi = lane / G;
+
+    conv0_load_segment<H>(xs, a, n, t0);
+
+    float wreg[VPL][4][C0_K], breg[VPL][4], gam[VPL][4], bet[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (v * G + gl) * 4 + e;
+#pragma unroll
+            for (int j = 0; j < C0_K; ++j) wreg[v][e][j] = a.w[c * C0_K + j];
+            breg[v][e] = a.b[c];
+            gam[v][e] = a.gamma[c];
+            bet[v][e] = a.beta[c];
+        }
+
+    // zero the halo rows of this sample (conv padding of layer 1)
+    if (t0 == 0 || t0 + C0_TB >= a.L1) {
+        const int lo0 = 0, hi0 = a.halo;                    // front halo
+        const int lo1 = a.halo + a.L1, hi1 = a.R0;          // back halo
+        const int nfront = (t0 == 0) ? (hi0 - lo0) : 0;
+        const int nback = (t0 + C0_TB >= a.L1) ? (hi1 - lo1) : 0;
+        const int total4 = (nfront + nback) * (H / 4);
+        for (int i = threadIdx.x; i < total4; i += blockDim.x) {
+            int row = i / (H / 4);
+            const int c4 = i - row * (H / 4);
+            row = row < nfront ? lo0 + row : lo1 + (row - nfront);
+            reinterpret_cast<float4 *>(a.y + ((long)n * a.R0 + row) * H)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    constexpr int ROWS_PER_PASS = 4 * RPW;
+    for (int it = 0; it < C0_TB / ROWS_PER_PASS; ++it) {
+        const int slot = it * ROWS_PER_PASS + wave * RPW + gi;
+        const int t = t0 + slot;
+        float xr[C0_K];
+#pragma unroll
+        for (int j = 0; j < C0_K; ++j) xr[j] = xs[C0_S * slot + j];
+
+        float u[VPL][4];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = breg[v][e];
+#pragma unroll
+                for (int j = 0; j < C0_K; ++j) acc = fmaf(wreg[v][e][j], xr[j], acc);
+                u[v][e] = acc;
+                s += acc;
+            }
+        const float mean = group_sum<G>(s) * (1.f / H);
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u[v][e] -= mean;
+                ss = fmaf(u[v][e], u[v][e], ss);
+            }
+        const float rstd = rsqrtf(group_sum<G>(ss) * (1.f / (H - 1)) + a.eps);
+        if (t < a.L1) {
+            float *yrow = a.y + ((long)n * a.R0 + a.halo + t) * H;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float4 o;
+                o.x = fmaxf(fmaf(u[v][0] * rstd, gam[v][0], bet[v][0]), 0.f);
+                o.y = fmaxf(fmaf(u[v][1] * rstd, gam[v][1], bet[v][1]), 0.f);
+                o.z = fmaxf(fmaf(u[v][2] * rstd, gam[v][2], bet[v][2]), 0.f);
+                o.w = fmaxf(fmaf(u[v][3] * rstd, gam[v][3], bet[v][3]), 0.f);
+                reinterpret_cast<float4 *>(yrow)[v * G + gl] = o;
+            }
+            if (gl == 0) {
+                a.stats[((long)n * a.L1 + t) * 2 + 0] = mean;
+                a.stats[((long)n * a.L1 + t) * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
+// Backward of relu(norm(conv0(x))): recomputes the conv (10 MACs per output) instead of saving it.
+// Persistent blocks stride over tiles; every lane group keeps its 13*4*VPL partial sums in registers
+// and writes them once: part[slot][q][c], q = 0..9 dW tap, 10 db, 11 dgamma, 12 dbeta.
+template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Args a)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL, RPW = Cfg::RPW;
+    __shared__ float xs[C0_S * C0_TB + 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gi = lane / G;
+
+    float wreg[VPL][4][C0_K], breg[VPL][4], gam[VPL][4], bet[VPL][4];
+    float dwacc[VPL][4][C0_K], dbacc[VPL][4], dgacc[VPL][4], dbeacc[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (v * G + gl) * 4 + e;
+#pragma unroll
+            for (int j = 0; j < C0_K; ++j) { wreg[v][e][j] = a.w[c * C0_K + j]; dwacc[v][e][j] = 0.f; }
+            breg[v][e] = a.b[c];
+            gam[v][e] = a.gamma[c];
+            bet[v][e] = a.beta[c];
+            dbacc[v][e] = dgacc[v][e] = dbeacc[v][e] = 0.f;
+        }
+
+    constexpr int ROWS_PER_PASS = 4 * RPW;
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int n = tile / a.tiles_per_sample;
+        const int t0 = (tile - n * a.tiles_per_sample) * C0_TB;
+        __syncthreads();
+        conv0_load_segment<H>(xs, a, n, t0);
+        __syncthreads();
+        for (int it = 0; it < C0_TB / ROWS_PER_PASS; ++it) {
+            const int slot = it * ROWS_PER_PASS + wave * RPW + gi;
+            const int t = t0 + slot;
+            const bool valid = t < a.L1;
+            float xr[C0_K];
+#pragma unroll
+            for (int j = 0; j < C0_K; ++j) xr[j] = xs[C0_S * slot + j];
+            float mean = 0.f, rstd = 0.f;
+            if (valid) {
+                mean = a.stats[((long)n * a.L1 + t) * 2 + 0];
+                rstd = a.stats[((long)n * a.L1 + t) * 2 + 1];
+            }
+            const float *dyrow = a.dy + ((long)n * a.L1 + (valid ? t : 0)) * H;
+            float xh[VPL][4], gx[VPL][4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) g4 = reinterpret_cast<const float4 *>(dyrow)[v * G + gl];
+                const float gy[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float acc = breg[v][e];
+#pragma unroll
+                    for (int j = 0; j < C0_K; ++j) acc = fmaf(wreg[v][e][j], xr[j], acc);
+                    const float xhat = (acc - mean) * rstd;
+                    const float act = fmaf(xhat, gam[v][e], bet[v][e]);
+                    const float g = act > 0.f ? gy[e] : 0.f;
+                    dbeacc[v][e] += g;
+                    dgacc[v][e] = fmaf(g, xhat, dgacc[v][e]);
+                    xh[v][e] = xhat;
+                    gx[v][e] = g * gam[v][e];
+                    s1 += gx[v][e];
+                    s2 = fmaf(gx[v][e], xhat, s2);
+                }
+            }
+            s1 = group_sum<G>(s1) * (1.f / H);
+            s2 = group_sum<G>(s2) * (1.f / (H - 1));
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float du = rstd * (gx[v][e] - s1 - xh[v][e] * s2);   // 0 when !valid (rstd = 0)
+                    dbacc[v][e] += du;
+#pragma unroll
+                    for (int j = 0; j < C0_K; ++j) dwacc[v][e][j] = fmaf(du, xr[j], dwacc[v][e][j]);
+                }
+        }
+    }
+
+    const int slot_id = (blockIdx.x * 4 + wave) * RPW + gi;
+    float *pp = a.part + (long)slot_id * 13 * H;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (v * G + gl) * 4 + e;
+#pragma unroll
+            for (int j = 0; j < C0_K; ++j) pp[j * H + c] = dwacc[v][e][j];
+            pp[10 * H + c] = dbacc[v][e];
+            pp[11 * H + c] = dgacc[v][e];
+            pp[12 * H + c] = dbeacc[v][e];
+        }
+}
+
+// sums[13][H] -> conv0.weight grad [H][1][10], bias grad, norm weight/bias grads
+__global__ void conv0_finalize_kernel(const float *sums, float *dw, float *db, float *dgamma, float *dbeta, int H)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    for (int j = 0; j < C0_K; ++j) dw[c * C0_K + j] = sums[j * H + c];
+    db[c] = sums[10 * H + c];
+    dgamma[c] = sums[11 * H + c];
+    dbeta[c] = sums[12 * H + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+struct NormArgs {
+    float *u;              // fwd: conv output [N*Rv][H], overwritten by xhat.  bwd: xhat (read)
+    const float *gamma, *beta;
+    float *rstd;           // [N*Rv]
+    float *y;              // fwd: next layer input [N][Rnext][H] (or z)
+    int N, Lout, Rv, Rnext, halo;
+    float eps;
+    // backward
+    const float *dy;       // [N][Lout][H]
+    float *du;             // [N*Rv + 1][H], shifted by one row
+    float *part;           // [slots][3][H]: dgamma, dbeta, dbias
+};
+
+template <int H> __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs a)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL, RPW = Cfg::RPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gi = lane / G;
+    float gam[VPL][4], bet[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gam[v][e] = a.gamma[(v * G + gl) * 4 + e];
+            bet[v][e] = a.beta[(v * G + gl) * 4 + e];
+        }
+    const long total = (long)a.N * a.Rnext;
+    const long stride = (long)gridDim.x * 4 * RPW;
+    for (long base = (long)blockIdx.x * 4 * RPW; base < total; base += stride) {
+        const long row = base + wave * RPW + gi;          // row of Y
+        const bool in_range = row < total;
+        const int n = in_range ? (int)(row / a.Rnext) : 0;
+        const int t = in_range ? (int)(row - (long)n * a.Rnext) - a.halo : -1;
+        const bool valid = in_range && t >= 0 && t < a.Lout;
+        const long m = (long)n * a.Rv + (valid ? t : 0);
+        float4 x4[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            x4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) x4[v] = reinterpret_cast<const float4 *>(a.u + m * H)[v * G + gl];
+            s += (x4[v].x + x4[v].y) + (x4[v].z + x4[v].w);
+        }
+        const float mean = group_sum<G>(s) * (1.f / H);
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            x4[v].x -= mean; x4[v].y -= mean; x4[v].z -= mean; x4[v].w -= mean;
+            ss = fmaf(x4[v].x, x4[v].x, ss); ss = fmaf(x4[v].y, x4[v].y, ss);
+            ss = fmaf(x4[v].z, x4[v].z, ss); ss = fmaf(x4[v].w, x4[v].w, ss);
+        }
+        const float rstd = rsqrtf(group_sum<G>(ss) * (1.f / (H - 1)) + a.eps);
+        if (!in_range) continue;
+        float *yrow = a.y + row * H;
+        if (valid) {
+            if (gl == 0) a.rstd[m] = rstd;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float4 xh, o;
+                xh.x = x4[v].x * rstd; xh.y = x4[v].y * rstd; xh.z = x4[v].z * rstd; xh.w = x4[v].w * rstd;
+                reinterpret_cast<float4 *>(a.u + m * H)[v * G + gl] = xh;
+                o.x = fmaxf(fmaf(xh.x, gam[v][0], bet[v][0]), 0.f);
+                o.y = fmaxf(fmaf(xh.y, gam[v][1], bet[v][1]), 0.f);
+                o.z = fmaxf(fmaf(xh.z, gam[v][2], bet[v][2]), 0.f);
+                o.w = fmaxf(fmaf(xh.w, gam[v][3], bet[v][3]), 0.f);
+                reinterpret_cast<float4 *>(yrow)[v * G + gl] = o;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) reinterpret_cast<float4 *>(yrow)[v * G + gl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+template <int H> __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs a)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL, RPW = Cfg::RPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gi = lane / G;
+    float gam[VPL][4], bet[VPL][4], dg[VPL][4], dbe[VPL][4], dbi[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gam[v][e] = a.gamma[(v * G + gl) * 4 + e];
+            bet[v][e] = a.beta[(v * G + gl) * 4 + e];
+            dg[v][e] = dbe[v][e] = dbi[v][e] = 0.f;
+        }
+    const long total = (long)a.N * a.Rv + 1;                 // rows of dU
+    const long stride = (long)gridDim.x * 4 * RPW;
+    for (long base = (long)blockIdx.x * 4 * RPW; base < total; base += stride) {
+        const long row = base + wave * RPW + gi;
+        const bool in_range = row < total;
+        const int n = in_range ? (int)(row / a.Rv) : 0;
+        const int t = in_range ? (int)(row - (long)n * a.Rv) - 1 : -1;
+        const bool valid = in_range && n < a.N && t >= 0 && t < a.Lout;
+        const long m = (long)n * a.Rv + (valid ? t : 0);
+        const float rstd = valid ? a.rstd[m] : 0.f;
+        float xh[VPL][4], gx[VPL][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = x4;
+            if (valid) {
+                x4 = reinterpret_cast<const float4 *>(a.u + m * H)[v * G + gl];
+                g4 = reinterpret_cast<const float4 *>(a.dy + ((long)n * a.Lout + t) * H)[v * G + gl];
+            }
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float act = fmaf(xv[e], gam[v][e], bet[v][e]);
+                const float g = (valid && act > 0.f) ? gv[e] : 0.f;
+                dbe[v][e] += g;
+                dg[v][e] = fmaf(g, xv[e], dg[v][e]);
+                xh[v][e] = xv[e];
+                gx[v][e] = g * gam[v][e];
+                s1 += gx[v][e];
+                s2 = fmaf(gx[v][e], xv[e], s2);
+            }
+        }
+        s1 = group_sum<G>(s1) * (1.f / H);
+        s2 = group_sum<G>(s2) * (1.f / (H - 1));
+        if (!in_range) continue;
+        float *durow = a.du + row * H;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = rstd * (gx[v][e] - s1 - xh[v][e] * s2);
+                dbi[v][e] += o[e];
+            }
+            reinterpret_cast<float4 *>(durow)[v * G + gl] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    const int slot_id = (blockIdx.x * 4 + wave) * RPW + gi;
+    float *pp = a.part + (long)slot_id * 3 * H;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (v * G + gl) * 4 + e;
+            pp[c] = dg[v][e];
+            pp[H + c] = dbe[v][e];
+            pp[2 * H + c] = dbi[v][e];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct EncLayout {
+    int H, N;
+    int L[6];        // L[0] = samples, L[i+1] = frames after layer i
+    int Rv[5];       // virtual GEMM rows per sample of layer i (i >= 1): L[i+1] + 2
+    int R[4];        // rows per sample of Y_i (i = 0..3): s_{i+1} * Rv[i+1]
+    // saved
+    float *Y[4];
+    float *Xh[5];    // index 1..4
+    float *rstd[5];  // index 1..4
+    float *stats0;
+    size_t saved_bytes;
+    // scratch
+    float *Wr;       // permuted weights (fwd operand) / dgrad operand
+    float *dYa, *dYb, *dU, *part, *sums, *tn;
+    size_t tn_bytes;
+    size_t scratch_bytes;
+};
+
+constexpr int NORM_BWD_BLOCKS = 256;
+constexpr int CONV0_BWD_BLOCKS = 512;
+
+static bool supported_hidden(int H) { return H == 32 || H == 64 || H == 128 || H == 256 || H == 512; }
+
+static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void *scratch)
+{
+    CPC_REQUIRE(supported_hidden(H), "encoder: hidden size %d not supported (32, 64, 128, 256, 512)", H);
+    CPC_REQUIRE(N > 0 && length >= 400, "encoder: need n_windows > 0 and length >= 400 (got %d, %d)", N, length);
+    e.H = H; e.N = N;
+    e.L[0] = length;
+    for (int i = 0; i < 5; ++i) {
+        e.L[i + 1] = (e.L[i] + 2 * kConv[i].p - kConv[i].k) / kConv[i].s + 1;
+        CPC_REQUIRE(e.L[i + 1] >= 1, "encoder: input too short");
+    }
+    for (int i = 1; i < 5; ++i) e.Rv[i] = e.L[i + 1] + 2;
+    e.Rv[0] = 0;
+    for (int i = 0; i < 4; ++i) e.R[i] = kConv[i + 1].s * e.Rv[i + 1];
+
+    Carver sv(saved);
+    for (int i = 0; i < 4; ++i) e.Y[i] = sv.take<float>(((size_t)N * e.R[i] + kConv[i + 1].k) * H);   // + slack rows
+    e.Xh[0] = nullptr; e.rstd[0] = nullptr;
+    for (int i = 1; i < 5; ++i) {
+        e.Xh[i] = sv.take<float>((size_t)N * e.Rv[i] * H);
+        e.rstd[i] = sv.take<float>((size_t)N * e.Rv[i]);
+    }
+    e.stats0 = sv.take<float>((size_t)N * e.L[1] * 2);
+    e.saved_bytes = sv.used();
+
+    Carver sc(scratch);
+    e.Wr = sc.take<float>((size_t)8 * H * H);                         // max k*H*H (k = 8) == s*H*2H (s = 4)
+    e.dYa = sc.take<float>((size_t)N * e.L[1] * H);
+    e.dYb = sc.take<float>((size_t)N * e.L[2] * H);
+    e.dU = sc.take<float>(((size_t)N * e.Rv[1] + 2) * H);
+    const size_t rpw = 64 / std::min(64, H / 4);            // lane groups (rows) per wave
+    const size_t part_floats = std::max((size_t)CONV0_BWD_BLOCKS * 4 * rpw * 13 * H,
+                                        (size_t)NORM_BWD_BLOCKS * 4 * rpw * 3 * H);
+    e.part = sc.take<float>(part_floats);
+    e.sums = sc.take<float>((size_t)13 * H);
+    e.tn_bytes = 0;
+    for (int i = 1; i < 5; ++i)
+        e.tn_bytes = std::max(e.tn_bytes, gemm_tn_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]));
+    e.tn = sc.take<float>(e.tn_bytes / sizeof(float));
+    e.scratch_bytes = sc.used();
+    return CPC_OK;
+}
+
+#define CPC_DISPATCH_H(H, ...)                                  \
+    switch (H) {                                                \
+    case 32: { constexpr int HH = 32; __VA_ARGS__; } break;    \
+    case 64: { constexpr int HH = 64; __VA_ARGS__; } break;    \
+    case 128: { constexpr int HH = 128; __VA_ARGS__; } break;  \
+    case 256: { constexpr int HH = 256; __VA_ARGS__; } break;  \
+    case 512: { constexpr int HH = 512; __VA_ARGS__; } break;  \
+    default: break;                                             \
+    }
+
+static int encoder_forward(const float *x, const float *const *prm, float *z, void *saved, void *scratch, int N,
+                           int length, int H, float eps, hipStream_t st)
+{
+    EncLayout e;
+    CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
+
+    // layer 0: fused conv + norm + relu straight from the waveform
+    Conv0Args c0{};
+    c0.x = x; c0.w = prm[0]; c0.b = prm[1]; c0.gamma = prm[2]; c0.beta = prm[3];
+    c0.y = e.Y[0]; c0.stats = e.stats0;
+    c0.N = N; c0.L0 = e.L[0]; c0.L1 = e.L[1]; c0.R0 = e.R[0]; c0.halo = kConv[1].p; c0.eps = eps;
+    c0.tiles_per_sample = (int)cdiv(e.L[1], C0_TB);
+    c0.n_tiles = N * c0.tiles_per_sample;
+    {
+        ProfScope prof(PROF_CONV0_FWD, st);
+        CPC_DISPATCH_H(H, hipLaunchKernelGGL(conv0_fwd_kernel<HH>, dim3(c0.n_tiles), dim3(256), 0, st, c0));
+    }
+    CPC_CHECK_LAUNCH("conv0_fwd_kernel");
+
+    for (int i = 1; i < 5; ++i) {
+        const int k = kConv[i].k, s = kConv[i].s;
+        // slack rows after Y_{i-1}: read by junk GEMM rows and by the weight-gradient GEMM -> must be finite
+        CPC_CHECK_HIP(hipMemsetAsync(e.Y[i - 1] + (size_t)N * e.R[i - 1] * H, 0, sizeof(float) * k * H, st));
+        CPC_TRY(permute_conv_fwd(prm[4 * i], e.Wr, H, H, k, st));
+        RowMap none{};
+        CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wr, (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
+                        k * H, none, st));
+        NormArgs na{};
+        na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
+        na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;
+        if (i < 4) { na.y = e.Y[i]; na.Rnext = e.R[i]; na.halo = kConv[i + 1].p; }
+        else { na.y = z; na.Rnext = e.L[5]; na.halo = 0; }
+        const long rows = (long)N * na.Rnext;
+        const int rpb = 4 * (64 / std::min(64, H / 4));
+        const int blocks = (int)std::min<long>(cdiv(rows, rpb), 4096);
+        CPC_DISPATCH_H(H, hipLaunchKernelGGL(norm_fwd_kernel<HH>, dim3(blocks), dim3(256), 0, st, na));
+        CPC_CHECK_LAUNCH("norm_fwd_kernel");
+    }
+    return CPC_OK;
+}
+
+static int encoder_backward(const float *x, const float *const *prm, const float *dz, void *saved, void *scratch,
+                            float *const *grads, int N, int length, int H, float eps, hipStream_t st)
+{
+    EncLayout e;
+    CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
+    const int rpw = 64 / std::min(64, H / 4);
+
+    const float *dy = dz;                  // [N][L[i+1]][H] of the current layer
+    for (int i = 4; i >= 1; --i) {
+        const int k = kConv[i].k, s = kConv[i].s, p = kConv[i].p;
+        // norm + relu backward -> dU_i (shifted rows), partial sums for dgamma, dbeta, dbias
+        NormArgs na{};
+        na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
+        na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;
+        na.dy = dy; na.du = e.dU; na.part = e.part;
+        CPC_DISPATCH_H(H, hipLaunchKernelGGL(norm_bwd_kernel<HH>, dim3(NORM_BWD_BLOCKS), dim3(256), 0, st, na));
+        CPC_CHECK_LAUNCH("norm_bwd_kernel");
+        // the row after the last one is read by the weight-gradient GEMM (A(m) = dU + (m+1)H, m+1 <= N*Rv)
+        // and by backward-data (rows m, m+1); row N*Rv is written (zero) by the kernel, one more for safety:
+        CPC_CHECK_HIP(hipMemsetAsync(e.dU + ((size_t)N * e.Rv[i] + 1) * H, 0, sizeof(float) * H, st));
+        const long slots = (long)NORM_BWD_BLOCKS * 4 * rpw;
+        CPC_TRY(colsum(e.part, slots, 3L * H, H, grads[4 * i + 2], st));            // dgamma
+        CPC_TRY(colsum(e.part + H, slots, 3L * H, H, grads[4 * i + 3], st));        // dbeta
+        CPC_TRY(colsum(e.part + 2 * H, slots, 3L * H, H, grads[4 * i + 1], st));    // conv bias
+
+        // weight gradient: dW[co][j*H+ci] = sum_m dU(m)[co] * Y_{i-1}(m)[j*H+ci]
+        CPC_TRY(gemm_tn(e.dU + H, H, e.Y[i - 1], (long)s * H, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], e.tn,
+                        e.tn_bytes, H, k, st));
+
+        // backward data, one GEMM per phase j: dY_{i-1}[n][t_hi*s + j - p] = [dU(t_hi-1), dU(t_hi)] . Bd[j]
+        CPC_TRY(permute_conv_dgrad(prm[4 * i], e.Wr, H, H, k, s, st));
+        float *dprev = (i % 2 == 0) ? e.dYb : e.dYa;         // i=4 -> dYb, 3 -> dYa, 2 -> dYb, 1 -> dYa
+        for (int j = 0; j < s; ++j) {
+            RowMap map{};
+            map.enabled = 1; map.rv = e.Rv[i]; map.out_stride = s; map.out_off = j - p;
+            map.l_max = e.L[i]; map.rows_out = e.L[i];
+            CPC_TRY(gemm_nt(e.dU, H, e.Wr + (size_t)j * H * 2 * H, 2L * H, dprev, H, nullptr, (long)N * e.Rv[i], H,
+                            2 * H, map, st));
+        }
+        dy = dprev;
+    }
+
+    // layer 0
+    Conv0Args c0{};
+    c0.x = x; c0.w = prm[0]; c0.b = prm[1]; c0.gamma = prm[2]; c0.beta = prm[3];
+    c0.stats = e.stats0; c0.dy = dy; c0.part = e.part;
+    c0.N = N; c0.L0 = e.L[0]; c0.L1 = e.L[1]; c0.R0 = e.R[0]; c0.halo = kConv[1].p; c0.eps = eps;
+    c0.tiles_per_sample = (int)cdiv(e.L[1], C0_TB);
+    c0.n_tiles = N * c0.tiles_per_sample;
+    {
+        ProfScope prof(PROF_CONV0_BWD, st);
+        CPC_DISPATCH_H(H, hipLaunchKernelGGL(conv0_bwd_kernel<HH>, dim3(CONV0_BWD_BLOCKS), dim3(256), 0, st, c0));
+    }
+    CPC_CHECK_LAUNCH("conv0_bwd_kernel");
+    CPC_TRY(colsum(e.part, (long)CONV0_BWD_BLOCKS * 4 * rpw, 13L * H, 13 * H, e.sums, st));
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), 0, st, e.sums, grads[0], grads[1],
+                       grads[2], grads[3], H);
+    CPC_CHECK_LAUNCH("conv0_finalize_kernel");
+    return CPC_OK;
+}
+
+}  // namespace cpc
+
+extern "C" int cpc_encoder_frames(int length)
+{
+    int l = length;
+    for (int i = 0; i < 5; ++i) l = (l + 2 * cpc::kConv[i].p - cpc::kConv[i].k) / cpc::kConv[i].s + 1;
+    return l;
+}
+
+extern "C" size_t cpc_encoder_saved_bytes(int n_windows, int length, int hidden)
+{
+    cpc::EncLayout e;
+    if (cpc::enc_layout(e, n_windows, length, hidden, nullptr, nullptr) != CPC_OK) return 0;
+    return e.saved_bytes;
+}
+
+extern "C" size_t cpc_encoder_scratch_bytes(int n_windows, int length, int hidden)
+{
+    cpc::EncLayout e;
+    if (cpc::enc_layout(e, n_windows, length, hidden, nullptr, nullptr) != CPC_OK) return 0;
+    return e.scratch_bytes;
+}
+
+extern "C" int cpc_encoder_forward(const float *x, const float *const *params, float *z, void *saved, void *scratch,
+                                   int n_windows, int length, int hidden, float eps, cpc_stream_t stream)
+{
+    return cpc::encoder_forward(x, params, z, saved, scratch, n_windows, length, hidden, eps, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_encoder_backward(const float *x, const float *const *params, const float *dz, void *saved, void *scratch,
+                                    float *const *grads, int n_windows, int length, int hidden, float eps, cpc_stream_t stream)
+{
+    return cpc::encoder_backward(x, params, dz, saved, scratch, grads, n_windows, length, hidden, eps,
+                                 static_cast<hipStream_t>(stream));
+}

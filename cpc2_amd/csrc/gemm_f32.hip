@@ -1,0 +1,348 @@
+// fp32 GEMMs on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 64 FLOP/clk/SIMD).
+//
+//   gemm_nt : C[map(m)][n] = sum_k A[m*lda + k] * B[n*ldb + k] (+ bias[n])
+//             A rows may OVERLAP (lda < K): that is how the strided Conv1d layers run as
+//             implicit GEMMs over channel-last activations (see encoder.hip).
+//   gemm_tn : C[i][j] = sum_r A[r*lda + i] * B[r*ldb + j]   (weight gradients; split over r,
+//             partial slabs reduced by a second kernel -> bitwise reproducible, no atomics)
+//
+// Block tile 128x128, 256 threads = 4 waves (2x2), wave tile 64x64 = 2x2 MFMA tiles of 32x32,
+// K step 32.  Operands are staged global -> registers -> LDS (prefetch of the next K tile is
+// in flight while the current one is multiplied); LDS rows are padded to 36 floats so the
+// ds_read_b128 fragment reads are bank-conflict free.
+#include "common.h"
+
+namespace cpc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_NT = BK + 4;    // 36 floats per LDS row (NT: k contiguous)
+constexpr int LDS_TN = BM + 4;    // 132 floats per LDS row (TN: i/j contiguous)
+
+struct GemmNTArgs {
+    const float *A; long lda;
+    const float *B; long ldb;
+    float *C; long ldc;
+    const float *bias;
+    long M; int N; int K;
+    RowMap map;
+    int aligned;   // K%4==0, lda%4==0, ldb%4==0, bases 16-B aligned
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float *row, int k, int K, bool row_ok, bool aligned)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_ok) {
+        if (aligned) {
+            if (k < K) v = *reinterpret_cast<const float4 *>(row + k);
+        } else {
+            if (k < K) v.x = row[k];
+            if (k + 1 < K) v.y = row[k + 1];
+            if (k + 2 < K) v.z = row[k + 2];
+            if (k + 3 < K) v.w = row[k + 3];
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_NT];
+    float *As = lds;                  // [BM][LDS_NT]
+    float *Bs = lds + BM * LDS_NT;    // [BN][LDS_NT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // 1-D grid, N tile fastest: the blocks that share an A panel are dispatched back to back
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long m0 = (long)(blockIdx.x / tiles_n) * BM;
+    const int n0 = (int)(blockIdx.x % tiles_n) * BN;
+
+    // loader: 4 float4 of A and 4 of B per thread; slot = tid + 256*q -> row = slot/8, c4 = slot%8
+    const int lrow = tid >> 3;        // + 32*q
+    const int lc4 = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + lrow + 32 * q;
+            const int n = n0 + lrow + 32 * q;
+            ra[q] = ld4_guard(p.A + m * p.lda, k0 + lc4, p.K, m < p.M, p.aligned);
+            rb[q] = ld4_guard(p.B + (long)n * p.ldb, k0 + lc4, p.K, n < p.N, p.aligned);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4 *>(&As[(lrow + 32 * q) * LDS_NT + lc4]) = ra[q];
+            *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * q) * LDS_NT + lc4]) = rb[q];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            // lane (r32, h) takes k = kk*8 + 4h + {0,1,2,3}; MFMA step e pairs k-slot (h, e) of A
+            // with the same k of B, so any k permutation shared by both operands is valid.
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4 *>(&As[(wm * 64 + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
+                b[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][e] is C[m][n], m = m0 + wm*64 + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
+    float bias_v[2];
+    int ncol[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ncol[j] = n0 + wn * 64 + j * 32 + r32;
+        bias_v[j] = (p.bias != nullptr && ncol[j] < p.N) ? p.bias[ncol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m >= p.M) continue;
+            long crow = m;
+            if (p.map.enabled) {
+                const long g = m / p.map.rv;
+                const int t = (int)(m - g * p.map.rv);
+                const long l = (long)t * p.map.out_stride + p.map.out_off;
+                if (l < 0 || l >= p.map.l_max) continue;
+                crow = g * p.map.rows_out + l;
+            }
+            float *crowp = p.C + crow * p.ldc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (ncol[j] < p.N) crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
+        }
+    }
+}
+
+int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
+            long M, int N, int K, const RowMap &map, hipStream_t st)
+{
+    CPC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%ld N=%d K=%d", M, N, K);
+    GemmNTArgs a;
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.map = map;
+    a.aligned = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
+    const long blocks = cdiv(M, BM) * cdiv(N, BN);
+    CPC_REQUIRE(blocks <= 2147483647L, "gemm_nt: grid too large (%ld blocks)", blocks);
+    dim3 grid((unsigned)blocks);
+    ProfScope prof(PROF_GEMM_NT, st);
+    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, st, a);
+    CPC_CHECK_LAUNCH("gemm_nt_kernel");
+    return CPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GemmTNArgs {
+    const float *A; long lda;
+    const float *B; long ldb;
+    float *slab;       // [S][M][N]
+    int M, N;
+    long R, chunk;     // rows per split (multiple of BK)
+    int aligned;
+};
+
+__device__ __forceinline__ float4 ld4_guard_cols(const float *row, int c, int ncols, bool row_ok, bool aligned)
+{
+    return ld4_guard(row, c, ncols, row_ok, aligned);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDS_TN];
+    float *As = lds;                   // [BK][LDS_TN]  (row r, column i)
+    float *Bs = lds + BK * LDS_TN;     // [BK][LDS_TN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int i0 = blockIdx.y * BM;
+    const int j0 = blockIdx.x * BN;
+    const long rbeg = (long)blockIdx.z * p.chunk;
+    long rend = rbeg + p.chunk;
+    if (rend > p.R) rend = p.R;
+
+    // loader: tile [32 rows][128 cols] = 1024 float4; slot = tid + 256*q -> row = slot/32, c4 = slot%32
+    const int lr = tid >> 5;           // + 8*q
+    const int lc = (tid & 31) * 4;
+    float4 ra[4], rb[4];
+    auto load_tiles = [&](long r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long r = r0 + lr + 8 * q;
+            ra[q] = ld4_guard_cols(p.A + r * p.lda, i0 + lc, p.M, r < rend, p.aligned);
+            rb[q] = ld4_guard_cols(p.B + r * p.ldb, j0 + lc, p.N, r < rend, p.aligned);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (rbeg < rend) {
+        load_tiles(rbeg);
+        for (long r0 = rbeg; r0 < rend; r0 += BK) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<float4 *>(&As[(lr + 8 * q) * LDS_TN + lc]) = ra[q];
+                *reinterpret_cast<float4 *>(&Bs[(lr + 8 * q) * LDS_TN + lc]) = rb[q];
+            }
+            __syncthreads();
+            if (r0 + BK < rend) load_tiles(r0 + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                // MFMA tile (i_t, j_t) owns rows wm*64 + 2*r + i_t and columns wn*64 + 2*c + j_t (interleaved),
+                // so one ds_read_b64 per operand feeds both tiles of that operand.
+                const float2 a = *reinterpret_cast<const float2 *>(&As[(2 * kk + h) * LDS_TN + wm * 64 + 2 * r32]);
+                const float2 b = *reinterpret_cast<const float2 *>(&Bs[(2 * kk + h) * LDS_TN + wn * 64 + 2 * r32]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // slab[z][i][j]: i = i0 + wm*64 + 2*((e&3) + 8*(e>>2) + 4h) + i_t ; j = j0 + wn*64 + 2*r32 + j_t
+    float *slab = p.slab + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * h) + it;
+            if (i >= p.M) continue;
+            const int j = j0 + wn * 64 + 2 * r32;
+            float *dst = slab + (long)i * p.N + j;
+            if (j + 1 < p.N && (p.N % 2 == 0)) {
+                *reinterpret_cast<float2 *>(dst) = make_float2(acc[it][0][e], acc[it][1][e]);
+            } else {
+                if (j < p.N) dst[0] = acc[it][0][e];
+                if (j + 1 < p.N) dst[1] = acc[it][1][e];
+            }
+        }
+}
+
+// out = sum over slabs; optional Conv1d weight re-layout (column jj*cin+ci -> [ci][jj])
+__global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k)
+{
+    const long total = (long)M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += slab[(long)z * total + idx];
+        const int i = (int)(idx / N), j = (int)(idx - (long)i * N);
+        if (conv_cin > 0) {
+            const int jj = j / conv_cin, ci = j - jj * conv_cin;
+            C[(long)i * conv_cin * conv_k + (long)ci * conv_k + jj] = s;
+        } else {
+            C[(long)i * ldc + j] = s;
+        }
+    }
+}
+
+static int tn_splits(int M, int N, long R, long *chunk_out)
+{
+    const long tiles = cdiv(M, BM) * cdiv(N, BN);
+    long S = cdiv(1024, tiles);
+    const long max_s = cdiv(R, 4 * BK);      // at least 128 rows per split
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    long chunk = cdiv(cdiv(R, S), BK) * BK;
+    S = cdiv(R, chunk);
+    *chunk_out = chunk;
+    return (int)S;
+}
+
+size_t gemm_tn_scratch_bytes(int M, int N, long R)
+{
+    long chunk;
+    const int S = tn_splits(M, N, R, &chunk);
+    return align_up((size_t)S * M * N * sizeof(float), 256);
+}
+
+int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, long R,
+            void *scratch, size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st)
+{
+    CPC_REQUIRE(M > 0 && N > 0 && R > 0, "gemm_tn: empty problem M=%d N=%d R=%ld", M, N, R);
+    GemmTNArgs a;
+    long chunk;
+    const int S = tn_splits(M, N, R, &chunk);
+    if ((size_t)S * M * N * sizeof(float) > scratch_bytes) {
+        set_error("gemm_tn: scratch too small (%zu < %zu)", scratch_bytes, (size_t)S * M * N * sizeof(float));
+        return CPC_ERR_WORKSPACE;
+    }
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.slab = static_cast<float *>(scratch);
+    a.M = M; a.N = N; a.R = R; a.chunk = chunk;
+    a.aligned = (M % 4 == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
+    dim3 grid((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM), (unsigned)S);
+    ProfScope prof(PROF_GEMM_TN, st);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, a);
+    CPC_CHECK_LAUNCH("gemm_tn_kernel");
+    const long total = (long)M * N;
+    int blocks = (int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256));
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.slab, S, M, N, C, ldc, conv_cin, conv_k);
+    CPC_CHECK_LAUNCH("gemm_tn_reduce_kernel");
+    return CPC_OK;
+}
+
+}  // namespace cpc
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,
+                           const float *bias, int M, int N, int K, cpc_stream_t stream)
+{
+    cpc::RowMap map{};
+    return cpc::gemm_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, map, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t cpc_gemm_tn_scratch_bytes(int M, int N, long R) { return cpc::gemm_tn_scratch_bytes(M, N, R); }
+
+extern "C" int cpc_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N,
+                           long R, void *scratch, size_t scratch_bytes, cpc_stream_t stream)
+{
+    return cpc::gemm_tn(A, lda, B, ldb, C, ldc, M, N, R, scratch, scratch_bytes, 0, 0, static_cast<hipStream_t>(stream));
+}

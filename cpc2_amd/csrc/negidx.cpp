@@ -1,0 +1,138 @@
+// Host-side negative-index sampler, bit-exact with the reference's CPU path.
+// Reference: /root/reference/cpc/criterion/criterion.py:247-266 (two torch.randint calls on the CPU
+// generator = 32-bit MT19937, one output per element in order, value = out % range + low;
+// batchIdx first, then seqIdx; extIdx = (seqIdx + t) % T + batchIdx * T with t fastest).
+//
+// The generator state is kept in torch's bookkeeping form (left / next) so that it can be seeded from,
+// and written back to, torch.get_rng_state() -- the criterion then consumes the SAME stream the
+// reference would.  Whole 624-word blocks are twisted and tempered in bulk.
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/cpc2_hip.h"
+
+namespace cpc { void set_error(const char *fmt, ...); }
+
+struct cpc_mt19937 {
+    uint32_t mt[624];
+    int left;   // torch: twist when --left == 0
+    int next;
+    std::vector<uint32_t> tmp;
+};
+
+namespace {
+constexpr int N = 624, M = 397;
+
+inline void twist(uint32_t *mt)
+{
+    auto mix = [](uint32_t u, uint32_t v) { return (u & 0x80000000u) | (v & 0x7fffffffu); };
+    auto mag = [](uint32_t y) { return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
+    int i = 0;
+    for (; i < N - M; ++i) mt[i] = mt[i + M] ^ mag(mix(mt[i], mt[i + 1]));
+    for (; i < N - 1; ++i) mt[i] = mt[i + M - N] ^ mag(mix(mt[i], mt[i + 1]));
+    mt[N - 1] = mt[M - 1] ^ mag(mix(mt[N - 1], mt[0]));
+}
+
+inline uint32_t temper(uint32_t y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// n raw outputs into dst, same stream as torch's mt19937::operator()
+void draw(cpc_mt19937 *g, uint32_t *dst, size_t n)
+{
+    size_t pos = 0;
+    while (pos < n) {
+        if (g->left == 1) {          // next draw would twist
+            twist(g->mt);
+            g->left = N + 1;
+            g->next = 0;
+        }
+        size_t take = (size_t)(g->left - 1);
+        if (take > n - pos) take = n - pos;
+        const uint32_t *src = g->mt + g->next;
+        for (size_t i = 0; i < take; ++i) dst[pos + i] = temper(src[i]);
+        g->next += (int)take;
+        g->left -= (int)take;
+        pos += take;
+    }
+}
+}  // namespace
+
+extern "C" cpc_mt19937 *cpc_mt_create(uint32_t seed)
+{
+    cpc_mt19937 *g = new (std::nothrow) cpc_mt19937();
+    if (g != nullptr) cpc_mt_seed(g, seed);
+    return g;
+}
+
+extern "C" void cpc_mt_destroy(cpc_mt19937 *g) { delete g; }
+
+extern "C" int cpc_mt_seed(cpc_mt19937 *g, uint32_t seed)
+{
+    if (g == nullptr) { cpc::set_error("cpc_mt_seed: null generator"); return CPC_ERR_INVALID; }
+    g->mt[0] = seed;
+    for (int i = 1; i < N; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->left = 1;
+    g->next = 0;
+    return CPC_OK;
+}
+
+extern "C" int cpc_mt_get_state(const cpc_mt19937 *g, uint32_t *mt624, int *left, int *next)
+{
+    if (g == nullptr || mt624 == nullptr) { cpc::set_error("cpc_mt_get_state: null argument"); return CPC_ERR_INVALID; }
+    std::memcpy(mt624, g->mt, sizeof(g->mt));
+    if (left) *left = g->left;
+    if (next) *next = g->next;
+    return CPC_OK;
+}
+
+extern "C" int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left, int next)
+{
+    if (g == nullptr || mt624 == nullptr || left < 1 || left > N || next < 0 || next > N || (left > 1 && next + left - 1 != N)) {
+        cpc::set_error("cpc_mt_set_state: invalid state (left=%d next=%d)", left, next);
+        return CPC_ERR_INVALID;
+    }
+    std::memcpy(g->mt, mt624, sizeof(g->mt));
+    g->left = left;
+    g->next = next;
+    return CPC_OK;
+}
+
+extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int32_t *ext_idx_host,
+                                      int64_t *batch_idx_host_opt, int64_t *seq_idx_host_opt)
+{
+    if (g == nullptr || ext_idx_host == nullptr || batch < 1 || seq_len < 2 || window < 1 || window > seq_len || n_neg < 1) {
+        cpc::set_error("cpc_negidx_sample_host: bad arguments (batch=%d seq_len=%d window=%d n_neg=%d)", batch, seq_len, window, n_neg);
+        return CPC_ERR_INVALID;
+    }
+    if ((long long)batch * seq_len > 2147483647LL) {
+        cpc::set_error("cpc_negidx_sample_host: batch*seq_len exceeds int32");
+        return CPC_ERR_INVALID;
+    }
+    const size_t n = (size_t)n_neg * window * batch;
+    g->tmp.resize(2 * n);
+    uint32_t *raw_b = g->tmp.data(), *raw_s = raw_b + n;
+    draw(g, raw_b, n);      // batchIdx stream first (criterion.py:247-250)
+    draw(g, raw_s, n);      // then seqIdx (criterion.py:253-256)
+    const uint32_t ub = (uint32_t)batch, us = (uint32_t)(seq_len - 1);
+    size_t i = 0;
+    for (size_t row = 0; row < (size_t)n_neg * batch; ++row) {
+        for (int t = 0; t < window; ++t, ++i) {
+            const uint32_t bi = raw_b[i] % ub;
+            const uint32_t si = raw_s[i] % us + 1u;
+            uint32_t seq = si + (uint32_t)t;
+            if (seq >= (uint32_t)seq_len) seq -= (uint32_t)seq_len;     // si <= T-1, t <= T-1 -> one wrap at most
+            ext_idx_host[i] = (int32_t)(seq + bi * (uint32_t)seq_len);
+            if (batch_idx_host_opt) batch_idx_host_opt[i] = (int64_t)bi;
+            if (seq_idx_host_opt) seq_idx_host_opt[i] = (int64_t)si;
+        }
+    }
+    return CPC_OK;
+}

@@ -1,0 +1,259 @@
+"""Drop-in counterparts of the reference's cpc/model.py classes on the hot path.
+
+Same class names, constructor and forward signatures, attributes and state-dict keys as
+/root/reference/cpc/model.py (ChannelNorm :27-60, CPCEncoder :63-108, CPCAR :158-207,
+CPCModel :279-390), so `cpc/train.py` can construct and drive them unchanged and reference
+checkpoints load with load_state_dict.  The arithmetic runs in libcpc2_hip.so.
+
+Parameter containers are the same torch modules the reference instantiates (nn.Conv1d,
+nn.GRU) so that default initialisation under a given torch seed is identical; their own
+forward() is never called.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, f32c, ptr, ptr_array, require_gpu, scratch, stream_ptr
+
+
+# --------------------------------------------------------------------------- ChannelNorm
+class _ChannelNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        require_gpu(x)
+        lib = _lib.load()
+        x = f32c(x)
+        n, c, l = x.shape
+        y = torch.empty_like(x)
+        rstd = torch.empty(n * l, dtype=torch.float32, device=x.device)
+        w = f32c(weight) if weight is not None else None
+        b = f32c(bias) if bias is not None else None
+        check(lib.cpc_channelnorm_forward(ptr(x), ptr(w), ptr(b), ptr(y), ptr(rstd), n, c, l, eps,
+                                          stream_ptr(x.device)), "channelnorm_forward")
+        ctx.save_for_backward(x, w, rstd)
+        ctx.eps = eps
+        ctx.affine = weight is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, rstd = ctx.saved_tensors
+        dy = f32c(dy)
+        n, c, l = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty(1, c, 1, dtype=torch.float32, device=x.device) if ctx.affine else None
+        db = torch.empty(1, c, 1, dtype=torch.float32, device=x.device) if ctx.affine else None
+        check(lib.cpc_channelnorm_backward(ptr(x), ptr(w), ptr(dy), ptr(rstd), ptr(dx), ptr(dw), ptr(db),
+                                           n, c, l, ctx.eps, stream_ptr(x.device)), "channelnorm_backward")
+        return dx, dw, db, None
+
+
+class ChannelNorm(nn.Module):
+    """model.py:27-60 -- normalisation over the channel axis of [N, C, L], unbiased variance."""
+
+    def __init__(self, numFeatures, epsilon=1e-05, affine=True):
+        super(ChannelNorm, self).__init__()
+        if affine:
+            self.weight = nn.parameter.Parameter(torch.Tensor(1, numFeatures, 1))
+            self.bias = nn.parameter.Parameter(torch.Tensor(1, numFeatures, 1))
+        else:
+            self.weight = None
+            self.bias = None
+        self.epsilon = epsilon
+        self.p = 0
+        self.affine = affine
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.affine:
+            torch.nn.init.ones_(self.weight)
+            torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x):
+        return _ChannelNormFn.apply(x, self.weight, self.bias, float(self.epsilon))
+
+
+# --------------------------------------------------------------------------- CPCEncoder
+_ENC_GEOMETRY = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
+
+
+class _EncoderFn(torch.autograd.Function):
+    """relu(norm_i(conv_i(.))) x5 in one call; returns the channel-LAST output [N, T, H]."""
+
+    @staticmethod
+    def forward(ctx, x, eps, *params):
+        require_gpu(x, *params)
+        lib = _lib.load()
+        x = f32c(x)
+        params = tuple(f32c(p) for p in params)
+        n, cin, length = x.shape
+        if cin != 1:
+            raise ValueError(f"CPCEncoder expects [N, 1, L] waveforms (got {tuple(x.shape)})")
+        hidden = params[0].shape[0]
+        frames = lib.cpc_encoder_frames(length)
+        nsaved = lib.cpc_encoder_saved_bytes(n, length, hidden)
+        nscratch = lib.cpc_encoder_scratch_bytes(n, length, hidden)
+        if nsaved == 0:
+            check(-1, "encoder shape query")
+        z = torch.empty(n, frames, hidden, dtype=torch.float32, device=x.device)
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
+        sc = scratch(nscratch, x.device)
+        check(lib.cpc_encoder_forward(ptr(x), ptr_array(params), ptr(z), ptr(saved), ptr(sc), n, length, hidden,
+                                      eps, stream_ptr(x.device)), "encoder_forward")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.eps = eps
+        ctx.dims = (n, length, hidden)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, saved, *params = ctx.saved_tensors
+        n, length, hidden = ctx.dims
+        dz = f32c(dz)
+        grads = [torch.empty_like(p) for p in params]
+        sc = scratch(lib.cpc_encoder_scratch_bytes(n, length, hidden), x.device)
+        check(lib.cpc_encoder_backward(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
+                                       n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward")
+        return (None, None) + tuple(grads)
+
+
+class CPCEncoder(nn.Module):
+    """model.py:63-108.  Only normMode="layerNorm" (ChannelNorm, the default of the reference's
+    config) runs on the fused HIP path; the other modes are not on the hot path."""
+
+    def __init__(self, sizeHidden=512, normMode="layerNorm"):
+        super(CPCEncoder, self).__init__()
+        validModes = ["batchNorm", "instanceNorm", "ID", "layerNorm"]
+        if normMode not in validModes:
+            raise ValueError(f"Norm mode must be in {validModes}")
+        if normMode != "layerNorm":
+            raise NotImplementedError(
+                f"normMode={normMode!r}: only 'layerNorm' (ChannelNorm) has an MI355X kernel path")
+        self.dimEncoded = sizeHidden
+        cin = 1
+        for i, (k, s, p) in enumerate(_ENC_GEOMETRY):
+            setattr(self, f"conv{i}", nn.Conv1d(cin, sizeHidden, k, stride=s, padding=p))
+            setattr(self, f"batchNorm{i}", ChannelNorm(sizeHidden))
+            cin = sizeHidden
+        self.DOWNSAMPLING = 160
+
+    def getDimOutput(self):
+        return self.conv4.out_channels
+
+    def _param_list(self):
+        out = []
+        for i in range(5):
+            conv, norm = getattr(self, f"conv{i}"), getattr(self, f"batchNorm{i}")
+            out += [conv.weight, conv.bias, norm.weight, norm.bias]
+        return out
+
+    def forward_channel_last(self, x):
+        """[N, 1, L] -> [N, T, H] (what CPCModel consumes); eps taken from batchNorm0."""
+        return _EncoderFn.apply(x, float(self.batchNorm0.epsilon), *self._param_list())
+
+    def forward(self, x):
+        # reference layout [N, H, T]; a permuted view of the channel-last buffer
+        return self.forward_channel_last(x).permute(0, 2, 1)
+
+
+# --------------------------------------------------------------------------- CPCAR (GRU)
+class _GruFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h0, n_layers, want_hidden, *params):
+        require_gpu(x, *params)
+        lib = _lib.load()
+        x = f32c(x)
+        params = tuple(f32c(p) for p in params)
+        n, t, dim_in = x.shape
+        hidden = params[1].shape[1]
+        nsaved = lib.cpc_gru_saved_bytes(n, t, dim_in, hidden, n_layers)
+        nscratch = lib.cpc_gru_scratch_bytes(n, t, dim_in, hidden, n_layers)
+        if nsaved == 0:
+            check(-1, "gru shape query")
+        out = torch.empty(n, t, hidden, dtype=torch.float32, device=x.device)
+        h_last = torch.empty(n_layers, n, hidden, dtype=torch.float32, device=x.device) if want_hidden else None
+        h0c = f32c(h0) if h0 is not None else None
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
+        sc = scratch(nscratch, x.device)
+        check(lib.cpc_gru_forward(ptr(x), ptr_array(params), ptr(h0c), ptr(out), ptr(h_last), ptr(saved), ptr(sc),
+                                  n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "gru_forward")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.dims = (n, t, dim_in, hidden, n_layers)
+        if want_hidden:
+            ctx.mark_non_differentiable(h_last)
+            return out, h_last
+        return out, None
+
+    @staticmethod
+    def backward(ctx, dout, _dh):
+        lib = _lib.load()
+        x, saved, *params = ctx.saved_tensors
+        n, t, dim_in, hidden, n_layers = ctx.dims
+        dout = f32c(dout)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        grads = [torch.empty_like(p) for p in params]
+        sc = scratch(lib.cpc_gru_scratch_bytes(n, t, dim_in, hidden, n_layers), x.device)
+        check(lib.cpc_gru_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
+                                   ptr_array(grads), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
+              "gru_backward")
+        return (dx, None, None, None) + tuple(grads)
+
+
+class CPCAR(nn.Module):
+    """model.py:158-207.  mode="GRU" runs on the HIP path (LSTM / RNN are not on the hot path)."""
+
+    def __init__(self, dimEncoded, dimOutput, keepHidden, nLevelsGRU, mode="GRU", reverse=False):
+        super(CPCAR, self).__init__()
+        self.RESIDUAL_STD = 0.1
+        if mode in ("LSTM", "RNN"):
+            raise NotImplementedError(f"CPCAR mode={mode!r}: only 'GRU' has an MI355X kernel path")
+        self.baseNet = nn.GRU(dimEncoded, dimOutput, num_layers=nLevelsGRU, batch_first=True)
+        self.hidden = None
+        self.keepHidden = keepHidden
+        self.reverse = reverse
+
+    def getDimOutput(self):
+        return self.baseNet.hidden_size
+
+    def _param_list(self):
+        out = []
+        for layer in range(self.baseNet.num_layers):
+            out += [getattr(self.baseNet, f"{n}_l{layer}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return out
+
+    def forward(self, x):
+        if self.reverse:
+            x = torch.flip(x, [1])
+        x, h = _GruFn.apply(x, self.hidden, self.baseNet.num_layers, bool(self.keepHidden), *self._param_list())
+        if self.keepHidden:
+            self.hidden = h.detach()
+        # a sequence's order is preserved by each module (model.py:203-206)
+        if self.reverse:
+            x = torch.flip(x, [1])
+        return x
+
+
+# --------------------------------------------------------------------------- CPCModel
+class CPCModel(nn.Module):
+    """model.py:279-390 with mask_prob == 0 (the default; the wav2vec-style masking of
+    :300-379 is not on the hot path)."""
+
+    def __init__(self, encoder, AR, mask_prob=0.0, mask_length=10):
+        super(CPCModel, self).__init__()
+        self.gEncoder = encoder
+        self.gAR = AR
+        self.mask_prob = mask_prob
+        self.mask_length = mask_length
+        if mask_prob > 0.0:
+            raise NotImplementedError("mask_prob > 0 is not supported by the MI355X hot path")
+
+    def forward(self, batchData, label):
+        if hasattr(self.gEncoder, "forward_channel_last"):
+            encodedData = self.gEncoder.forward_channel_last(batchData)      # [N, T, H], contiguous
+        else:
+            encodedData = self.gEncoder(batchData).permute(0, 2, 1)
+        cFeature = self.gAR(encodedData)
+        return cFeature, encodedData, label

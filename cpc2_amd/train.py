@@ -1,0 +1,244 @@
+"""The caller side of the hot path: factories, the optimisation step and data-parallel glue.
+
+Mirrors (semantics, names) /root/reference/cpc/train.py:27-59 (getCriterion), :72-187
+(trainStep / valStep), :472-484 (Adam over criterion + model parameters), :523-527 (DDP wrap) and
+/root/reference/cpc/feature_loader.py:202-235 (getEncoder / getAR).  Differences, all deliberate:
+  * device-agnostic tensors come from the caller (the reference hard-codes .cuda());
+  * parameters and gradients live in ONE flat fp32 buffer each, so the optimiser is one fused
+    HIP Adam launch and data parallelism is one RCCL all-reduce per step (instead of DDP buckets);
+  * per-step losses stay on the device; the host reads them every `loggingStep` steps only.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .criterion import CPCUnsupersivedCriterion, NoneCriterion
+from .model import CPCAR, CPCEncoder, CPCModel
+
+
+# --------------------------------------------------------------------------- factories
+def getEncoder(args):
+    """feature_loader.py:202-212 (CPCEncoder branch)."""
+    if getattr(args, "encoder_type", "cpc") in ("mfcc", "lfb"):
+        raise NotImplementedError("only the raw-waveform CPCEncoder is on the MI355X hot path")
+    return CPCEncoder(args.hiddenEncoder, args.normMode)
+
+
+def getAR(args):
+    """feature_loader.py:215-235 (CPCAR / transformer branches)."""
+    if args.arMode == "transformer":
+        from .transformers import buildTransformerAR
+        arNet = buildTransformerAR(args.hiddenEncoder, args.hiddenGar, args.nLevelsGRU,
+                                   args.sizeWindow // 160, args.abspos)
+        args.hiddenGar = args.hiddenEncoder
+        return arNet
+    return CPCAR(args.hiddenEncoder, args.hiddenGar, args.samplingType == "sequential", args.nLevelsGRU,
+                 mode=args.arMode, reverse=getattr(args, "cpc_mode", None) == "reverse")
+
+
+def getCriterion(args, downsampling, nSpeakers=0, nPhones=0):
+    """train.py:27-48 (unsupervised branch)."""
+    if getattr(args, "supervised", False):
+        raise NotImplementedError("supervised criteria are not on the MI355X hot path")
+    if getattr(args, "cpc_mode", None) == "none":
+        return NoneCriterion()
+    sizeInputSeq = args.sizeWindow // downsampling
+    return CPCUnsupersivedCriterion(args.nPredicts, args.hiddenGar, args.hiddenEncoder, args.negativeSamplingExt,
+                                    mode=getattr(args, "cpc_mode", None), rnnMode=args.rnnMode,
+                                    dropout=getattr(args, "dropout", False), nSpeakers=nSpeakers,
+                                    sizeInputSeq=sizeInputSeq,
+                                    multihead_rnn=getattr(args, "multihead_rnn", False),
+                                    transformer_pruning=getattr(args, "transformer_pruning", 0),
+                                    n_skipped=getattr(args, "n_skipped", 0),
+                                    growth_rate=getattr(args, "growth_rate", None),
+                                    inflection_point_x=getattr(args, "inflection_point_x", None))
+
+
+# --------------------------------------------------------------------------- flat parameters + fused Adam
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas, eps) of train.py:477-479 on one flat buffer.
+
+    Re-homes every parameter into `self.flat` (views, same values) and every .grad into
+    `self.flat_grad`, then `step()` is a single cpc_adam_step launch.  State-dict interop with
+    torch.optim.Adam is kept through `state_dict()` / `load_state_dict()` (per-parameter
+    exp_avg / exp_avg_sq / step)."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam got an empty parameter list")
+        dev = self.params[0].device
+        _lib.require_gpu(*self.params)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.flat_grad[off:off + n].view(p.shape)
+            self.offsets.append(off)
+            off += n
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "params": self.params}]
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        for p, off in zip(self.params, self.offsets):      # re-attach if someone replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        check(_lib.load().cpc_adam_step(ptr(self.flat), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                        self.flat.numel(), self.step_count, lr, self.betas[0], self.betas[1], self.eps,
+                                        grad_scale, stream_ptr(self.flat.device)), "adam_step")
+
+    def state_dict(self):
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": [{"lr": self.param_groups[0]["lr"], "betas": self.betas,
+                                                  "eps": self.eps, "params": list(range(len(self.params)))}]}
+
+    def load_state_dict(self, sd):
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(st["step"])
+        self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]
+
+
+def buildOptimizer(cpcModel, cpcCriterion, lr=2e-4, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    """train.py:472-479: criterion parameters first, then model parameters."""
+    g_params = list(cpcCriterion.parameters()) + list(cpcModel.parameters())
+    return FlatAdam(g_params, lr=lr, betas=(beta1, beta2), eps=epsilon)
+
+
+# --------------------------------------------------------------------------- data parallel
+class DataParallelContext:
+    """One process per GPU (train.py:291-295, 523-527 with --distributed).  Replaces the two DDP
+    wrappers by: one broadcast of the flat parameter buffer from rank 0 at start, and one all-reduce
+    (SUM) of the flat gradient buffer per step whose 1/world_size is folded into the Adam kernel."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            dist.broadcast(self.opt.flat, src=0)
+
+    def reduce_and_step(self):
+        if self.world > 1:
+            dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM)
+        self.opt.step(grad_scale=1.0 / self.world)
+
+
+# --------------------------------------------------------------------------- the step
+def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None):
+    """train.py:95-108: model on cat([past, future]); context from the past half, targets from the
+    future half; returns (totLoss, allLosses [1,K], allAcc [1,K])."""
+    b = past.size(0)
+    combined = torch.cat([past, future], dim=0)
+    label = torch.cat([label, label])
+    c_feature, encoded_data, label = cpcModel(combined, label)
+    c_feature = c_feature[:b, :, :]
+    encoded_data = encoded_data[b:, :, :]
+    label = label[:b]
+    allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
+    return allLosses.sum(), allLosses, allAcc
+
+
+def trainStep(dataLoader, cpcModel, cpcCriterion, optimizer, scheduler, loggingStep, dp=None, device=None):
+    """train.py:72-142.  `dataLoader` yields (sequence [b,2,1,L], label [b][, signal_quality])."""
+    cpcModel.train()
+    cpcCriterion.train()
+    device = device or next(cpcModel.parameters()).device
+    dp = dp or DataParallelContext(optimizer)
+    start_time = time.perf_counter()
+    n_examples, it = 0, 0
+    sum_loss = sum_acc = None
+    logs = {}
+    for step, full_data in enumerate(dataLoader):
+        sequence, label, *signal_quality = full_data
+        sequence = sequence.to(device, non_blocking=True)
+        label = label.to(device, non_blocking=True)
+        signal_quality = signal_quality[0].to(device, non_blocking=True) if len(signal_quality) else None
+        past, future = sequence[:, 0, ...], sequence[:, 1, ...]
+        n_examples += past.size(0)
+        totLoss, allLosses, allAcc = cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality)
+        totLoss.backward()
+        dp.reduce_and_step()
+        optimizer.zero_grad()
+        if allLosses.nelement() > 0:
+            it += 1
+            ls, ac = allLosses.detach().mean(dim=0), allAcc.mean(dim=0)
+            sum_loss = ls if sum_loss is None else sum_loss + ls
+            sum_acc = ac if sum_acc is None else sum_acc + ac
+            if (step + 1) % loggingStep == 0:
+                elapsed = time.perf_counter() - start_time
+                print(f"Update {step + 1}\nelapsed: {elapsed:.1f} s")
+                print(f"{1000.0 * elapsed / loggingStep:.1f} ms per batch, {1000.0 * elapsed / n_examples:.1f} ms / example")
+                print("locLoss_train", (sum_loss / it).cpu().numpy())
+                start_time, n_examples = time.perf_counter(), 0
+    if scheduler is not None:
+        scheduler.step()
+    if it > 0:
+        logs["locLoss_train"] = (sum_loss / it).cpu().numpy()
+        logs["locAcc_train"] = (sum_acc / it).cpu().numpy()
+    logs["iter"] = it
+    return logs
+
+
+def valStep(dataLoader, cpcModel, cpcCriterion, device=None):
+    """train.py:145-187."""
+    cpcCriterion.eval()
+    cpcModel.eval()
+    device = device or next(cpcModel.parameters()).device
+    it = 0
+    sum_loss = sum_acc = None
+    for full_data in dataLoader:
+        sequence, label, *_ = full_data
+        sequence, label = sequence.to(device, non_blocking=True), label.to(device, non_blocking=True)
+        past, future = sequence[:, 0, ...], sequence[:, 1, ...]
+        with torch.no_grad():
+            _, allLosses, allAcc = cpcStep(past, future, label, cpcModel, cpcCriterion, None)
+        it += 1
+        ls, ac = allLosses.mean(dim=0), allAcc.mean(dim=0)
+        sum_loss = ls if sum_loss is None else sum_loss + ls
+        sum_acc = ac if sum_acc is None else sum_acc + ac
+    logs = {"iter": it}
+    if it > 0:
+        logs["locLoss_val"] = (sum_loss / it).cpu().numpy()
+        logs["locAcc_val"] = (sum_acc / it).cpu().numpy()
+    return logs
+
+
+def init_distributed_mode(backend="nccl"):
+    """distributed_mode.py:75-142 reduced to the torch.distributed.run environment: RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR/PORT; one process per GPU; backend 'nccl' is RCCL on ROCm."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(init_method="env://", backend=backend, world_size=world, rank=rank)
+    return rank, local_rank, world

@@ -1,0 +1,169 @@
+/*
+ * cpc2_hip.h -- C ABI of the MI355X-native CPC training hot path (libcpc2_hip.so).
+ *
+ * The reference (MarvinLvn/CPC2) has no FFI/operator registry on this path: its boundary is
+ * the Python nn.Module API of cpc/model.py and cpc/criterion/criterion.py, under which it
+ * dispatches PyTorch ATen ops.  This library is what sits UNDER that boundary here: each entry
+ * point replaces the ATen call sequence of one reference function (cited per function as
+ * file:line relative to /root/reference).  The Python modules under cpc2_amd/ keep the
+ * reference's class names,
+ * constructor/forward signatures and state-dict keys and call these through ctypes.
+ *
+ * Conventions
+ *   - plain C, no torch types; all pointers are DEVICE pointers unless named *_host.
+ *   - the caller allocates every buffer (inputs, outputs, saved-for-backward workspace,
+ *     scratch); sizes come from the *_bytes() queries; the library never frees or retains.
+ *   - all work is enqueued on `stream` (a hipStream_t); no internal synchronisation.
+ *   - every function returns 0 on success, a negative cpc_status otherwise;
+ *     cpc_last_error() gives a thread-local message.
+ *   - fp32 everywhere (the reference's arithmetic); activations are CHANNEL-LAST
+ *     ([windows][frames][channels]) inside the library.
+ *   - hidden sizes supported by the fused row kernels: 32, 64, 128, 256, 512.
+ */
+#ifndef CPC2_HIP_H
+#define CPC2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *cpc_stream_t; /* hipStream_t */
+
+enum cpc_status {
+    CPC_OK = 0,
+    CPC_ERR_INVALID = -1, /* bad argument / unsupported shape */
+    CPC_ERR_HIP = -2,     /* a HIP runtime call or kernel launch failed */
+    CPC_ERR_WORKSPACE = -3 /* workspace / scratch too small */
+};
+
+int cpc_version(void);
+const char *cpc_last_error(void);
+
+/* In-situ kernel timing for bench.py: when enabled, the launchers bracket each launch of the named
+ * kernel class with hipEvents on the launch stream.  cpc_prof_read sums and releases the finished
+ * records of one class: "gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd",
+ * "conv0_fwd", "conv0_bwd".  Off by default. */
+int cpc_prof_enable(int on);
+int cpc_prof_read(const char *name, double *total_ms, long *count);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense fp32 GEMMs on the f32 MFMA (v_mfma_f32_32x32x2_f32).  Replace the ATen addmm/linear
+ * calls behind nn.Linear / nn.GRU input projections (criterion.py:144-146,163; model.py:196).
+ *   nt:  C[M,N] = A[M,K] . B[N,K]^T (+ bias[N])          (lda/ldb/ldc in elements)
+ *   tn:  C[M,N] = sum_r A[r,M]^T . B[r,N], r < R   (split over R; scratch from the query)
+ * ------------------------------------------------------------------------------------------ */
+int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,
+                const float *bias, int M, int N, int K, cpc_stream_t stream);
+size_t cpc_gemm_tn_scratch_bytes(int M, int N, long R);
+int cpc_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc,
+                int M, int N, long R, void *scratch, size_t scratch_bytes, cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ChannelNorm on a channel-FIRST tensor x[N,C,L] (standalone module API, model.py:27-60):
+ * per (n,l) statistics over C, UNBIASED variance, y = (x-mean)*rsqrt(var+eps)*w[c]+b[c].
+ * w/b may be NULL (affine=False).  rstd_save[N*L] is written by forward, read by backward.
+ * ------------------------------------------------------------------------------------------ */
+int cpc_channelnorm_forward(const float *x, const float *w, const float *b, float *y,
+                            float *rstd_save, int N, int C, int L, float eps, cpc_stream_t stream);
+int cpc_channelnorm_backward(const float *x, const float *w, const float *dy, const float *rstd_save,
+                             float *dx, float *dw, float *db, int N, int C, int L, float eps,
+                             cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CPCEncoder (model.py:63-108): five strided Conv1d (k,s,p) = (10,5,3),(8,4,2),(4,2,1)x3, each
+ * followed by ChannelNorm (model.py:52-60) and ReLU.
+ *   x        [n_windows, 1, length]                     raw waveform
+ *   params   20 pointers in state-dict order: for i in 0..4:
+ *              conv{i}.weight [H, Cin, k], conv{i}.bias [H],
+ *              batchNorm{i}.weight [1,H,1], batchNorm{i}.bias [1,H,1]
+ *   z        [n_windows, frames, H] channel-last output (== reference output.permute(0,2,1),
+ *            i.e. exactly what CPCModel.forward hands on, model.py:382)
+ *   saved    activations kept for backward (cpc_encoder_saved_bytes)
+ *   scratch  temporaries (cpc_encoder_scratch_bytes; same query serves forward and backward)
+ *   grads    20 pointers, same order/shapes as params; overwritten (not accumulated)
+ * ------------------------------------------------------------------------------------------ */
+int cpc_encoder_frames(int length);
+size_t cpc_encoder_saved_bytes(int n_windows, int length, int hidden);
+size_t cpc_encoder_scratch_bytes(int n_windows, int length, int hidden);
+int cpc_encoder_forward(const float *x, const float *const *params, float *z, void *saved,
+                        void *scratch, int n_windows, int length, int hidden, float eps,
+                        cpc_stream_t stream);
+int cpc_encoder_backward(const float *x, const float *const *params, const float *dz, void *saved,
+                         void *scratch, float *const *grads, int n_windows, int length, int hidden,
+                         float eps, cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CPCAR with mode="GRU" (model.py:158-207 -> torch.nn.GRU, batch_first, gate order r,z,n).
+ *   x       [n, t, dim_in]
+ *   params  4 pointers per layer: weight_ih_l{k} [3H, in], weight_hh_l{k} [3H, H],
+ *           bias_ih_l{k} [3H], bias_hh_l{k} [3H]
+ *   h0      [layers, n, H] or NULL (zeros)          (model.py:196, keepHidden :197-201)
+ *   out     [n, t, H];  h_last [layers, n, H] or NULL
+ *   backward: dout [n,t,H] -> dx [n,t,dim_in] (may be NULL), grads (4 per layer, overwritten)
+ * ------------------------------------------------------------------------------------------ */
+size_t cpc_gru_saved_bytes(int n, int t, int dim_in, int hidden, int layers);
+size_t cpc_gru_scratch_bytes(int n, int t, int dim_in, int hidden, int layers);
+int cpc_gru_forward(const float *x, const float *const *params, const float *h0, float *out,
+                    float *h_last, void *saved, void *scratch, int n, int t, int dim_in, int hidden,
+                    int layers, cpc_stream_t stream);
+int cpc_gru_backward(const float *x, const float *const *params, const float *dout, void *saved,
+                     void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
+                     int hidden, int layers, cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Negative-index sampler of CPCUnsupersivedCriterion.sampleClean (criterion.py:247-266), HOST
+ * side, bit-exact with torch's CPU generator: 32-bit MT19937, one draw per element,
+ * batchIdx = draw % batch (all n first), then seqIdx = draw % (T-1) + 1;
+ * extIdx[(bb*n_neg + nn)*W + t] = (seqIdx + t) % T + batchIdx*T.
+ * State interop: mt[624], left, next as in torch's CPUGeneratorImpl legacy state.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cpc_mt19937 cpc_mt19937;
+cpc_mt19937 *cpc_mt_create(uint32_t seed);
+void cpc_mt_destroy(cpc_mt19937 *g);
+int cpc_mt_seed(cpc_mt19937 *g, uint32_t seed);
+int cpc_mt_get_state(const cpc_mt19937 *g, uint32_t *mt624, int *left, int *next);
+int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left, int next);
+int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg,
+                           int32_t *ext_idx_host, int64_t *batch_idx_host_opt,
+                           int64_t *seq_idx_host_opt);
+
+/* ------------------------------------------------------------------------------------------
+ * CPCUnsupersivedCriterion.forward with linear predictors (criterion.py:329-363, 291-302,
+ * 237-286, PredictionNetwork.forward :152-173): K predictions W_k c_t, scored by dot product / H
+ * against 1 positive z[b, t+k] + n_neg gathered negatives, cross-entropy vs class 0.
+ * The gathered candidate tensors of the reference are never materialised.
+ *   c        [b, T, dim_ar]   context (only t < W = T-K is used)
+ *   z        [b, T, dim_enc]  encoder targets
+ *   wpred    [K, dim_enc, dim_ar] packed nn.Linear weights (predictors.k.weight)
+ *   ext_idx  [b, n_neg, W] int32 rows of z.view(b*T, dim_enc) (cpc_negidx_sample_host layout)
+ *   weights  [b*W] per-sample loss weights or NULL (ones)        (criterion.py:334-340)
+ *   losses   [K]  mean_i(w_i * CE_i);  acc [K] = #(argmax == 0) / (b*W)
+ * backward: dlosses [K] upstream gradient -> dc [b,T,dim_ar], dz [b,T,dim_enc],
+ *           dwpred [K,dim_enc,dim_ar]  (all overwritten; dz uses fp32 atomics)
+ * ------------------------------------------------------------------------------------------ */
+size_t cpc_infonce_saved_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
+size_t cpc_infonce_scratch_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
+int cpc_infonce_forward(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
+                        const float *weights, float *losses, float *acc, void *saved, void *scratch,
+                        int b, int t, int k, int dim_ar, int dim_enc, int n_neg, cpc_stream_t stream);
+int cpc_infonce_backward(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
+                         const float *weights, const float *dlosses, void *saved, void *scratch,
+                         float *dc, float *dz, float *dwpred, int b, int t, int k, int dim_ar,
+                         int dim_enc, int n_neg, cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam on one flat fp32 buffer (torch.optim.Adam as built at train.py:477-479: no weight decay,
+ * no amsgrad).  g is multiplied by grad_scale first (1/world_size after an all-reduce SUM).
+ *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * ------------------------------------------------------------------------------------------ */
+int cpc_adam_step(float *p, const float *g, float *m, float *v, long n, int step, float lr,
+                  float beta1, float beta2, float eps, float grad_scale, cpc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPC2_HIP_H */

@@ -1,0 +1,114 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol that
+include/cpc2_hip.h declares, the host-side negative-index sampler is bit-exact against the
+reference golden vectors, the module classes keep the reference's state-dict contract, and the
+product refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cpc2_amd
+from cpc2_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cpc2_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(cpc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in cpc2_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().cpc_version() >= 100
+
+
+def test_shape_queries_and_error_reporting():
+    lib = _lib.load()
+    assert lib.cpc_encoder_frames(20480) == 128
+    assert lib.cpc_encoder_frames(64000) == 400
+    assert lib.cpc_encoder_saved_bytes(4, 20480, 256) > 0
+    assert lib.cpc_encoder_saved_bytes(4, 20480, 100) == 0          # unsupported hidden size
+    assert b"not supported" in lib.cpc_last_error()
+    assert lib.cpc_infonce_saved_bytes(8, 128, 12, 256, 256, 128) > 0
+    assert lib.cpc_infonce_saved_bytes(8, 128, 17, 256, 256, 128) == 0
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_sampler_bit_exact_vs_reference(golden, tag):
+    g = golden("g1_negidx.npz")
+    seed, b, t_len, k, nn = (int(v) for v in g[f"{tag}_cfg"])
+    s = cpc2_amd.criterion.NegativeSampler()
+    s.seed(seed)
+    ext, bi, si = s.sample_host(b, t_len, t_len - k, nn, want_parts=True)
+    assert np.array_equal(ext.numpy().astype(np.int64), g[f"{tag}_extIdx"])
+    assert np.array_equal(bi.numpy(), g[f"{tag}_batchIdx"])
+    assert np.array_equal(si.numpy(), g[f"{tag}_seqIdx"])
+
+
+def test_sampler_full_size_follows_torch_generator(golden):
+    g = golden("g1_negidx.npz")
+    seed, b, t_len, k, nn = (int(v) for v in g["full_cfg"])
+    s = cpc2_amd.criterion.NegativeSampler()          # default: consumes torch's global CPU generator
+    torch.manual_seed(seed)
+    ext = s.sample_host(b, t_len, t_len - k, nn).numpy().astype("<i8")
+    assert hashlib.sha256(ext.tobytes()).hexdigest() == str(g["full_ext_sha256"])
+    ext2 = s.sample_host(b, t_len, t_len - k, nn).numpy().astype("<i8")     # next step, same stream
+    assert hashlib.sha256(ext2.tobytes()).hexdigest() == str(g["full_ext2_sha256"])
+    # the global generator was advanced by exactly 4 * n draws
+    after = torch.randint(0, 1000, (8,))
+    torch.manual_seed(seed)
+    n = b * nn * (t_len - k)
+    for _ in range(2):
+        torch.randint(0, b, (n,))
+        torch.randint(1, t_len, (n,))
+    assert torch.equal(after, torch.randint(0, 1000, (8,)))
+
+
+def test_state_dict_contract_and_default_init(golden):
+    g = golden("g6_init_seed0_h64.npz")
+    torch.manual_seed(0)
+    enc = cpc2_amd.CPCEncoder(64, "layerNorm")
+    ar = cpc2_amd.CPCAR(64, 64, False, 1, mode="GRU", reverse=False)
+    model = cpc2_amd.CPCModel(enc, ar)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, 64, 64, 128, rnnMode="linear", sizeInputSeq=128)
+    sd = dict(model.state_dict())
+    sd.update(crit.state_dict())
+    ref_names = {k[len("abs."):] for k in g.files if k.startswith("abs.")}
+    assert set(sd) == ref_names
+    for name, v in sd.items():
+        assert tuple(v.shape) == tuple(int(x) for x in g["shape." + name]), name
+        ref = float(g["abs." + name])
+        assert abs(float(v.double().abs().sum()) - ref) <= 1e-6 * max(ref, 1.0), name
+    assert enc.DOWNSAMPLING == 160 and enc.dimEncoded == 64 and enc.getDimOutput() == 64 and ar.getDimOutput() == 64
+
+
+def test_constructor_errors_mirror_reference():
+    with pytest.raises(ValueError):
+        cpc2_amd.CPCEncoder(64, "nope")
+    with pytest.raises(ValueError):
+        cpc2_amd.CPCUnsupersivedCriterion(12, 64, 64, 128, mode="sideways", rnnMode="linear")
+
+
+def test_no_cpu_fallback():
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(32), cpc2_amd.CPCAR(32, 32, False, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(2, 1, 20480), None)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(4, 32, 32, 16, rnnMode="linear", sizeInputSeq=32)
+    with pytest.raises(RuntimeError):
+        crit(torch.zeros(2, 32, 32), torch.zeros(2, 32, 32), None)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "cpc2_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"

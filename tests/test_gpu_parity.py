@@ -1,0 +1,328 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, reached through the C ABI of
+libcpc2_hip.so, against (a) golden vectors produced by the reference implementation and (b) the
+CPU oracle (float64 where a tighter check of the fp32 kernels is useful).
+
+Tolerances: fp32 kernels vs fp64 oracle -> 2e-5 relative to the tensor's scale unless noted;
+the InfoNCE LOSS must be within 1e-3 relative (north_star), negative indices bit-exact."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cpc2_amd
+from cpc2_amd import _lib
+from cpc2_amd.train import FlatAdam, buildOptimizer, cpcStep
+from oracle import cpc_oracle as O
+from oracle import synth
+from oracle.mt19937 import MT19937, negative_indices
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def assert_close(got, ref, tol, what=""):
+    e = rel_err(got, ref)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def load_encoder(hidden, params):
+    enc = cpc2_amd.CPCEncoder(hidden)
+    enc.load_state_dict({k[len("gEncoder."):]: v for k, v in params.items()})
+    return enc.to(DEV)
+
+
+def to64(p):
+    return {k: v.double() for k, v in p.items()}
+
+
+# ----------------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 200, 72), (1, 5, 3), (1026, 256, 2048), (257, 770, 24)])
+def test_gemm_nt(m, n, k):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a, b, bias = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g), torch.randn(n, generator=g)
+    ad, bd, biasd = a.to(DEV), b.to(DEV), bias.to(DEV)
+    c = torch.full((m, n), float("nan"), device=DEV)
+    _lib.check(lib.cpc_gemm_nt(_lib.ptr(ad), k, _lib.ptr(bd), k, _lib.ptr(c), n, _lib.ptr(biasd), m, n, k, _lib.stream_ptr(c.device)))
+    ref = a.double() @ b.double().t() + bias.double()
+    assert_close(c, ref, 2e-6 * max(1, k ** 0.5), "gemm_nt")
+
+
+def test_gemm_nt_overlapping_rows_is_a_strided_conv():
+    """A rows with lda < K: the implicit-GEMM form of Conv1d over a channel-last signal."""
+    lib = _lib.load()
+    c_in, c_out, k, s, length = 32, 64, 8, 4, 400
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(length, c_in, generator=g)                       # channel-last
+    w = torch.randn(c_out, c_in, k, generator=g)
+    rows = (length - k) // s + 1
+    wr = w.permute(0, 2, 1).reshape(c_out, k * c_in).contiguous()
+    out = torch.empty(rows, c_out, device=DEV)
+    xd, wd = x.to(DEV), wr.to(DEV)
+    _lib.check(lib.cpc_gemm_nt(_lib.ptr(xd), s * c_in, _lib.ptr(wd), k * c_in, _lib.ptr(out), c_out, None, rows, c_out, k * c_in,
+                               _lib.stream_ptr(out.device)))
+    ref = torch.nn.functional.conv1d(x.t().unsqueeze(0).double(), w.double(), stride=s)[0].t()
+    assert_close(out, ref, 1e-5, "strided-A gemm")
+
+
+@pytest.mark.parametrize("m,n,r", [(128, 128, 64), (256, 2048, 5000), (96, 24, 333), (3, 5, 7), (768, 256, 2064)])
+def test_gemm_tn(m, n, r):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + n + r)
+    a, b = torch.randn(r, m, generator=g), torch.randn(r, n, generator=g)
+    ad, bd = a.to(DEV), b.to(DEV)
+    c = torch.full((m, n), float("nan"), device=DEV)
+    nbytes = lib.cpc_gemm_tn_scratch_bytes(m, n, r)
+    sc = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cpc_gemm_tn(_lib.ptr(ad), m, _lib.ptr(bd), n, _lib.ptr(c), n, m, n, r, _lib.ptr(sc), nbytes, _lib.stream_ptr(c.device)))
+    ref = a.double().t() @ b.double()
+    assert_close(c, ref, 2e-6 * max(1, r ** 0.5), "gemm_tn")
+
+
+# ----------------------------------------------------------------------------- ChannelNorm (standalone, channel-first)
+def test_channelnorm_module_vs_reference_golden(golden):
+    g = golden("g3_channelnorm.npz")
+    cn = cpc2_amd.ChannelNorm(16).to(DEV)
+    cn.weight.data.copy_(t(g["w"]))
+    cn.bias.data.copy_(t(g["b"]))
+    x = t(g["x"]).to(DEV).requires_grad_(True)
+    y = cn(x)
+    (y * t(g["g"]).to(DEV)).sum().backward()
+    assert_close(y, t(g["y"]), 1e-5, "y")
+    assert_close(x.grad, t(g["dx"]), 2e-5, "dx")
+    assert_close(cn.weight.grad, t(g["dw"]), 2e-5, "dw")
+    assert_close(cn.bias.grad, t(g["db"]), 2e-5, "db")
+
+
+# ----------------------------------------------------------------------------- encoder
+def test_encoder_vs_reference_golden(golden):
+    g = golden("g2_encoder_h32.npz")
+    hidden = int(g["hidden"])
+    enc = load_encoder(hidden, synth.encoder_params(hidden, int(g["param_seed"])))
+    x = synth.audio_windows(2, 20480, int(g["x_seed"])).to(DEV)
+    out = enc(x)
+    assert out.shape == (2, hidden, 128)
+    assert_close(out, t(g["out"]), 2e-5, "encoder output")
+    (out * synth.features((2, hidden, 128), int(g["gout_seed"])).to(DEV)).sum().backward()
+    for name, p in enc.named_parameters():
+        assert_close(p.grad, t(g["grad." + name]), 1e-4, f"grad {name}")
+
+
+@pytest.mark.parametrize("hidden,n,length", [(256, 3, 20480), (64, 2, 3300), (512, 2, 4800), (128, 1, 20480)])
+def test_encoder_vs_oracle_fp64(hidden, n, length):
+    params = synth.encoder_params(hidden, seed=5)
+    enc = load_encoder(hidden, params)
+    x = synth.audio_windows(n, length, seed=6)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    ref = O.encoder_forward(x.double(), p64, "gEncoder.")
+    gout = synth.features(tuple(ref.shape), seed=7)
+    (ref * gout.double()).sum().backward()
+    out = enc(x.to(DEV))
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close(out, ref, 2e-5, "encoder output")
+    (out * gout.to(DEV)).sum().backward()
+    for name, p in enc.named_parameters():
+        assert_close(p.grad, p64["gEncoder." + name].grad, 2e-4, f"grad {name}")
+
+
+# ----------------------------------------------------------------------------- GRU
+def load_ar(hin, hid, layers, params, reverse=False, keep=False):
+    ar = cpc2_amd.CPCAR(hin, hid, keep, layers, mode="GRU", reverse=reverse)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in params.items()})
+    return ar.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["l1", "l2"])
+def test_gru_vs_reference_golden(golden, tag):
+    g = golden("g4_gru.npz")
+    hin, hid, layers, n, t_len = (int(v) for v in g[f"{tag}_cfg"])
+    ar = load_ar(hin, hid, layers, synth.gru_params(hin, hid, layers, 41))
+    x = synth.features((n, t_len, hin), 42, relu=True).to(DEV).requires_grad_(True)
+    out = ar(x)
+    assert_close(out, t(g[f"{tag}_out"]), 1e-5, "gru out")
+    (out * synth.features((n, t_len, hid), 43).to(DEV)).sum().backward()
+    assert_close(x.grad, t(g[f"{tag}_dx"]), 1e-4, "gru dx")
+    for name, p in ar.named_parameters():
+        assert_close(p.grad, t(g[f"{tag}_grad." + name]), 1e-4, f"gru grad {name}")
+
+
+def test_gru_reverse_and_keep_hidden(golden):
+    g = golden("g4_gru.npz")
+    params = synth.gru_params(32, 32, 1, 41)
+    x = synth.features((3, 20, 32), 42, relu=True).to(DEV)
+    assert_close(load_ar(32, 32, 1, params, reverse=True)(x), t(g["rev_out"]), 1e-5, "reverse")
+    # keepHidden: two half-sequences with carried state == one full sequence (model.py:197-201)
+    full = load_ar(32, 32, 1, params)(x)
+    ar = load_ar(32, 32, 1, params, keep=True)
+    halves = torch.cat([ar(x[:, :10].contiguous()), ar(x[:, 10:].contiguous())], dim=1)
+    assert_close(halves, full, 1e-6, "keepHidden")
+
+
+@pytest.mark.parametrize("hid,layers,n,t_len", [(256, 1, 5, 128), (512, 2, 3, 40)])
+def test_gru_vs_oracle_fp64(hid, layers, n, t_len):
+    params = synth.gru_params(hid, hid, layers, 9)
+    ar = load_ar(hid, hid, layers, params)
+    x = synth.features((n, t_len, hid), 10, relu=True)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x.double().requires_grad_(True)
+    ref, _ = O.gru_forward(x64, p64, layers, "gAR.baseNet.")
+    gout = synth.features((n, t_len, hid), 11)
+    (ref * gout.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = ar(xd)
+    assert_close(out, ref, 1e-5, "gru out")
+    (out * gout.to(DEV)).sum().backward()
+    assert_close(xd.grad, x64.grad, 1e-4, "gru dx")
+    for name, p in ar.named_parameters():
+        assert_close(p.grad, p64["gAR." + name].grad, 1e-4, f"gru grad {name}")
+
+
+# ----------------------------------------------------------------------------- criterion
+def make_criterion(k, har, henc, nn, pseed, scale=4.0, **kw):
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, har, henc, nn, rnnMode="linear", sizeInputSeq=999, **kw)
+    crit.load_state_dict(synth.predictor_params(k, har, henc, seed=pseed, scale=scale))
+    return crit.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["plain", "skip", "reverse", "quality", "rect"])
+def test_criterion_small_vs_reference_golden(golden, tag):
+    g = golden("g5_criterion_small.npz")
+    har = 24 if tag == "rect" else 32
+    kw = {}
+    if tag == "skip":
+        kw["n_skipped"] = 1
+    if tag == "reverse":
+        kw["mode"] = "reverse"
+    if tag == "quality":
+        kw.update(growth_rate=2.0, inflection_point_x=0.1)
+    crit = make_criterion(4, har, 32, 16, 50, **kw)
+    c = synth.features((4, 32, har), 51).to(DEV).requires_grad_(True)
+    z = synth.features((4, 32, 32), 52, relu=True).to(DEV).requires_grad_(True)
+    quality = t(g["quality_signal"]).to(DEV) if tag == "quality" else None
+    torch.manual_seed(99)                      # the reference drew its negatives from this CPU stream
+    losses, acc = crit(c, z, None, quality)
+    assert losses.shape == tuple(g[f"{tag}_losses"].shape)
+    assert_close(losses, t(g[f"{tag}_losses"]), 2e-6, "losses")
+    assert torch.allclose(acc.cpu(), t(g[f"{tag}_acc"]), atol=1.5 / (4 * 28))
+    losses.sum().backward()
+    assert_close(c.grad, t(g[f"{tag}_dc"]), 5e-5, "dc")
+    assert_close(z.grad, t(g[f"{tag}_dz"]), 5e-5, "dz")
+    for i in range(4):
+        w = crit.wPrediction.predictors[i].weight
+        ref = t(g[f"{tag}_dW{i}"])
+        if float(ref.abs().max()) == 0.0:
+            assert w.grad is None or float(w.grad.abs().max()) == 0.0
+        else:
+            assert_close(w.grad, ref, 5e-5, f"dW{i}")
+
+
+def test_criterion_full_shape_vs_reference_golden(golden):
+    """Config-C2 shapes (T=128, H=256, K=12, 128 negatives) at b=8; loss within 1e-3 relative (north_star)."""
+    g = golden("g5_criterion_full.npz")
+    crit = make_criterion(12, 256, 256, 128, 60)
+    c = synth.features((8, 128, 256), 61).to(DEV).requires_grad_(True)
+    z = synth.features((8, 128, 256), 62, relu=True).to(DEV).requires_grad_(True)
+    torch.manual_seed(1234)
+    losses, acc = crit(c, z, None)
+    assert_close(losses, t(g["losses"]), 1e-5, "losses")          # far inside the 1e-3 requirement
+    assert torch.allclose(acc.cpu(), t(g["acc"]), atol=3e-3)
+    losses.sum().backward()
+    assert_close(c.grad[:, :3, :8], t(g["dc_head"]), 1e-4, "dc head")
+    assert_close(z.grad[:, :3, :8], t(g["dz_head"]), 1e-4, "dz head")
+    assert_close(z.grad[:, -3:, :8], t(g["dz_tail"]), 1e-4, "dz tail")
+    for name, ten in (("dc", c.grad), ("dz", z.grad)):
+        got, ref = float(ten.double().abs().sum()), float(g[f"{name}_abs"])
+        assert abs(got - ref) <= 1e-4 * ref, name
+    for i in range(12):
+        w = crit.wPrediction.predictors[i].weight.grad
+        assert abs(float(w.double().abs().sum()) - float(g[f"dW{i}_abs"])) <= 1e-4 * float(g[f"dW{i}_abs"])
+        assert_close(w[:4, :8], t(g[f"dW{i}_head"]), 2e-4, f"dW{i} head")
+
+
+def test_criterion_indices_on_device_are_bit_exact(golden):
+    g = golden("g1_negidx.npz")
+    seed, b, t_len, k, nn = (int(v) for v in g["mid_cfg"])
+    crit = make_criterion(k, 32, 32, nn, 50)
+    torch.manual_seed(seed)
+    ext = crit.sampleIndices(b, t_len, t_len - k, torch.device(DEV))
+    assert np.array_equal(ext.cpu().numpy().astype(np.int64), g["mid_extIdx"])
+
+
+def test_criterion_properties_at_full_size():
+    """b=64 (BASELINE config C2): untrained-predictor loss is ln(1+Nneg) for every step; the loss does not
+    depend on a common shift of all logits; gradients are finite and dz rows beyond reach are zero."""
+    b, t_len, h, k, nn = 64, 128, 256, 12, 128
+    crit = make_criterion(k, h, h, nn, 70, scale=0.0)            # zero predictors -> uniform logits
+    c = synth.features((b, t_len, h), 71).to(DEV).requires_grad_(True)
+    z = synth.features((b, t_len, h), 72, relu=True).to(DEV).requires_grad_(True)
+    crit.seed(5)
+    losses, acc = crit(c, z, None)
+    assert torch.allclose(losses.cpu(), torch.full((1, k), float(np.log(nn + 1))), atol=1e-5)
+    assert torch.allclose(acc.cpu(), torch.ones(1, k))          # all ties -> index 0 wins (criterion.py:356)
+    crit2 = make_criterion(k, h, h, nn, 73, scale=2.0)
+    crit2.seed(5)
+    l2, _ = crit2(c, z, None)
+    l2.sum().backward()
+    assert torch.isfinite(c.grad).all() and torch.isfinite(z.grad).all()
+    assert float(c.grad[:, t_len - k:].abs().max()) == 0.0       # context frames >= W are never used
+    # two identical calls with the same index stream agree to fp32 atomics noise
+    crit2.seed(5)
+    l3, _ = crit2(c, z, None)
+    assert torch.equal(l2, l3)
+
+
+# ----------------------------------------------------------------------------- Adam + full train steps
+def test_fused_adam_vs_oracle():
+    g = torch.Generator().manual_seed(0)
+    p0 = {"a": torch.randn(1000, generator=g), "b": torch.randn(33, 7, generator=g)}
+    prm = [torch.nn.Parameter(v.clone().to(DEV)) for v in p0.values()]
+    opt = FlatAdam(prm, lr=2e-4)
+    ref = O.Adam({k: v.clone().double() for k, v in p0.items()}, lr=2e-4)
+    for step in range(5):
+        grads = {k: torch.randn(v.shape, generator=g) for k, v in p0.items()}
+        for p, gr in zip(prm, grads.values()):
+            p.grad.copy_(gr.to(DEV))
+        opt.step()
+        ref.step({k: v.double() for k, v in grads.items()})
+    for p, r in zip(prm, ref.params.values()):
+        assert_close(p.data, r, 1e-6, "adam params")
+
+
+def test_train_steps_reproduce_reference_loss_curve(golden):
+    """G6: 20 Adam steps, H=64, b=4, reference semantics (model on cat([past, future]))."""
+    g = golden("g6_trainsteps.npz")
+    hidden, b, k, nn, steps, seed = (int(v) for v in g["cfg"])
+    mp = synth.encoder_params(hidden, 21)
+    mp.update(synth.gru_params(hidden, hidden, 1, 22))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+    model.load_state_dict(mp)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, hidden, hidden, nn, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(synth.predictor_params(k, hidden, hidden, 23))
+    model, crit = model.to(DEV), crit.to(DEV)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    x = synth.audio_windows(b, 20480, 24).to(DEV)
+    label = torch.zeros(b, dtype=torch.long, device=DEV)
+    torch.manual_seed(seed)
+    curve = []
+    for _ in range(steps):
+        tot, losses, _acc = cpcStep(x, x, label, model, crit)
+        tot.backward()
+        opt.step()
+        opt.zero_grad()
+        curve.append(losses.detach())
+    curve = torch.cat(curve).cpu()
+    ref = t(g["curve"])
+    err = ((curve - ref).abs() / ref.abs()).max()
+    assert err <= 1e-3, f"loss curve deviates by {float(err):.2e} relative"
+    assert_close(model.state_dict()["gEncoder.conv0.weight"], t(g["final.gEncoder.conv0.weight"]), 2e-3, "conv0.weight after 20 steps")
