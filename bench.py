@@ -24,6 +24,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.perf_counter()
 WINDOW = 20480
 SECONDS_PER_WINDOW = WINDOW / 16000.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
@@ -73,12 +74,30 @@ def build(cfg, device):
     return model, crit, opt
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this process: affinity mask, capped by the cgroup quota and by 16 (the GPU box's
+    per-GPU share; its host has many more cores than the job may use)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("CPC_BENCH_MAX_CORES", "16"))))
+
+
 def cpu_baseline(cfg, seconds_budget):
     """The oracle's train step (CPU restatement of the reference, fp32 torch-CPU ops) timed on this
     host's cores on a bounded sample of the same workload."""
     from oracle import cpc_oracle as O, synth
     from oracle.mt19937 import MT19937
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
+    log(f"cpu baseline on {torch.get_num_threads()} threads")
     b, h = 8, cfg["hidden"]
     mp = synth.encoder_params(h, 1)
     mp.update(synth.gru_params(h, h, cfg["layers"], 2))
@@ -95,11 +114,13 @@ def cpu_baseline(cfg, seconds_budget):
         opt.step(dict(zip(params, grads)))
 
     step()                                                  # warm-up
+    log("cpu baseline warm-up step done")
     t0 = time.perf_counter()
     n = 0
     while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
         step()
         n += 1
+        log(f"cpu baseline step {n}")
     dt = (time.perf_counter() - t0) / n
     return {"value": round(b * SECONDS_PER_WINDOW / dt, 3), "unit": "audio-seconds/sec",
             "cores": torch.get_num_threads(), "kind": "port",
@@ -147,9 +168,14 @@ def main():
         opt.zero_grad()
         return losses
 
-    for _ in range(args.warmup):
+    log(f"rank {rank}: model built, starting {args.warmup} warm-up steps")
+    for i in range(args.warmup):
         losses = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     torch.cuda.synchronize()
+    log("warm-up done")
     if world > 1:
         dist.barrier()
     prof = not args.no_prof
@@ -164,6 +190,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     lib.cpc_prof_enable(0)
+    log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

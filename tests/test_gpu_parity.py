@@ -325,4 +325,8 @@ def test_train_steps_reproduce_reference_loss_curve(golden):
     ref = t(g["curve"])
     err = ((curve - ref).abs() / ref.abs()).max()
     assert err <= 1e-3, f"loss curve deviates by {float(err):.2e} relative"
-    assert_close(model.state_dict()["gEncoder.conv0.weight"], t(g["final.gEncoder.conv0.weight"]), 2e-3, "conv0.weight after 20 steps")
+    # Adam moves every weight by ~lr per step whatever the gradient's size, so weights whose gradient is
+    # fp32 noise may differ by up to steps*lr = 4e-3 absolute; the bulk must agree much more closely.
+    got, ref_w = model.state_dict()["gEncoder.conv0.weight"].cpu(), t(g["final.gEncoder.conv0.weight"])
+    assert float((got - ref_w).abs().max()) <= steps * 2e-4
+    assert float((got - ref_w).abs().mean()) <= 2e-5, float((got - ref_w).abs().mean())
