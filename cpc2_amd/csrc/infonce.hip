@@ -149,24 +149,22 @@ template <int H> __global__ __launch_bounds__(256) void infonce_fwd_kernel(NceAr
     }
 }
 
-// losses[k] = sum_i lossp[i][k] / count ; acc[k] = sum_i hit[i][k] / count     (one workgroup)
+// losses[k] = sum_i lossp[i][k] / count ; acc[k] = sum_i hit[i][k] / count     (one workgroup per output)
 __global__ void infonce_reduce_kernel(const float *lossp, const float *hit, long rows, int K, float inv_count, float *losses, float *acc)
 {
     __shared__ float red[256];
-    for (int k = 0; k < 2 * K; ++k) {
-        const float *src = k < K ? lossp : hit;
-        const int kk = k < K ? k : k - K;
-        float s = 0.f;
-        for (long r = threadIdx.x; r < rows; r += blockDim.x) s += src[r * K + kk];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) (k < K ? losses : acc)[kk] = red[0] * inv_count;
+    const int k = blockIdx.x;
+    const float *src = k < K ? lossp : hit;
+    const int kk = k < K ? k : k - K;
+    float s = 0.f;
+    for (long r = threadIdx.x; r < rows; r += blockDim.x) s += src[r * K + kk];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
+    if (threadIdx.x == 0) (k < K ? losses : acc)[kk] = red[0] * inv_count;
 }
 
 // Backward: grid over b*T; workgroups with t >= W only zero their dP row.
@@ -352,7 +350,7 @@ static int infonce_forward(const float *c, const float *z, const float *wpred, c
     }
     CPC_TRY(status);
     CPC_CHECK_LAUNCH("infonce_fwd_kernel");
-    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, l.lossp, l.hit, (long)b * l.W, K, a.inv_count, losses, acc);
+    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(2 * K), dim3(256), 0, st, l.lossp, l.hit, (long)b * l.W, K, a.inv_count, losses, acc);
     CPC_CHECK_LAUNCH("infonce_reduce_kernel");
     return CPC_OK;
 }

@@ -47,18 +47,27 @@ ProfScope::~ProfScope()
 }
 
 // ---------------------------------------------------------------- column sums
+// block (64 columns x 16 row lanes): coalesced along columns, rows strided over threadIdx.y, LDS tree over y
 __global__ void colsum_kernel(const float *part, long rows, long ld, int width, float *out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+    __shared__ float red[16][65];
+    const int c = blockIdx.x * 64 + threadIdx.x;
     float s = 0.f;
-    for (long r = 0; r < rows; ++r) s += part[r * ld + c];
-    out[c] = s;
+    if (c < width)
+        for (long r = threadIdx.y; r < rows; r += 16) s += part[r * ld + c];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 int colsum(const float *part, long rows, long ld, int width, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(width, 64)), dim3(64), 0, st, part, rows, ld, width, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(width, 64)), dim3(64, 16), 0, st, part, rows, ld, width, out);
     CPC_CHECK_LAUNCH("colsum_kernel");
     return CPC_OK;
 }
