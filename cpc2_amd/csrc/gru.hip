@@ -5,16 +5,14 @@
 //
 // Forward per layer: one MFMA GEMM for all input projections GI = X W_ih^T + b_ih, then ONE
 // persistent kernel for the T sequential steps.  Windows are independent, so each workgroup owns
-// GRU_NB windows for the whole sequence (no inter-workgroup synchronisation); thread j owns hidden
-// unit j, keeps h in LDS and streams W_hh (re-laid out so that lanes read consecutive float4s)
-// from L2 every step.  Backward mirrors it (BPTT), then three GEMMs give dW_hh, dW_ih and dX.
+// one window for the whole sequence (no inter-workgroup synchronisation); thread (j, q) owns hidden
+// unit j and K slice q, h lives in LDS and W_hh (re-laid out so that lanes read consecutive float4s)
+// is streamed from L2 every step.  Backward mirrors it (BPTT), then three GEMMs give dW_hh, dW_ih and dX.
 #include "common.h"
 
 #include <algorithm>
 
 namespace cpc {
-
-constexpr int GRU_NB = 2;   // windows per workgroup
 
 // W_hh [3H][H] -> wf[(k4*3 + g)*H + j] = W[g*H + j][4*k4 .. 4*k4+3]   (forward: thread j, all k)
 __global__ void gru_pack_fwd_kernel(const float *w, float4 *wf, int H)
@@ -54,154 +52,142 @@ struct GruArgs {
     float *hn;            // [N*T][H]     W_hn h + b_hn
     float *hlast;         // [N][H] or null
     int N, T, H;
+    int hp, kq;           // threads = kq * hp: hp = H rounded up to 64, kq = K-split factor
     // backward
     const float *dout;    // [N][T][H]
     float *dgi;           // [N*T][3H]
     float *dgh;           // [N][T+1][3H], row T zero
 };
 
+// One workgroup per window; thread (j, q): hidden unit j, K slice q.  The K split puts kq x more waves
+// (and W_hh loads) in flight per CU: the step time is the L2 -> CU stream of W_hh (3H*H*4 bytes).
 __global__ void gru_fwd_kernel(GruArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // hs[GRU_NB][H]
-    const int H = a.H, T = a.T;
-    const int j = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // hs[H] | red[kq][3][hp]
+    const int H = a.H, T = a.T, hp = a.hp, kq = a.kq;
+    float *hs = smem;
+    float *red = smem + ((H + 3) / 4) * 4;
+    const int j = threadIdx.x % hp, q = threadIdx.x / hp;
     const bool act = j < H;
-    const int n0 = blockIdx.x * GRU_NB;
-    float hprev[GRU_NB];
-#pragma unroll
-    for (int s = 0; s < GRU_NB; ++s) {
-        const int n = n0 + s;
-        hprev[s] = (act && n < a.N && a.h0 != nullptr) ? a.h0[(long)n * H + j] : 0.f;
-        if (act) {
-            smem[s * H + j] = hprev[s];
-            if (n < a.N) a.hall[((long)n * (T + 1)) * H + j] = hprev[s];
-        }
-    }
+    const int n = blockIdx.x;
+    const int k4_per = (H / 4 + kq - 1) / kq;
+    const int k4_lo = q * k4_per, k4_hi = min(H / 4, k4_lo + k4_per);
+
+    float hprev = 0.f;
     float bh[3] = {0.f, 0.f, 0.f};
-    if (act) { bh[0] = a.bhh[j]; bh[1] = a.bhh[H + j]; bh[2] = a.bhh[2 * H + j]; }
+    if (act && q == 0) {
+        hprev = a.h0 != nullptr ? a.h0[(long)n * H + j] : 0.f;
+        hs[j] = hprev;
+        a.hall[((long)n * (T + 1)) * H + j] = hprev;
+        bh[0] = a.bhh[j]; bh[1] = a.bhh[H + j]; bh[2] = a.bhh[2 * H + j];
+    }
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        float acc[GRU_NB][3];
-#pragma unroll
-        for (int s = 0; s < GRU_NB; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (act) {
             const float4 *wp = a.wpack + j;
-            for (int k4 = 0; k4 < H / 4; ++k4) {
+#pragma unroll 4
+            for (int k4 = k4_lo; k4 < k4_hi; ++k4) {
                 const float4 wr = wp[(long)(k4 * 3 + 0) * H];
                 const float4 wz = wp[(long)(k4 * 3 + 1) * H];
                 const float4 wn = wp[(long)(k4 * 3 + 2) * H];
-#pragma unroll
-                for (int s = 0; s < GRU_NB; ++s) {
-                    const float4 h4 = reinterpret_cast<const float4 *>(smem + s * H)[k4];
-                    acc[s][0] = fmaf(wr.x, h4.x, fmaf(wr.y, h4.y, fmaf(wr.z, h4.z, fmaf(wr.w, h4.w, acc[s][0]))));
-                    acc[s][1] = fmaf(wz.x, h4.x, fmaf(wz.y, h4.y, fmaf(wz.z, h4.z, fmaf(wz.w, h4.w, acc[s][1]))));
-                    acc[s][2] = fmaf(wn.x, h4.x, fmaf(wn.y, h4.y, fmaf(wn.z, h4.z, fmaf(wn.w, h4.w, acc[s][2]))));
-                }
+                const float4 h4 = reinterpret_cast<const float4 *>(hs)[k4];
+                acc0 = fmaf(wr.x, h4.x, fmaf(wr.y, h4.y, fmaf(wr.z, h4.z, fmaf(wr.w, h4.w, acc0))));
+                acc1 = fmaf(wz.x, h4.x, fmaf(wz.y, h4.y, fmaf(wz.z, h4.z, fmaf(wz.w, h4.w, acc1))));
+                acc2 = fmaf(wn.x, h4.x, fmaf(wn.y, h4.y, fmaf(wn.z, h4.z, fmaf(wn.w, h4.w, acc2))));
             }
+            red[(q * 3 + 0) * hp + j] = acc0;
+            red[(q * 3 + 1) * hp + j] = acc1;
+            red[(q * 3 + 2) * hp + j] = acc2;
         }
-        float hnew[GRU_NB];
-#pragma unroll
-        for (int s = 0; s < GRU_NB; ++s) {
-            const int n = n0 + s;
-            hnew[s] = 0.f;
-            if (act && n < a.N) {
-                const long row = (long)n * T + t;
-                const float *g = a.gi + row * 3 * H;
-                const float ghn = acc[s][2] + bh[2];
-                const float r = sigmoidf_(g[j] + acc[s][0] + bh[0]);
-                const float z = sigmoidf_(g[H + j] + acc[s][1] + bh[1]);
-                const float c = tanhf(g[2 * H + j] + r * ghn);
-                const float hv = (1.f - z) * c + z * hprev[s];
-                hnew[s] = hv;
-                float *gs = a.gates + row * 3 * H;
-                gs[j] = r; gs[H + j] = z; gs[2 * H + j] = c;
-                a.hn[row * H + j] = ghn;
-                a.out[row * H + j] = hv;
-                a.hall[((long)n * (T + 1) + t + 1) * H + j] = hv;
+        __syncthreads();                       // partial sums visible; nobody reads hs any more
+        if (act && q == 0) {
+            float g0 = bh[0], g1 = bh[1], g2 = bh[2];
+            for (int qq = 0; qq < kq; ++qq) {
+                g0 += red[(qq * 3 + 0) * hp + j];
+                g1 += red[(qq * 3 + 1) * hp + j];
+                g2 += red[(qq * 3 + 2) * hp + j];
             }
-        }
-        __syncthreads();            // every thread is done reading the old h
-        if (act) {
-#pragma unroll
-            for (int s = 0; s < GRU_NB; ++s) { smem[s * H + j] = hnew[s]; hprev[s] = hnew[s]; }
+            const long row = (long)n * T + t;
+            const float *g = a.gi + row * 3 * H;
+            const float r = sigmoidf_(g[j] + g0);
+            const float z = sigmoidf_(g[H + j] + g1);
+            const float c = tanhf(g[2 * H + j] + r * g2);
+            const float hv = (1.f - z) * c + z * hprev;
+            float *gs = a.gates + row * 3 * H;
+            gs[j] = r; gs[H + j] = z; gs[2 * H + j] = c;
+            a.hn[row * H + j] = g2;
+            a.out[row * H + j] = hv;
+            a.hall[((long)n * (T + 1) + t + 1) * H + j] = hv;
+            hs[j] = hv;
+            hprev = hv;
         }
         __syncthreads();
     }
-    if (act && a.hlast != nullptr) {
-#pragma unroll
-        for (int s = 0; s < GRU_NB; ++s)
-            if (n0 + s < a.N) a.hlast[(long)(n0 + s) * H + j] = hprev[s];
-    }
+    if (act && q == 0 && a.hlast != nullptr) a.hlast[(long)n * H + j] = hprev;
 }
 
 __global__ void gru_bwd_kernel(GruArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // dgh[GRU_NB][3H]
-    const int H = a.H, T = a.T;
-    const int j = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // dgh[3H] | red[kq][hp]
+    const int H = a.H, T = a.T, hp = a.hp, kq = a.kq;
+    float *dg = smem;
+    float *red = smem + 3 * H;
+    const int j = threadIdx.x % hp, q = threadIdx.x / hp;
     const bool act = j < H;
-    const int n0 = blockIdx.x * GRU_NB;
-    float carry[GRU_NB];
-#pragma unroll
-    for (int s = 0; s < GRU_NB; ++s) {
-        carry[s] = 0.f;
-        const int n = n0 + s;
-        if (act && n < a.N) {                                   // zero junk row T of dGH
-            float *zr = a.dgh + ((long)n * (T + 1) + T) * 3 * H;
-            zr[j] = 0.f; zr[H + j] = 0.f; zr[2 * H + j] = 0.f;
-        }
+    const int n = blockIdx.x;
+    const int g4_total = 3 * H / 4;
+    const int g4_per = (g4_total + kq - 1) / kq;
+    const int g4_lo = q * g4_per, g4_hi = min(g4_total, g4_lo + g4_per);
+
+    float carry = 0.f;
+    if (act && q == 0) {                                         // zero junk row T of dGH
+        float *zr = a.dgh + ((long)n * (T + 1) + T) * 3 * H;
+        zr[j] = 0.f; zr[H + j] = 0.f; zr[2 * H + j] = 0.f;
     }
     for (int t = T - 1; t >= 0; --t) {
-        float keep[GRU_NB];
-#pragma unroll
-        for (int s = 0; s < GRU_NB; ++s) {
-            const int n = n0 + s;
-            float dpr = 0.f, dpz = 0.f, dhn = 0.f;
-            keep[s] = 0.f;
-            if (act && n < a.N) {
-                const long row = (long)n * T + t;
-                const float dh = a.dout[row * H + j] + carry[s];
-                const float *gs = a.gates + row * 3 * H;
-                const float r = gs[j], z = gs[H + j], c = gs[2 * H + j];
-                const float hnv = a.hn[row * H + j];
-                const float hp = a.hall[((long)n * (T + 1) + t) * H + j];
-                const float dc = dh * (1.f - z);
-                const float dz = dh * (hp - c);
-                const float dpn = dc * (1.f - c * c);
-                dpr = dpn * hnv * r * (1.f - r);
-                dpz = dz * z * (1.f - z);
-                dhn = dpn * r;
-                keep[s] = dh * z;
-                float *gi = a.dgi + row * 3 * H;
-                gi[j] = dpr; gi[H + j] = dpz; gi[2 * H + j] = dpn;
-                float *gh = a.dgh + ((long)n * (T + 1) + t) * 3 * H;
-                gh[j] = dpr; gh[H + j] = dpz; gh[2 * H + j] = dhn;
-            }
-            if (act) {
-                smem[s * 3 * H + j] = dpr;
-                smem[s * 3 * H + H + j] = dpz;
-                smem[s * 3 * H + 2 * H + j] = dhn;
-            }
+        float keep = 0.f;
+        if (act && q == 0) {
+            const long row = (long)n * T + t;
+            const float dh = a.dout[row * H + j] + carry;
+            const float *gs = a.gates + row * 3 * H;
+            const float r = gs[j], z = gs[H + j], c = gs[2 * H + j];
+            const float hnv = a.hn[row * H + j];
+            const float hp_ = a.hall[((long)n * (T + 1) + t) * H + j];
+            const float dc = dh * (1.f - z);
+            const float dz = dh * (hp_ - c);
+            const float dpn = dc * (1.f - c * c);
+            const float dpr = dpn * hnv * r * (1.f - r);
+            const float dpz = dz * z * (1.f - z);
+            const float dhn = dpn * r;
+            keep = dh * z;
+            float *gi = a.dgi + row * 3 * H;
+            gi[j] = dpr; gi[H + j] = dpz; gi[2 * H + j] = dpn;
+            float *gh = a.dgh + ((long)n * (T + 1) + t) * 3 * H;
+            gh[j] = dpr; gh[H + j] = dpz; gh[2 * H + j] = dhn;
+            dg[j] = dpr; dg[H + j] = dpz; dg[2 * H + j] = dhn;
         }
         __syncthreads();
         if (act) {
-            float acc[GRU_NB];
-#pragma unroll
-            for (int s = 0; s < GRU_NB; ++s) acc[s] = 0.f;
+            float acc = 0.f;
             const float4 *wp = a.wpack + j;
-            for (int g4 = 0; g4 < 3 * H / 4; ++g4) {
+#pragma unroll 4
+            for (int g4 = g4_lo; g4 < g4_hi; ++g4) {
                 const float4 w4 = wp[(long)g4 * H];
-#pragma unroll
-                for (int s = 0; s < GRU_NB; ++s) {
-                    const float4 d4 = reinterpret_cast<const float4 *>(smem + s * 3 * H)[g4];
-                    acc[s] = fmaf(w4.x, d4.x, fmaf(w4.y, d4.y, fmaf(w4.z, d4.z, fmaf(w4.w, d4.w, acc[s]))));
-                }
+                const float4 d4 = reinterpret_cast<const float4 *>(dg)[g4];
+                acc = fmaf(w4.x, d4.x, fmaf(w4.y, d4.y, fmaf(w4.z, d4.z, fmaf(w4.w, d4.w, acc))));
             }
-#pragma unroll
-            for (int s = 0; s < GRU_NB; ++s) carry[s] = keep[s] + acc[s];
+            red[q * hp + j] = acc;
         }
         __syncthreads();
+        if (act && q == 0) {
+            float sum = keep;
+            for (int qq = 0; qq < kq; ++qq) sum += red[qq * hp + j];
+            carry = sum;
+        }
+        // the next iteration's writes to dg happen after every thread passed the barrier above; its reads of
+        // red happen after the next two barriers -> no extra barrier needed here
     }
 }
 
@@ -253,7 +239,8 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
 {
     GruLayout g;
     CPC_TRY(gru_layout(g, N, T, Din, H, layers, saved, scratch));
-    const int threads = std::max(64, (int)cdiv(H, 64) * 64);
+    const int hp = std::max(64, (int)cdiv(H, 64) * 64);
+    const int kq = std::max(1, std::min(1024 / hp, H / 4));
     const float *xin = x;
     int din = Din;
     for (int l = 0; l < layers; ++l) {
@@ -268,10 +255,11 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         a.out = (l + 1 < layers) ? g.outl[l] : out;
         a.hall = g.hall[l]; a.gates = g.gates[l]; a.hn = g.hn[l];
         a.hlast = h_last ? h_last + (size_t)l * N * H : nullptr;
-        a.N = N; a.T = T; a.H = H;
+        a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
         {
             ProfScope prof(PROF_GRU_FWD, st);
-            hipLaunchKernelGGL(gru_fwd_kernel, dim3((unsigned)cdiv(N, GRU_NB)), dim3(threads), sizeof(float) * GRU_NB * H, st, a);
+            const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * 3 * hp);
+            hipLaunchKernelGGL(gru_fwd_kernel, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
         }
         CPC_CHECK_LAUNCH("gru_fwd_kernel");
         xin = a.out;
@@ -285,7 +273,8 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
 {
     GruLayout g;
     CPC_TRY(gru_layout(g, N, T, Din, H, layers, saved, scratch));
-    const int threads = std::max(64, (int)cdiv(H, 64) * 64);
+    const int hp = std::max(64, (int)cdiv(H, 64) * 64);
+    const int kq = std::max(1, std::min(1024 / hp, H / 4));
     const float *dcur = dout;
     for (int l = layers - 1; l >= 0; --l) {
         const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1];
@@ -295,11 +284,12 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         CPC_CHECK_LAUNCH("gru_pack_bwd_kernel");
         GruArgs a{};
         a.wpack = g.wpack; a.hall = g.hall[l]; a.gates = g.gates[l]; a.hn = g.hn[l];
-        a.N = N; a.T = T; a.H = H;
+        a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
         {
             ProfScope prof(PROF_GRU_BWD, st);
-            hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)cdiv(N, GRU_NB)), dim3(threads), sizeof(float) * GRU_NB * 3 * H, st, a);
+            const size_t lds = sizeof(float) * ((size_t)3 * H + (size_t)kq * hp);
+            hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
         }
         CPC_CHECK_LAUNCH("gru_bwd_kernel");
 
