@@ -67,22 +67,24 @@ class NegativeSampler:
         st[24:24 + 624 * 8].view(np.uint64)[:] = mt.astype(np.uint64)
         torch.set_rng_state(torch.from_numpy(st))
 
-    def sample_host(self, batch, seq_len, window, n_neg, out=None, want_parts=False):
-        """int32 extIdx [batch, n_neg, window] on the host (criterion.py:247-266)."""
+    def sample_host(self, batch, seq_len, window, n_neg, out=None, want_parts=False, time_major=False):
+        """int32 extIdx on the host (criterion.py:247-266): [batch, n_neg, window] in the reference's
+        order, or the same values as [batch, window, n_neg] with time_major (the kernels' layout)."""
         n = batch * n_neg * window
         if out is None:
             out = torch.empty(n, dtype=torch.int32)
         bidx = torch.empty(n, dtype=torch.int64) if want_parts else None
         sidx = torch.empty(n, dtype=torch.int64) if want_parts else None
         st = self._pull_torch_state() if self.follow_torch else None
-        check(self._lib.cpc_negidx_sample_host(self._h, batch, seq_len, window, n_neg, ptr(out), ptr(bidx), ptr(sidx)),
-              "negidx_sample_host")
+        check(self._lib.cpc_negidx_sample_host(self._h, batch, seq_len, window, n_neg, int(time_major), ptr(out),
+                                               ptr(bidx), ptr(sidx)), "negidx_sample_host")
         if st is not None:
             self._push_torch_state(st)
         return (out, bidx, sidx) if want_parts else out
 
-    def sample(self, batch, seq_len, window, n_neg, device):
-        """Device int32 extIdx; staged through a small ring of pinned buffers (async copy)."""
+    def sample(self, batch, seq_len, window, n_neg, device, time_major=True):
+        """Device int32 extIdx (time-major by default: what the fused kernels read); staged through a
+        small ring of pinned buffers (async copy)."""
         n = batch * n_neg * window
         key = (n, str(device))
         if key not in self._ring:
@@ -94,7 +96,7 @@ class NegativeSampler:
         if ev is not None:
             ev.synchronize()          # the copy that last used this staging buffer has finished
         host = self._ring[key][slot]
-        self.sample_host(batch, seq_len, window, n_neg, out=host)
+        self.sample_host(batch, seq_len, window, n_neg, out=host, time_major=time_major)
         dev = host.to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
@@ -114,7 +116,7 @@ class _InfoNCEFn(torch.autograd.Function):
         if z.shape != (b, t, dim_enc) or wpred.shape[2] != dim_ar:
             raise ValueError(f"shape mismatch c={tuple(c.shape)} z={tuple(z.shape)} W={tuple(wpred.shape)}")
         if ext_idx.dtype != torch.int32 or ext_idx.numel() != b * n_neg * (t - k):
-            raise ValueError("ext_idx must be int32 [b, n_neg, W]")
+            raise ValueError("ext_idx must be int32 [b, W, n_neg]")
         w = f32c(weights) if weights is not None else None
         nsaved = lib.cpc_infonce_saved_bytes(b, t, k, dim_ar, dim_enc, n_neg)
         nscratch = lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg)
@@ -237,9 +239,11 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             cFeature = torch.flip(cFeature, [1])
         return cFeature, encodedData
 
-    def sampleIndices(self, batchSize, nNegativeExt, windowSize, device):
-        """Device int32 extIdx [batchSize, negativeSamplingExt, windowSize] (criterion.py:247-266)."""
-        return self.sampler.sample(batchSize, nNegativeExt, windowSize, self.negativeSamplingExt, device)
+    def sampleIndices(self, batchSize, nNegativeExt, windowSize, device, time_major=True):
+        """Device int32 extIdx (criterion.py:247-266): [batchSize, windowSize, negativeSamplingExt] when
+        time_major (the kernels' layout), else the reference's [batchSize, negativeSamplingExt, windowSize]."""
+        return self.sampler.sample(batchSize, nNegativeExt, windowSize, self.negativeSamplingExt, device,
+                                   time_major=time_major)
 
     def forward(self, cFeature, encodedData, label, signal_quality=None):
         batchSize, seqSize, _ = cFeature.size()

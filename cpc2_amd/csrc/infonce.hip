@@ -3,10 +3,10 @@
 // :237-286 (sampleClean), :152-173 (PredictionNetwork.forward).
 //
 // The reference materialises, for each of the K prediction steps, a [b, 1+Nneg, W, H] candidate tensor
-// (11.8 GB at b=64) and a same-size product.  Here one workgroup owns one (window b, frame t): it keeps
-// the K predictions P_k = W_k c_t in LDS, GATHERS candidate rows of z (L2/MALL resident) into LDS in
-// chunks, scores all K x candidates with the f32 MFMA and does the cross-entropy in place; only the
-// logits (for backward), K partial losses and K hit flags leave the kernel.
+// (11.8 GB at b=64) and a same-size product.  Here one WAVE owns one (window b, frame t): it keeps the K
+// predictions P_k = W_k c_t in registers, streams the gathered candidate rows of z (8.4 MB, L2/MALL
+// resident) straight into the MFMA operand, scores all K x candidates with the f32 MFMA and does the
+// cross-entropy in registers; only the logits (for backward), K partial losses and K hit flags leave it.
 //
 // Candidate list of a workgroup: 16 "positive-tile" rows z[b][t+1 .. t+16] (the positive of step k is
 // column k of that tile -- computed by the same MFMA chain as the negatives, so a negative that happens
@@ -23,22 +23,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NCE_ROWS = 16;   // MFMA M: predictions padded to 16 rows
 constexpr int NCE_POS = 16;    // positive-tile columns
 
-template <int H> struct NceCfg {
-    static constexpr int NC = (H <= 256) ? 64 : 32;   // candidates per LDS chunk
-    static constexpr int LD = H + 4;                   // padded LDS row (floats)
-};
-
 struct NceArgs {
     const float *P;        // [b*T][K*H]  predictions
     const float *z;        // [b*T][H]
-    const int32_t *ext;    // [b][Nneg][W]
+    const int32_t *ext;    // [b][W][Nneg]  TIME-MAJOR index layout (the negatives of one (b,t) are contiguous)
     const float *weights;  // [b*W] or null
     float *logits;         // [b*W][K][Nneg+1]
     float *lse;            // [b*W][K]
     float *lossp;          // [b*W][K]   w * CE
     float *hit;            // [b*W][K]   1 if argmax == 0
     int b, T, W, K, Nneg;
-    int lw;                // LDS logits/dS row length (floats), multiple of 4
+    int lw;                // LDS dS row length (floats), multiple of 4
     // backward
     const float *dloss;    // [K]
     float *dP;             // [b*T][K*H]
@@ -46,105 +41,110 @@ struct NceArgs {
     float inv_count;       // 1 / (b*W)
 };
 
-// gathers candidates [c0, c0+NC) of the workgroup's list into Cs (zero rows where the slot is empty)
-template <int H> __device__ __forceinline__ void nce_gather(float *Cs, int *rowidx, const NceArgs &a, int bb, int t, int c0)
+// z row of candidate g of (bb, t): g < 16 -> positive tile (row t+1+g, only g < K), else negative g-16
+__device__ __forceinline__ long nce_row(const NceArgs &a, int bb, int t, int g)
 {
-    constexpr int NC = NceCfg<H>::NC, LD = NceCfg<H>::LD;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < NC; i += 4) {
-        const int g = c0 + i;                    // global candidate index
-        long row = -1;
-        if (g < NCE_POS) {
-            const int tt = t + 1 + g;
-            if (g < a.K && tt < a.T) row = (long)bb * a.T + tt;
-        } else if (g - NCE_POS < a.Nneg) {
-            row = a.ext[((long)bb * a.Nneg + (g - NCE_POS)) * a.W + t];
-        }
-        if (lane == 0 && rowidx != nullptr) rowidx[i] = (int)row;
-        for (int d4 = lane; d4 < H / 4; d4 += 64) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row >= 0) v = reinterpret_cast<const float4 *>(a.z + row * H)[d4];
-            *reinterpret_cast<float4 *>(&Cs[i * LD + 4 * d4]) = v;
-        }
-    }
+    if (g < NCE_POS) return (g < a.K && t + 1 + g < a.T) ? (long)bb * a.T + t + 1 + g : -1;
+    const int j = g - NCE_POS;
+    return j < a.Nneg ? (long)a.ext[((long)bb * a.W + t) * a.Nneg + j] : -1;
 }
 
-template <int H> __device__ __forceinline__ void nce_load_p(float *Ps, const NceArgs &a, long bt_row)
+// Forward: ONE WAVE per (b,t), no LDS, no barriers.  The wave keeps its K predictions (the MFMA A
+// operand, P[k][16kk + 4q ..]) in registers and walks the candidate tiles; each lane streams the 16-byte
+// pieces of "its" candidate row straight from L2 into the MFMA B operand (lane (r,q): candidate r of the
+// tile, k-slice q), so a gathered row is read exactly once and never staged.  Logits of a tile land as
+// acc[e] = <P_{4q+e}, cand_r> / H; the cross-entropy is an online (max, sum-exp) over tiles, merged across
+// the 16 lanes of a row group at the end.
+template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArgs a)
 {
-    constexpr int LD = NceCfg<H>::LD;
-    const float *src = a.P + bt_row * a.K * H;
-    for (int i = threadIdx.x; i < NCE_ROWS * (H / 4); i += blockDim.x) {
-        const int k = i / (H / 4), d4 = i - k * (H / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < a.K) v = reinterpret_cast<const float4 *>(src + (long)k * H)[d4];
-        *reinterpret_cast<float4 *>(&Ps[k * LD + 4 * d4]) = v;
-    }
-}
-
-template <int H> __global__ __launch_bounds__(256) void infonce_fwd_kernel(NceArgs a)
-{
-    constexpr int NC = NceCfg<H>::NC, LD = NceCfg<H>::LD;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ps = smem;                          // [16][LD]
-    float *Cs = Ps + NCE_ROWS * LD;            // [NC][LD]
-    float *Ls = Cs + NC * LD;                  // [16][lw]   logits by global candidate index
-
+    constexpr int KK = H / 16;
     const int bt = blockIdx.x;
     const int bb = bt / a.W, t = bt - bb * a.W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     const float inv_h = 1.f / H;
 
-    nce_load_p<H>(Ps, a, (long)bb * a.T + t);
-    const int ncand = NCE_POS + a.Nneg;
-    for (int c0 = 0; c0 < ncand; c0 += NC) {
-        __syncthreads();                       // Cs free (and Ps visible on the first pass)
-        nce_gather<H>(Cs, nullptr, a, bb, t, c0);
-        __syncthreads();
-        if (wave < NC / 16 && c0 + wave * 16 < ncand) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float *pa = &Ps[(lane & 15) * LD + 4 * (lane >> 4)];
-            const float *pb = &Cs[(wave * 16 + (lane & 15)) * LD + 4 * (lane >> 4)];
-#pragma unroll 4
-            for (int kk = 0; kk < H / 16; ++kk) {
-                const float4 av = *reinterpret_cast<const float4 *>(pa + 16 * kk);
-                const float4 bv = *reinterpret_cast<const float4 *>(pb + 16 * kk);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-            }
-            // acc[r] = <P_k, cand_g>, k = 4*(lane>>4) + r, g = c0 + 16*wave + (lane&15)
-            const int g = c0 + wave * 16 + (lane & 15);
+    float4 areg[KK];
+    {
+        const float *prow = a.P + ((long)bb * a.T + t) * a.K * H + (long)r * H + 4 * q;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 4 * (lane >> 4) + r;
-                if (k < a.K && g < ncand) Ls[k * a.lw + g] = acc[r] * inv_h;
+        for (int kk = 0; kk < KK; ++kk)
+            areg[kk] = r < a.K ? *reinterpret_cast<const float4 *>(prow + 16 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ntiles = 1 + (a.Nneg + 15) / 16;
+    float pos[4] = {0.f, 0.f, 0.f, 0.f};
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f};
+
+    long row = nce_row(a, bb, t, r);
+    float4 bcur[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+        bcur[kk] = row >= 0 ? *reinterpret_cast<const float4 *>(a.z + row * H + 4 * q + 16 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        // prefetch the next tile's rows while this one is multiplied
+        float4 bnext[KK];
+        const long nrow = (tile + 1 < ntiles) ? nce_row(a, bb, t, 16 * (tile + 1) + r) : -1;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            bnext[kk] = nrow >= 0 ? *reinterpret_cast<const float4 *>(a.z + nrow * H + 4 * q + 16 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].x, bcur[kk].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].y, bcur[kk].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].z, bcur[kk].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].w, bcur[kk].w, acc, 0, 0, 0);
+        }
+        if (tile == 0) {
+            // positive of step k = column k of this tile: lane 16q + (4q+e) of row group q holds it
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pos[e] = __shfl(acc[e], 16 * q + 4 * q + e, 64) * inv_h;
+        } else {
+            const int j = 16 * (tile - 1) + r;              // negative index of this lane's column
+            if (j < a.Nneg) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q + e;
+                    const float x = acc[e] * inv_h;
+                    if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + j] = x;
+                    const float mn = fmaxf(m[e], x);
+                    s[e] = s[e] * expf(m[e] - mn) + expf(x - mn);    // m = -inf: s = 0, exp(-inf) = 0
+                    m[e] = mn;
+                }
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bcur[kk] = bnext[kk];
     }
-    __syncthreads();
 
-    // cross-entropy vs class 0 (the positive = column k of the positive tile), criterion.py:345-357
-    const float wgt = a.weights != nullptr ? a.weights[bt] : 1.f;
-    for (int k = wave; k < a.K; k += 4) {
-        const float *lrow = Ls + k * a.lw;
-        const float pos = lrow[k];
-        float mneg = -INFINITY;
-        for (int j = lane; j < a.Nneg; j += 64) mneg = fmaxf(mneg, lrow[NCE_POS + j]);
-        for (int off = 32; off > 0; off >>= 1) mneg = fmaxf(mneg, __shfl_xor(mneg, off, 64));
-        const float m = fmaxf(mneg, pos);
-        float se = 0.f;
-        for (int j = lane; j < a.Nneg; j += 64) se += expf(lrow[NCE_POS + j] - m);
-        for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
-        se += expf(pos - m);
-        const float lse = m + logf(se);
-        float *lg = a.logits + ((long)bt * a.K + k) * (a.Nneg + 1);
-        for (int j = lane; j < a.Nneg; j += 64) lg[1 + j] = lrow[NCE_POS + j];
-        if (lane == 0) {
-            lg[0] = pos;
-            a.lse[(long)bt * a.K + k] = lse;
-            a.lossp[(long)bt * a.K + k] = wgt * (lse - pos);
-            a.hit[(long)bt * a.K + k] = pos >= mneg ? 1.f : 0.f;    // first-index-wins argmax
+    // merge (m, s) over the 16 lanes of the row group; lanes that saw no candidate carry (-inf, 0)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const float m2 = __shfl_xor(m[e], off, 64), s2 = __shfl_xor(s[e], off, 64);
+            const float mn = fmaxf(m[e], m2);
+            const float f1 = (m[e] == -INFINITY) ? 0.f : expf(m[e] - mn);
+            const float f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+            s[e] = s[e] * f1 + s2 * f2;
+            m[e] = mn;
+        }
+    }
+    if (r == 0) {
+        const float wgt = a.weights != nullptr ? a.weights[bt] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * q + e;
+            if (k < a.K) {
+                const float mx = fmaxf(m[e], pos[e]);
+                const float se = s[e] * expf(m[e] - mx) + expf(pos[e] - mx);
+                const float lse = mx + logf(se);
+                a.logits[((long)bt * a.K + k) * (a.Nneg + 1)] = pos[e];
+                a.lse[(long)bt * a.K + k] = lse;
+                a.lossp[(long)bt * a.K + k] = wgt * (lse - pos[e]);
+                a.hit[(long)bt * a.K + k] = pos[e] >= m[e] ? 1.f : 0.f;       // first-index-wins argmax
+            }
         }
     }
 }
@@ -167,33 +167,34 @@ __global__ void infonce_reduce_kernel(const float *lossp, const float *hit, long
     if (threadIdx.x == 0) (k < K ? losses : acc)[kk] = red[0] * inv_count;
 }
 
-// Backward: grid over b*T; workgroups with t >= W only zero their dP row.
-template <int H> __global__ __launch_bounds__(256) void infonce_bwd_kernel(NceArgs a)
+// Backward: ONE WAVE per (b,t) of the b*T grid (t >= W only zeroes its dP row).  LDS (private to the wave)
+// holds dS[16][lw] = d loss / d <P_k, cand_g> and the candidates' z-row indices.
+//   dP^T[d][k] += sum_g cand_g[d] * dS[k][g]    16x16x4, A = candidate rows streamed from L2 as float4s: lane
+//                 (i, q) reads cand_{4s+q}[64T + 4i ..+3] and feeds the 4 row-interleaved tiles d = 64T + 4i + e
+//   dz[row_g][d] += sum_k dS[k][g] * P_k[d]     32x32x2, output rows leave as 128-byte fp32 atomic segments
+template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArgs a)
 {
-    constexpr int NC = NceCfg<H>::NC, LD = NceCfg<H>::LD;
-    constexpr int DP_TILES = (H / 16 + 3) / 4;       // 16-wide dP column tiles per wave
+    constexpr int DG = (H + 63) / 64;          // groups of 4 interleaved 16-row d tiles (H = 32: half a group)
+    constexpr int DT32 = H / 32;               // 32-wide d tiles of the dz product
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ps = smem;                          // [16][LD]
-    float *Cs = Ps + NCE_ROWS * LD;            // [NC][LD]
-    float *dS = Cs + NC * LD;                  // [16][lw]   d loss / d <P_k, cand_g>
-    int *rowidx = reinterpret_cast<int *>(dS + NCE_ROWS * a.lw);   // [NC]
+    float *dS = smem;                                              // [16][lw]
+    int *rowidx = reinterpret_cast<int *>(dS + NCE_ROWS * a.lw);   // [lw]
 
     const int bb = blockIdx.x / a.T, t = blockIdx.x - bb * a.T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     float *dprow = a.dP + (long)blockIdx.x * a.K * H;
     if (t >= a.W) {
-        for (int i = threadIdx.x; i < a.K * H / 4; i += blockDim.x)
-            reinterpret_cast<float4 *>(dprow)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < a.K * H / 4; i += 64) reinterpret_cast<float4 *>(dprow)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const long bt = (long)bb * a.W + t;
     const int ncand = NCE_POS + a.Nneg;
+    const int npad = a.lw - 4;                                     // multiple of 32 >= ncand
     const float inv_h = 1.f / H;
     const float wgt = (a.weights != nullptr ? a.weights[bt] : 1.f) * a.inv_count;
 
-    nce_load_p<H>(Ps, a, (long)bb * a.T + t);
-    // dS[k][g]: softmax - onehot, scaled by upstream grad, weight, 1/count and 1/H
-    for (int i = threadIdx.x; i < NCE_ROWS * a.lw; i += blockDim.x) {
+    for (int g = lane; g < a.lw; g += 64) rowidx[g] = g < ncand ? (int)nce_row(a, bb, t, g) : -1;
+    for (int i = lane; i < NCE_ROWS * a.lw; i += 64) {
         const int k = i / a.lw, g = i - k * a.lw;
         float v = 0.f;
         if (k < a.K) {
@@ -208,64 +209,78 @@ template <int H> __global__ __launch_bounds__(256) void infonce_bwd_kernel(NceAr
         }
         dS[i] = v;
     }
+    __syncthreads();                           // one wave: orders the LDS writes before the reads below
 
-    f32x4 dp[DP_TILES];
+    // ---- dP ------------------------------------------------------------------------------------
+    f32x4 dp[DG][4];
 #pragma unroll
-    for (int i = 0; i < DP_TILES; ++i) dp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int c0 = 0; c0 < ncand; c0 += NC) {
-        __syncthreads();
-        nce_gather<H>(Cs, rowidx, a, bb, t, c0);
-        __syncthreads();
-
-        // dP[k][d] += sum_g dS[k][g] * cand_g[d]      (16x16x4: M = k, N = d tile, K = candidates)
+    for (int T4 = 0; T4 < DG; ++T4)
 #pragma unroll
-        for (int i = 0; i < DP_TILES; ++i) {
-            const int dt = wave + 4 * i;
-            if (dt < H / 16) {
-                for (int q = 0; q < NC / 16; ++q) {
-                    const float4 av = *reinterpret_cast<const float4 *>(&dS[(lane & 15) * a.lw + c0 + 16 * q + 4 * (lane >> 4)]);
-                    const float *pb = &Cs[(16 * q + 4 * (lane >> 4)) * LD + dt * 16 + (lane & 15)];
-                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, pb[0], dp[i], 0, 0, 0);
-                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, pb[LD], dp[i], 0, 0, 0);
-                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, pb[2 * LD], dp[i], 0, 0, 0);
-                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, pb[3 * LD], dp[i], 0, 0, 0);
-                }
+        for (int e = 0; e < 4; ++e) dp[T4][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < npad / 4; s0 += 4) {          // npad is a multiple of 32 -> npad/4 of 8
+        int rows4[4];
+        float bv4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = 4 * (s0 + u) + q;
+            rows4[u] = rowidx[g];
+            bv4[u] = dS[r * a.lw + g];
+        }
+        float4 av[4][DG];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *src = a.z + (long)(rows4[u] >= 0 ? rows4[u] : 0) * H + 4 * r;
+#pragma unroll
+            for (int T4 = 0; T4 < DG; ++T4) {
+                av[u][T4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rows4[u] >= 0 && 64 * T4 + 4 * r < H) av[u][T4] = *reinterpret_cast<const float4 *>(src + 64 * T4);
             }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int T4 = 0; T4 < DG; ++T4) {
+                dp[T4][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][T4].x, bv4[u], dp[T4][0], 0, 0, 0);
+                dp[T4][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][T4].y, bv4[u], dp[T4][1], 0, 0, 0);
+                dp[T4][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][T4].z, bv4[u], dp[T4][2], 0, 0, 0);
+                dp[T4][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][T4].w, bv4[u], dp[T4][3], 0, 0, 0);
+            }
+    }
+    // dp[T4][e][reg] = dP[k = r][d = 64*T4 + 4*(4q + reg) + e]  -> 16 consecutive d per (T4, lane)
+    if (r < a.K) {
+#pragma unroll
+        for (int T4 = 0; T4 < DG; ++T4)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (64 * T4 + 16 * q + 4 * reg < H)
+                    *reinterpret_cast<float4 *>(dprow + (long)r * H + 64 * T4 + 16 * q + 4 * reg) =
+                        make_float4(dp[T4][0][reg], dp[T4][1][reg], dp[T4][2][reg], dp[T4][3][reg]);
+    }
 
-        // dCand_g[d] = sum_k dS[k][g] * P_k[d] -> atomicAdd into dz[row_g]   (32x32x2: M = cand, N = d, K = k)
-        constexpr int NT = (NC / 32) * (H / 32);
-        for (int tt = wave; tt < NT; tt += 4) {
-            const int ct = tt % (NC / 32), dt = tt / (NC / 32);
+    // ---- dz ------------------------------------------------------------------------------------
+    const int r32 = lane & 31, h = lane >> 5;
+    const float *pbase = a.P + ((long)bb * a.T + t) * a.K * H;
+    for (int dt = 0; dt < DT32; ++dt) {
+        float bvals[NCE_ROWS / 2];
+#pragma unroll
+        for (int kp = 0; kp < NCE_ROWS / 2; ++kp) {
+            const int k = 2 * kp + h;
+            bvals[kp] = k < a.K ? pbase[(long)k * H + dt * 32 + r32] : 0.f;
+        }
+        for (int ct = 0; ct < npad / 32; ++ct) {
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
             for (int kp = 0; kp < NCE_ROWS / 2; ++kp) {
-                const int kr = 2 * kp + (lane >> 5);
-                const float av = dS[kr * a.lw + c0 + ct * 32 + (lane & 31)];
-                const float bv = Ps[kr * LD + dt * 32 + (lane & 31)];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                const float av = dS[(2 * kp + h) * a.lw + ct * 32 + r32];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvals[kp], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int ci = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int ci = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int row = rowidx[ci];
-                if (row >= 0) atomicAdd(a.dz + (long)row * H + dt * 32 + (lane & 31), acc[e]);
-            }
-        }
-    }
-
-    // dp[i][r] = dP[k = 4*(lane>>4) + r][d = dt*16 + (lane&15)]
-#pragma unroll
-    for (int i = 0; i < DP_TILES; ++i) {
-        const int dt = wave + 4 * i;
-        if (dt < H / 16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 4 * (lane >> 4) + r;
-                if (k < a.K) dprow[(long)k * H + dt * 16 + (lane & 15)] = dp[i][r];
+                if (row >= 0) atomicAdd(a.dz + (long)row * H + dt * 32 + r32, acc[e]);
             }
         }
     }
@@ -289,8 +304,7 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     CPC_REQUIRE(b > 0 && K >= 1 && K <= 16 && T > K && Nneg >= 1 && Har >= 1,
                 "infonce: bad shape b=%d T=%d K=%d (1..16) dim_ar=%d n_neg=%d", b, T, K, Har, Nneg);
     l.b = b; l.T = T; l.K = K; l.W = T - K; l.Har = Har; l.Henc = Henc; l.Nneg = Nneg;
-    const int nc = Henc <= 256 ? 64 : 32;
-    l.lw = (int)cdiv(NCE_POS + Nneg, nc) * nc + 4;
+    l.lw = (int)cdiv(NCE_POS + Nneg, 32) * 32 + 4;
     Carver sv(saved);
     l.P = sv.take<float>((size_t)b * T * K * Henc);
     l.logits = sv.take<float>((size_t)b * l.W * K * (Nneg + 1));
@@ -304,10 +318,9 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.tn_bytes = gemm_tn_scratch_bytes(K * Henc, Har, (long)b * T);
     l.tn = sc.take<float>(l.tn_bytes / sizeof(float));
     l.scratch_bytes = sc.used();
-    const size_t ld = Henc + 4;
-    l.lds_fwd = sizeof(float) * ((NCE_ROWS + nc) * ld + (size_t)NCE_ROWS * l.lw);
-    l.lds_bwd = l.lds_fwd + sizeof(int) * nc;
-    CPC_REQUIRE(l.lds_bwd <= 160 * 1024, "infonce: n_neg=%d needs %zu B of LDS (> 160 KiB)", Nneg, l.lds_bwd);
+    l.lds_fwd = 0;
+    l.lds_bwd = sizeof(float) * (size_t)NCE_ROWS * l.lw + sizeof(int) * (size_t)l.lw;
+    CPC_REQUIRE(l.lds_bwd <= 64 * 1024, "infonce: n_neg=%d needs %zu B of LDS (> 64 KiB)", Nneg, l.lds_bwd);
     return CPC_OK;
 }
 
@@ -345,7 +358,7 @@ static int infonce_forward(const float *c, const float *z, const float *wpred, c
         ProfScope prof(PROF_NCE_FWD, st);
         NCE_DISPATCH(Henc, {
             status = allow_lds(infonce_fwd_kernel<HH>, l.lds_fwd);
-            if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(b * l.W)), dim3(256), l.lds_fwd, st, a);
+            if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(b * l.W)), dim3(64), l.lds_fwd, st, a);
         });
     }
     CPC_TRY(status);
@@ -371,7 +384,7 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
         ProfScope prof(PROF_NCE_BWD, st);
         NCE_DISPATCH(Henc, {
             status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
-            if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(b * T)), dim3(256), l.lds_bwd, st, a);
+            if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(b * T)), dim3(64), l.lds_bwd, st, a);
         });
     }
     CPC_TRY(status);

@@ -105,8 +105,8 @@ extern "C" int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left,
     return CPC_OK;
 }
 
-extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int32_t *ext_idx_host,
-                                      int64_t *batch_idx_host_opt, int64_t *seq_idx_host_opt)
+extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major,
+                                      int32_t *ext_idx_host, int64_t *batch_idx_host_opt, int64_t *seq_idx_host_opt)
 {
     if (g == nullptr || ext_idx_host == nullptr || batch < 1 || seq_len < 2 || window < 1 || window > seq_len || n_neg < 1) {
         cpc::set_error("cpc_negidx_sample_host: bad arguments (batch=%d seq_len=%d window=%d n_neg=%d)", batch, seq_len, window, n_neg);
@@ -122,14 +122,16 @@ extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, in
     draw(g, raw_b, n);      // batchIdx stream first (criterion.py:247-250)
     draw(g, raw_s, n);      // then seqIdx (criterion.py:253-256)
     const uint32_t ub = (uint32_t)batch, us = (uint32_t)(seq_len - 1);
-    size_t i = 0;
+    size_t i = 0;                   // draw order: i = (bb*n_neg + nn)*window + t   (criterion.py:259-263)
     for (size_t row = 0; row < (size_t)n_neg * batch; ++row) {
+        const size_t bb = row / (size_t)n_neg, nn = row % (size_t)n_neg;
         for (int t = 0; t < window; ++t, ++i) {
             const uint32_t bi = raw_b[i] % ub;
             const uint32_t si = raw_s[i] % us + 1u;
             uint32_t seq = si + (uint32_t)t;
             if (seq >= (uint32_t)seq_len) seq -= (uint32_t)seq_len;     // si <= T-1, t <= T-1 -> one wrap at most
-            ext_idx_host[i] = (int32_t)(seq + bi * (uint32_t)seq_len);
+            const size_t o = time_major ? (bb * (size_t)window + (size_t)t) * (size_t)n_neg + nn : i;
+            ext_idx_host[o] = (int32_t)(seq + bi * (uint32_t)seq_len);
             if (batch_idx_host_opt) batch_idx_host_opt[i] = (int64_t)bi;
             if (seq_idx_host_opt) seq_idx_host_opt[i] = (int64_t)si;
         }

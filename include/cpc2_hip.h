@@ -117,7 +117,9 @@ int cpc_gru_backward(const float *x, const float *const *params, const float *do
  * Negative-index sampler of CPCUnsupersivedCriterion.sampleClean (criterion.py:247-266), HOST
  * side, bit-exact with torch's CPU generator: 32-bit MT19937, one draw per element,
  * batchIdx = draw % batch (all n first), then seqIdx = draw % (T-1) + 1;
- * extIdx[(bb*n_neg + nn)*W + t] = (seqIdx + t) % T + batchIdx*T.
+ * extIdx[(bb*n_neg + nn)*W + t] = (seqIdx + t) % T + batchIdx*T   (draw / reference order).
+ * time_major != 0 stores the SAME values as [b][W][n_neg] (the negatives of one (b,t) contiguous):
+ * the layout cpc_infonce_* consume.  batch_idx/seq_idx outputs (optional) stay in draw order.
  * State interop: mt[624], left, next as in torch's CPUGeneratorImpl legacy state.
  * ------------------------------------------------------------------------------------------ */
 typedef struct cpc_mt19937 cpc_mt19937;
@@ -127,7 +129,7 @@ int cpc_mt_seed(cpc_mt19937 *g, uint32_t seed);
 int cpc_mt_get_state(const cpc_mt19937 *g, uint32_t *mt624, int *left, int *next);
 int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left, int next);
 int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg,
-                           int32_t *ext_idx_host, int64_t *batch_idx_host_opt,
+                           int time_major, int32_t *ext_idx_host, int64_t *batch_idx_host_opt,
                            int64_t *seq_idx_host_opt);
 
 /* ------------------------------------------------------------------------------------------
@@ -138,7 +140,8 @@ int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, i
  *   c        [b, T, dim_ar]   context (only t < W = T-K is used)
  *   z        [b, T, dim_enc]  encoder targets
  *   wpred    [K, dim_enc, dim_ar] packed nn.Linear weights (predictors.k.weight)
- *   ext_idx  [b, n_neg, W] int32 rows of z.view(b*T, dim_enc) (cpc_negidx_sample_host layout)
+ *   ext_idx  [b, W, n_neg] int32 rows of z.view(b*T, dim_enc): cpc_negidx_sample_host with
+ *            time_major = 1 (same values as the reference's [b, n_neg, W] order, transposed)
  *   weights  [b*W] per-sample loss weights or NULL (ones)        (criterion.py:334-340)
  *   losses   [K]  mean_i(w_i * CE_i);  acc [K] = #(argmax == 0) / (b*W)
  * backward: dlosses [K] upstream gradient -> dc [b,T,dim_ar], dz [b,T,dim_enc],

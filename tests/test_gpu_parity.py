@@ -255,8 +255,11 @@ def test_criterion_indices_on_device_are_bit_exact(golden):
     seed, b, t_len, k, nn = (int(v) for v in g["mid_cfg"])
     crit = make_criterion(k, 32, 32, nn, 50)
     torch.manual_seed(seed)
-    ext = crit.sampleIndices(b, t_len, t_len - k, torch.device(DEV))
+    ext = crit.sampleIndices(b, t_len, t_len - k, torch.device(DEV), time_major=False)
     assert np.array_equal(ext.cpu().numpy().astype(np.int64), g["mid_extIdx"])
+    torch.manual_seed(seed)                     # kernel layout: same values, [b, W, n_neg]
+    ext_tm = crit.sampleIndices(b, t_len, t_len - k, torch.device(DEV)).cpu().numpy().astype(np.int64)
+    assert np.array_equal(ext_tm.reshape(b, t_len - k, nn), g["mid_extIdx"].reshape(b, nn, t_len - k).transpose(0, 2, 1))
 
 
 def test_criterion_properties_at_full_size():
