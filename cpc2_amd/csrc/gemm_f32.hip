@@ -30,23 +30,32 @@ struct GemmNTArgs {
     int aligned;   // K%4==0, lda%4==0, ldb%4==0, bases 16-B aligned
 };
 
-__device__ __forceinline__ float4 ld4_guard(const float *row, int k, int K, bool row_ok, bool aligned)
+// 4 consecutive elements k..k+3 of row `row` (k < K or zero).  Rows beyond row_max are CLAMPED, not zeroed:
+// for the output dimensions (M, N) such rows only feed outputs the epilogue discards.
+// ALIGNED (extent % 4 == 0, 16-byte aligned rows) and !KTAIL: one unconditional 16-byte load -- no branch and
+// no select, so a K step's 8 loads issue back to back and are waited for only where the LDS write needs them.
+template <bool ALIGNED, bool KTAIL>
+__device__ __forceinline__ float4 ld4(const float *base, long row, long row_max, long ld, int k, int K)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row_ok) {
-        if (aligned) {
-            if (k < K) v = *reinterpret_cast<const float4 *>(row + k);
-        } else {
-            if (k < K) v.x = row[k];
-            if (k + 1 < K) v.y = row[k + 1];
-            if (k + 2 < K) v.z = row[k + 2];
-            if (k + 3 < K) v.w = row[k + 3];
-        }
+    const long rc = row < row_max ? row : row_max - 1;
+    const float *r = base + rc * ld;
+    if (ALIGNED) {
+        if (!KTAIL) return *reinterpret_cast<const float4 *>(r + k);
+        const int kc = k < K ? k : K - 4;
+        float4 v = *reinterpret_cast<const float4 *>(r + kc);
+        if (k >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return v;
+    } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) v.x = r[k];
+        if (k + 1 < K) v.y = r[k + 1];
+        if (k + 2 < K) v.z = r[k + 2];
+        if (k + 3 < K) v.w = r[k + 3];
+        return v;
     }
-    return v;
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
+template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
 {
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_NT];
     float *As = lds;                  // [BM][LDS_NT]
@@ -68,13 +77,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
     const int lc4 = (tid & 7) * 4;
     float4 ra[4], rb[4];
 
-    auto load_tiles = [&](int k0) {
+    const int nk_full = p.K / BK;              // K tiles that need no tail handling
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        if (ALIGNED && kt < nk_full) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long m = m0 + lrow + 32 * q;
-            const int n = n0 + lrow + 32 * q;
-            ra[q] = ld4_guard(p.A + m * p.lda, k0 + lc4, p.K, m < p.M, p.aligned);
-            rb[q] = ld4_guard(p.B + (long)n * p.ldb, k0 + lc4, p.K, n < p.N, p.aligned);
+            for (int q = 0; q < 4; ++q) {
+                ra[q] = ld4<ALIGNED, false>(p.A, m0 + lrow + 32 * q, p.M, p.lda, k0 + lc4, p.K);
+                rb[q] = ld4<ALIGNED, false>(p.B, n0 + lrow + 32 * q, p.N, p.ldb, k0 + lc4, p.K);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[q] = ld4<ALIGNED, true>(p.A, m0 + lrow + 32 * q, p.M, p.lda, k0 + lc4, p.K);
+                rb[q] = ld4<ALIGNED, true>(p.B, n0 + lrow + 32 * q, p.N, p.ldb, k0 + lc4, p.K);
+            }
         }
     };
 
@@ -95,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
             *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * q) * LDS_NT + lc4]) = rb[q];
         }
         __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        if (kt + 1 < nk) load_tiles(kt + 1);
 
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
@@ -157,13 +174,14 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     GemmNTArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.map = map;
-    a.aligned = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+    a.aligned = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
     const long blocks = cdiv(M, BM) * cdiv(N, BN);
     CPC_REQUIRE(blocks <= 2147483647L, "gemm_nt: grid too large (%ld blocks)", blocks);
     dim3 grid((unsigned)blocks);
     ProfScope prof(PROF_GEMM_NT, st);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, st, a);
+    if (a.aligned) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
     return CPC_OK;
 }
@@ -178,12 +196,7 @@ struct GemmTNArgs {
     int aligned;
 };
 
-__device__ __forceinline__ float4 ld4_guard_cols(const float *row, int c, int ncols, bool row_ok, bool aligned)
-{
-    return ld4_guard(row, c, ncols, row_ok, aligned);
-}
-
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p)
+template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDS_TN];
     float *As = lds;                   // [BK][LDS_TN]  (row r, column i)
@@ -205,14 +218,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p)
     const int lr = tid >> 5;           // + 8*q
     const int lc = (tid & 31) * 4;
     float4 ra[4], rb[4];
+    // rows r are the REDUCTION index: rows >= rend must contribute zero (tail tile only); columns beyond
+    // M / N are clamped (they only feed outputs that are never stored).
+    const int ca = ALIGNED ? min(i0 + lc, p.M - 4) : i0 + lc;
+    const int cb = ALIGNED ? min(j0 + lc, p.N - 4) : j0 + lc;
     auto load_tiles = [&](long r0) {
+        const bool full = r0 + BK <= rend;              // uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long r = r0 + lr + 8 * q;
-            ra[q] = ld4_guard_cols(p.A + r * p.lda, i0 + lc, p.M, r < rend, p.aligned);
-            rb[q] = ld4_guard_cols(p.B + r * p.ldb, j0 + lc, p.N, r < rend, p.aligned);
+            const long rc = (full || r < rend) ? r : rend - 1;
+            float4 va, vb;
+            if (ALIGNED) {
+                va = *reinterpret_cast<const float4 *>(p.A + rc * p.lda + ca);
+                vb = *reinterpret_cast<const float4 *>(p.B + rc * p.ldb + cb);
+            } else {
+                va = ld4<false, true>(p.A + i0 + lc, rc, rend, p.lda, 0, p.M - (i0 + lc));
+                vb = ld4<false, true>(p.B + j0 + lc, rc, rend, p.ldb, 0, p.N - (j0 + lc));
+            }
+            ra[q] = va;
+            rb[q] = vb;
         }
+        return full;
     };
+    // zeroing of the tail tile's out-of-range rows is applied when the registers are written to LDS
+    // (after the MFMAs of the previous tile), so the loads above stay free of dependent selects.
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -223,15 +253,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (rbeg < rend) {
-        load_tiles(rbeg);
+        bool full = load_tiles(rbeg);
         for (long r0 = rbeg; r0 < rend; r0 += BK) {
+            if (!full) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + lr + 8 * q >= rend) {
+                        ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 *reinterpret_cast<float4 *>(&As[(lr + 8 * q) * LDS_TN + lc]) = ra[q];
                 *reinterpret_cast<float4 *>(&Bs[(lr + 8 * q) * LDS_TN + lc]) = rb[q];
             }
             __syncthreads();
-            if (r0 + BK < rend) load_tiles(r0 + BK);
+            if (r0 + BK < rend) full = load_tiles(r0 + BK);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 // MFMA tile (i_t, j_t) owns rows wm*64 + 2*r + i_t and columns wn*64 + 2*c + j_t (interleaved),
@@ -316,11 +354,12 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
     }
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.slab = static_cast<float *>(scratch);
     a.M = M; a.N = N; a.R = R; a.chunk = chunk;
-    a.aligned = (M % 4 == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+    a.aligned = (M % 4 == 0) && (N % 4 == 0) && (M >= 4) && (N >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
     dim3 grid((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM), (unsigned)S);
     ProfScope prof(PROF_GEMM_TN, st);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, a);
+    if (a.aligned) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_tn_kernel");
     const long total = (long)M * N;
     int blocks = (int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256));
