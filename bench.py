@@ -31,6 +31,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 CONFIGS = {
     "small": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU"),
     "large": dict(hidden=512, layers=2, npred=12, nneg=256, ar="GRU"),
+    "transformer": dict(hidden=256, layers=1, npred=12, nneg=128, ar="transformer"),    # BASELINE configs[3]
 }
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
@@ -52,8 +53,12 @@ def gemm_nt_algorithmic_flops(b, cfg):
     t_len = lens[5]
     din = h
     for _layer in range(cfg["layers"]):
-        flops += 2 * (2.0 * n * t_len * din * 3 * h)   # GI and dX
-        launches += 2
+        if cfg["ar"] == "transformer":                # QKV(3) + Wo + lin1 + lin2 + last_linear, and their 5 dX GEMMs
+            flops += 2 * (2.0 * n * t_len * (5 * h * h + 2 * h * 2048))
+            launches += 12
+        else:
+            flops += 2 * (2.0 * n * t_len * din * 3 * h)   # GI and dX
+            launches += 2
         din = h
     w = t_len - cfg["npred"]
     flops += 2 * (2.0 * b * w * cfg["npred"] * h * h)   # P and dC
@@ -66,7 +71,11 @@ def build(cfg, device):
     from cpc2_amd.train import buildOptimizer
     torch.manual_seed(0)                                   # identical init on every rank
     enc = cpc2_amd.CPCEncoder(cfg["hidden"], "layerNorm")
-    ar = cpc2_amd.CPCAR(cfg["hidden"], cfg["hidden"], False, cfg["layers"], mode=cfg["ar"])
+    if cfg["ar"] == "transformer":
+        from cpc2_amd.transformers import buildTransformerAR
+        ar = buildTransformerAR(cfg["hidden"], cfg["hidden"], cfg["layers"], WINDOW // 160, False)
+    else:
+        ar = cpc2_amd.CPCAR(cfg["hidden"], cfg["hidden"], False, cfg["layers"], mode=cfg["ar"])
     model = cpc2_amd.CPCModel(enc, ar).to(device)
     crit = cpc2_amd.CPCUnsupersivedCriterion(cfg["npred"], cfg["hidden"], cfg["hidden"], cfg["nneg"],
                                              rnnMode="linear", sizeInputSeq=WINDOW // 160).to(device)
@@ -214,7 +223,7 @@ def main():
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, GRU x{cfg['layers']}, nPredicts "
+            "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
                                    f"{cfg['npred']}, {cfg['nneg']} negatives, linear predictors), {args.batch} x 1.28 s "
                                    f"windows per GPU, reference trainStep semantics (encoder+AR on 2b windows), "
                                    f"fwd+bwd+allreduce+Adam",

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcpc2_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm_f32.hip", "rowops.hip", "encoder.hip", "gru.hip", "infonce.hip", "negidx.cpp"]
+SOURCES = ["gemm_f32.hip", "rowops.hip", "encoder.hip", "gru.hip", "infonce.hip", "transformer.hip", "negidx.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -22,7 +22,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "..", "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "cpc2_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rowcfg.h"), os.path.join(HERE, "..", "include", "cpc2_hip.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + headers):
         return LIB

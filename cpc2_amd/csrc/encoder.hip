@@ -15,27 +15,11 @@
 //                  A(m) = dU + m*H (rows t_hi-1 and t_hi, 2H contiguous floats) and weight-gradient a TN
 //                  GEMM over m with A(m) = dU + (m+1)*H, B(m) = Y_{i-1} + m*s*H.
 #include "common.h"
+#include "rowcfg.h"
 
 #include <algorithm>
 
 namespace cpc {
-
-// ------------------------------------------------------------------------------------------------
-// Row kernels: a row of H channels is owned by a group of G lanes, 4*VPL channels per lane, as float4s
-// v*G + gl (v < VPL) so that a group's accesses are contiguous.
-template <int H> struct RowCfg {
-    static_assert(H % 32 == 0, "hidden size must be a multiple of 32");
-    static constexpr int G = (H / 4 < 64) ? H / 4 : 64;
-    static constexpr int VPL = H / (4 * G);
-    static constexpr int RPW = 64 / G;   // rows per wave pass
-};
-
-template <int G> __device__ __forceinline__ float group_sum(float v)
-{
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 constexpr int C0_TB = 64;     // conv0: output rows per block tile
 constexpr int C0_K = 10, C0_S = 5, C0_P = 3;
@@ -484,16 +468,6 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
     e.scratch_bytes = sc.used();
     return CPC_OK;
 }
-
-#define CPC_DISPATCH_H(H, ...)                                  \
-    switch (H) {                                                \
-    case 32: { constexpr int HH = 32; __VA_ARGS__; } break;    \
-    case 64: { constexpr int HH = 64; __VA_ARGS__; } break;    \
-    case 128: { constexpr int HH = 128; __VA_ARGS__; } break;  \
-    case 256: { constexpr int HH = 256; __VA_ARGS__; } break;  \
-    case 512: { constexpr int HH = 512; __VA_ARGS__; } break;  \
-    default: break;                                             \
-    }
 
 static int encoder_forward(const float *x, const float *const *prm, float *z, void *saved, void *scratch, int N,
                            int length, int H, float eps, hipStream_t st)

@@ -1,0 +1,681 @@
+// Light causal transformer used as autoregressive network (arMode="transformer", BASELINE config 4).
+// Reference: /root/reference/cpc/transformers.py -- ScaledDotProductAttention :10-70 (causal mask, relative
+// positions via the "skew" trick :61-66), MultiHeadAttention :73-104 (8 heads, no biases), FFNetwork :107-116
+// (dff 2048, ReLU, dropout), TransformerLayer :119-134:
+//        y   = LN1(x + Wo . MHA(x))            out = LN2(Wl (y + FFN(y)) + bl)
+//
+// GEMM-shaped parts (QKV/Wo/FFN/last_linear, forward and both gradients) run on the f32-MFMA GEMMs of
+// gemm_f32.hip; this file adds the fused causal attention with relative-position bias (forward keeps only the
+// attention probabilities; backward recomputes nothing and keeps dK/dV/dKrelpos in registers), LayerNorm row
+// kernels fused with the residual add, and the ReLU+dropout elementwise pair.
+//
+// Dropout (p = 0.1 in training mode, transformers.py:16,112) uses a counter-based hash keyed by (seed, element
+// index): statistically equivalent to torch's, not stream-identical (parity is checked with p = 0).
+#include "common.h"
+#include "rowcfg.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace cpc {
+
+constexpr int TR_HEADS = 8;          // transformers.py:120 (nheads=8)
+constexpr int TR_QT = 32;            // query rows per attention tile
+
+__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;          // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+// multiplier applied to a kept/dropped element: 1/(1-p) or 0 (thresh = p * 2^32; thresh == 0 -> always 1)
+__device__ __forceinline__ float drop_mul(uint64_t seed, uint64_t idx, uint32_t thresh, float scale)
+{
+    return (thresh == 0u || hash32(seed, idx) >= thresh) ? scale : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+struct LnArgs {
+    const float *a, *b;        // input = a (+ b)
+    const float *w, *bias;     // [D]
+    float *y, *xhat, *rstd;
+    long rows;
+    float eps;
+    const float *dy;           // backward
+    float *dx, *part;          // part[slot][2][D]: dw, db
+};
+
+template <int D> __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a)
+{
+    using Cfg = RowCfg<D>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL, RPW = Cfg::RPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gi = lane / G;
+    float4 w4[VPL], b4[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        w4[v] = reinterpret_cast<const float4 *>(a.w)[v * G + gl];
+        b4[v] = reinterpret_cast<const float4 *>(a.bias)[v * G + gl];
+    }
+    const long stride = (long)gridDim.x * 4 * RPW;
+    for (long base = (long)blockIdx.x * 4 * RPW; base < a.rows; base += stride) {
+        const long row = base + wave * RPW + gi;
+        const bool ok = row < a.rows;
+        float4 x4[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            x4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                x4[v] = reinterpret_cast<const float4 *>(a.a + row * D)[v * G + gl];
+                if (a.b != nullptr) {
+                    const float4 r = reinterpret_cast<const float4 *>(a.b + row * D)[v * G + gl];
+                    x4[v].x += r.x; x4[v].y += r.y; x4[v].z += r.z; x4[v].w += r.w;
+                }
+            }
+            s += (x4[v].x + x4[v].y) + (x4[v].z + x4[v].w);
+        }
+        const float mean = group_sum<G>(s) * (1.f / D);
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            x4[v].x -= mean; x4[v].y -= mean; x4[v].z -= mean; x4[v].w -= mean;
+            ss = fmaf(x4[v].x, x4[v].x, ss); ss = fmaf(x4[v].y, x4[v].y, ss);
+            ss = fmaf(x4[v].z, x4[v].z, ss); ss = fmaf(x4[v].w, x4[v].w, ss);
+        }
+        const float rstd = rsqrtf(group_sum<G>(ss) * (1.f / D) + a.eps);     // biased variance (nn.LayerNorm)
+        if (!ok) continue;
+        if (gl == 0) a.rstd[row] = rstd;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            float4 xh, o;
+            xh.x = x4[v].x * rstd; xh.y = x4[v].y * rstd; xh.z = x4[v].z * rstd; xh.w = x4[v].w * rstd;
+            o.x = fmaf(xh.x, w4[v].x, b4[v].x); o.y = fmaf(xh.y, w4[v].y, b4[v].y);
+            o.z = fmaf(xh.z, w4[v].z, b4[v].z); o.w = fmaf(xh.w, w4[v].w, b4[v].w);
+            reinterpret_cast<float4 *>(a.xhat + row * D)[v * G + gl] = xh;
+            reinterpret_cast<float4 *>(a.y + row * D)[v * G + gl] = o;
+        }
+    }
+}
+
+constexpr int LN_BWD_BLOCKS = 256;
+
+template <int D> __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a)
+{
+    using Cfg = RowCfg<D>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL, RPW = Cfg::RPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gi = lane / G;
+    float4 w4[VPL];
+    float dw[VPL][4], db[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        w4[v] = reinterpret_cast<const float4 *>(a.w)[v * G + gl];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dw[v][e] = db[v][e] = 0.f;
+    }
+    const long stride = (long)gridDim.x * 4 * RPW;
+    for (long base = (long)blockIdx.x * 4 * RPW; base < a.rows; base += stride) {
+        const long row = base + wave * RPW + gi;
+        const bool ok = row < a.rows;
+        float xh[VPL][4], g[VPL][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = x4;
+            if (ok) {
+                x4 = reinterpret_cast<const float4 *>(a.xhat + row * D)[v * G + gl];
+                d4 = reinterpret_cast<const float4 *>(a.dy + row * D)[v * G + gl];
+            }
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float wv[4] = {w4[v].x, w4[v].y, w4[v].z, w4[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                db[v][e] += dv[e];
+                dw[v][e] = fmaf(dv[e], xv[e], dw[v][e]);
+                xh[v][e] = xv[e];
+                g[v][e] = dv[e] * wv[e];
+                s1 += g[v][e];
+                s2 = fmaf(g[v][e], xv[e], s2);
+            }
+        }
+        s1 = group_sum<G>(s1) * (1.f / D);
+        s2 = group_sum<G>(s2) * (1.f / D);
+        if (!ok) continue;
+        const float rstd = a.rstd[row];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            reinterpret_cast<float4 *>(a.dx + row * D)[v * G + gl] =
+                make_float4(rstd * (g[v][0] - s1 - xh[v][0] * s2), rstd * (g[v][1] - s1 - xh[v][1] * s2),
+                            rstd * (g[v][2] - s1 - xh[v][2] * s2), rstd * (g[v][3] - s1 - xh[v][3] * s2));
+    }
+    const int slot = (blockIdx.x * 4 + wave) * RPW + gi;
+    float *pp = a.part + (long)slot * 2 * D;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pp[(v * G + gl) * 4 + e] = dw[v][e];
+            pp[D + (v * G + gl) * 4 + e] = db[v][e];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ void relu_dropout_fwd_kernel(float *h, long n, uint64_t seed, uint32_t thresh, float scale)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = h[i];
+        h[i] = v > 0.f ? v * drop_mul(seed, (uint64_t)i, thresh, scale) : 0.f;
+    }
+}
+
+// h holds relu(.)*mask*scale: an element carries gradient iff it is > 0
+__global__ void relu_dropout_bwd_kernel(float *dh, const float *h, long n, float scale)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dh[i] = h[i] > 0.f ? dh[i] * scale : 0.f;
+}
+
+__global__ void add2_kernel(float *out, const float *a, const float *b, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
+static int launch_add2(float *out, const float *a, const float *b, long n, hipStream_t st)
+{
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)std::min<long>(cdiv(n4, 256), 4096)), dim3(256), 0, st, out, a, b, n4);
+    CPC_CHECK_LAUNCH("add2_kernel");
+    return CPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+struct AttnArgs {
+    const float *qkv;      // [N*S][3D]  rows (n,s): Q | K | V, head h at columns h*dk
+    const float *krel;     // [dk][SS] or null
+    float *probs;          // [N*heads*chunks][SS][SS]  softmax output (before dropout)
+    float *ctx;            // [N*S][D]   heads merged
+    int N, S, D, dk, SS, chunks;
+    uint64_t seed;
+    uint32_t thresh;
+    float scale, inv_sqrt_dk;
+    // backward
+    const float *dctx;     // [N*S][D]
+    float *dqkv;           // [N*S][3D]
+    float *dkrel_part;     // [N*heads*chunks][dk][SS]
+};
+
+// one workgroup per (sequence chunk of one head, 32-row query tile)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int dk = a.dk, SS = a.SS, ldk = dk + 1, ldp = SS + 1;
+    float *Ks = smem;                    // [SS][ldk]
+    float *Vs = Ks + SS * ldk;           // [SS][ldk]
+    float *Rs = Vs + SS * ldk;           // [dk][ldp]
+    float *Qs = Rs + dk * ldp;           // [TR_QT][ldk]
+    float *Ps = Qs + TR_QT * ldk;        // [TR_QT][ldp]
+
+    const int tiles = (SS + TR_QT - 1) / TR_QT;
+    const int cid = blockIdx.x / tiles, qt = blockIdx.x - cid * tiles;     // cid = (n*heads + h)*chunks + c
+    const int c = cid % a.chunks, nh = cid / a.chunks;
+    const int h = nh % TR_HEADS, n = nh / TR_HEADS;
+    const long row0 = (long)n * a.S + (long)c * SS;                          // first row of this chunk in qkv
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < SS * dk; i += 256) {
+        const int j = i / dk, d = i - j * dk;
+        const float *src = a.qkv + (row0 + j) * 3 * a.D + h * dk + d;
+        Ks[j * ldk + d] = src[a.D];
+        Vs[j * ldk + d] = src[2 * a.D];
+    }
+    if (a.krel != nullptr)
+        for (int i = tid; i < dk * SS; i += 256) Rs[(i / SS) * ldp + (i % SS)] = a.krel[i];
+    for (int i = tid; i < TR_QT * dk; i += 256) {
+        const int r = i / dk, d = i - r * dk;
+        const int ig = qt * TR_QT + r;
+        Qs[r * ldk + d] = ig < SS ? a.qkv[(row0 + ig) * 3 * a.D + h * dk + d] : 0.f;
+    }
+    __syncthreads();
+
+    const int ti = tid >> 3, tj = tid & 7;
+    const int ig = qt * TR_QT + ti;
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = tj + 8 * cc;
+        float s = -INFINITY;
+        if (j < SS && j <= ig && ig < SS) {
+            float acc = 0.f;
+            for (int d = 0; d < dk; ++d) acc = fmaf(Qs[ti * ldk + d], Ks[j * ldk + d], acc);
+            if (a.krel != nullptr) {
+                const int m = SS - 1 - (ig - j);                          // transformers.py:61-66
+                for (int d = 0; d < dk; ++d) acc = fmaf(Qs[ti * ldk + d], Rs[d * ldp + m], acc);
+            }
+            s = acc * a.inv_sqrt_dk;
+        }
+        sc[cc] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int off = 4; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        sc[cc] = (sc[cc] == -INFINITY) ? 0.f : expf(sc[cc] - mx);
+        sum += sc[cc];
+    }
+    for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = tj + 8 * cc;
+        if (j < SS) {
+            const float p = sc[cc] * inv;
+            float pd = 0.f;
+            if (ig < SS) {
+                const long idx = ((long)cid * SS + ig) * SS + j;
+                a.probs[idx] = p;
+                pd = p * drop_mul(a.seed, (uint64_t)idx, a.thresh, a.scale);
+            }
+            Ps[ti * ldp + j] = pd;
+        }
+    }
+    __syncthreads();
+    if (ig < SS) {
+        for (int d = tj; d < dk; d += 8) {
+            float acc = 0.f;
+            for (int j = 0; j <= ig; ++j) acc = fmaf(Ps[ti * ldp + j], Vs[j * ldk + d], acc);
+            a.ctx[(row0 + ig) * a.D + h * dk + d] = acc;
+        }
+    }
+}
+
+// one workgroup per sequence chunk of one head; loops over its query tiles.  dK, dV and dKrelpos accumulate
+// in registers: thread (j = tid/2, half) owns K/V row j, thread (m = tid%128, half) owns Krelpos column m.
+template <int DKH>   // dk / 2
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int dk = a.dk, SS = a.SS, ldk = dk + 1, ldp = SS + 1;
+    float *Qs = smem;                    // [SS][ldk]
+    float *Ks = Qs + SS * ldk;
+    float *Vs = Ks + SS * ldk;
+    float *Rs = Vs + SS * ldk;           // [dk][ldp]
+    float *Ts = Rs + dk * ldp;           // [TR_QT][ldp]   P*mask, then dS
+    float *Os = Ts + TR_QT * ldp;        // [TR_QT][ldk]   dO tile
+
+    const int cid = blockIdx.x;
+    const int c = cid % a.chunks, nh = cid / a.chunks;
+    const int h = nh % TR_HEADS, n = nh / TR_HEADS;
+    const long row0 = (long)n * a.S + (long)c * SS;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < SS * dk; i += 256) {
+        const int j = i / dk, d = i - j * dk;
+        const float *src = a.qkv + (row0 + j) * 3 * a.D + h * dk + d;
+        Qs[j * ldk + d] = src[0];
+        Ks[j * ldk + d] = src[a.D];
+        Vs[j * ldk + d] = src[2 * a.D];
+    }
+    if (a.krel != nullptr)
+        for (int i = tid; i < dk * SS; i += 256) Rs[(i / SS) * ldp + (i % SS)] = a.krel[i];
+
+    float dKacc[DKH], dVacc[DKH], dRacc[DKH];
+#pragma unroll
+    for (int e = 0; e < DKH; ++e) dKacc[e] = dVacc[e] = dRacc[e] = 0.f;
+    const int oj = tid >> 1, ohalf = tid & 1;          // owner of K/V row oj, channels ohalf*DKH ..
+    const int om = tid & 127, omh = tid >> 7;          // owner of Krelpos column om, channels omh*DKH ..
+    const int ti = tid >> 3, tj = tid & 7;
+
+    const int tiles = (SS + TR_QT - 1) / TR_QT;
+    for (int qt = 0; qt < tiles; ++qt) {
+        __syncthreads();                                // previous tile fully consumed (and staging done)
+        for (int i = tid; i < TR_QT * dk; i += 256) {
+            const int r = i / dk, d = i - r * dk;
+            const int ig = qt * TR_QT + r;
+            Os[r * ldk + d] = ig < SS ? a.dctx[(row0 + ig) * a.D + h * dk + d] : 0.f;
+        }
+        __syncthreads();
+        const int ig = qt * TR_QT + ti;
+        float pa[16], da[16];
+        float rs = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int j = tj + 8 * cc;
+            pa[cc] = 0.f; da[cc] = 0.f;
+            if (j < SS && j <= ig && ig < SS) {
+                const long idx = ((long)cid * SS + ig) * SS + j;
+                const float p = a.probs[idx];
+                const float mul = drop_mul(a.seed, (uint64_t)idx, a.thresh, a.scale);
+                float dp = 0.f;
+                for (int d = 0; d < dk; ++d) dp = fmaf(Os[ti * ldk + d], Vs[j * ldk + d], dp);
+                pa[cc] = p;
+                da[cc] = dp * mul;                      // d loss / d A (through the dropout)
+                rs = fmaf(da[cc], p, rs);
+                Ts[ti * ldp + j] = p * mul;             // dropped probabilities, for dV
+            } else if (j < SS) {
+                Ts[ti * ldp + j] = 0.f;
+            }
+        }
+        for (int off = 4; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+        __syncthreads();
+        // dV[j][d] += sum_i Pdrop[i][j] * dO[i][d]
+        if (oj < SS) {
+            for (int r = 0; r < TR_QT; ++r) {
+                const float p = Ts[r * ldp + oj];
+#pragma unroll
+                for (int e = 0; e < DKH; ++e) dVacc[e] = fmaf(p, Os[r * ldk + ohalf * DKH + e], dVacc[e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int j = tj + 8 * cc;
+            if (j < SS) Ts[ti * ldp + j] = pa[cc] * (da[cc] - rs) * a.inv_sqrt_dk;      // dS (0 where masked)
+        }
+        __syncthreads();
+        // dQ[i][d] = sum_j dS[i][j] (K[j][d] + Krel[d][SS-1-(i-j)])
+        if (ig < SS) {
+            for (int d = tj; d < dk; d += 8) {
+                float acc = 0.f;
+                for (int j = 0; j <= ig; ++j) {
+                    float kv = Ks[j * ldk + d];
+                    if (a.krel != nullptr) kv += Rs[d * ldp + SS - 1 - (ig - j)];
+                    acc = fmaf(Ts[ti * ldp + j], kv, acc);
+                }
+                a.dqkv[(row0 + ig) * 3 * a.D + h * dk + d] = acc;
+            }
+        }
+        // dK[j][d] += sum_i dS[i][j] Q[i][d]
+        if (oj < SS) {
+            for (int r = 0; r < TR_QT; ++r) {
+                const int i2 = qt * TR_QT + r;
+                if (i2 >= SS) break;
+                const float ds = Ts[r * ldp + oj];
+#pragma unroll
+                for (int e = 0; e < DKH; ++e) dKacc[e] = fmaf(ds, Qs[i2 * ldk + ohalf * DKH + e], dKacc[e]);
+            }
+        }
+        // dKrel[d][m] += sum_{i: j = i-(SS-1-m) >= 0} dS[i][j] Q[i][d]
+        if (a.krel != nullptr && om < SS) {
+            for (int r = 0; r < TR_QT; ++r) {
+                const int i2 = qt * TR_QT + r;
+                if (i2 >= SS) break;
+                const int j = i2 - (SS - 1 - om);
+                if (j < 0) continue;
+                const float ds = Ts[r * ldp + j];
+#pragma unroll
+                for (int e = 0; e < DKH; ++e) dRacc[e] = fmaf(ds, Qs[i2 * ldk + omh * DKH + e], dRacc[e]);
+            }
+        }
+    }
+    if (oj < SS) {
+#pragma unroll
+        for (int e = 0; e < DKH; ++e) {
+            float *dst = a.dqkv + (row0 + oj) * 3 * a.D + h * dk + ohalf * DKH + e;
+            dst[a.D] = dKacc[e];
+            dst[2 * a.D] = dVacc[e];
+        }
+    }
+    if (a.krel != nullptr && om < SS) {
+#pragma unroll
+        for (int e = 0; e < DKH; ++e) a.dkrel_part[((long)cid * dk + omh * DKH + e) * SS + om] = dRacc[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ orchestration
+// per-layer parameter order of the C ABI
+enum { P_WQ = 0, P_WK, P_WV, P_WO, P_KREL, P_LN1W, P_LN1B, P_W1, P_B1, P_W2, P_B2, P_WL, P_BL, P_LN2W, P_LN2B, P_COUNT };
+constexpr int TR_DFF = 2048;        // transformers.py:119 (dff=2048)
+
+struct TrLayout {
+    int N, S, D, Dout, SS, layers, dk, chunks;
+    long rows;
+    // saved per layer
+    float *qkv[4], *probs[4], *ctx[4], *xh1[4], *rstd1[4], *y[4], *hdrop[4], *t[4], *xh2[4], *rstd2[4], *xout[4];
+    size_t saved_bytes;
+    // scratch
+    float *wqkv, *wt, *o, *u, *da, *db, *dc, *dh, *dqkv, *part, *krel_part, *tn, *cs;
+    size_t tn_bytes, scratch_bytes, lds_fwd, lds_bwd;
+};
+
+static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int layers, void *saved, void *scratch)
+{
+    CPC_REQUIRE(supported_row_width(D) && supported_row_width(Dout), "transformer: model dims %d/%d not supported", D, Dout);
+    CPC_REQUIRE(layers >= 1 && layers <= 4, "transformer: 1..4 layers supported (got %d)", layers);
+    CPC_REQUIRE(layers == 1 || D == Dout, "transformer: stacked layers need dmodel == dout");
+    CPC_REQUIRE(N > 0 && S > 0 && SS > 0 && SS <= 128, "transformer: need 0 < sizeSeq <= 128 (got %d)", SS);
+    CPC_REQUIRE(S % SS == 0, "transformer: sequence length %d must be a multiple of sizeSeq %d", S, SS);
+    L.N = N; L.S = S; L.D = D; L.Dout = Dout; L.SS = SS; L.layers = layers; L.dk = D / TR_HEADS; L.chunks = S / SS;
+    L.rows = (long)N * S;
+    const size_t R = (size_t)L.rows;
+    const size_t nchunk = (size_t)N * TR_HEADS * L.chunks;
+    Carver sv(saved);
+    for (int l = 0; l < layers; ++l) {
+        L.qkv[l] = sv.take<float>(R * 3 * D);
+        L.probs[l] = sv.take<float>(nchunk * SS * SS);
+        L.ctx[l] = sv.take<float>(R * D);
+        L.xh1[l] = sv.take<float>(R * D);
+        L.rstd1[l] = sv.take<float>(R);
+        L.y[l] = sv.take<float>(R * D);
+        L.hdrop[l] = sv.take<float>(R * TR_DFF);
+        L.t[l] = sv.take<float>(R * D);
+        L.xh2[l] = sv.take<float>(R * Dout);
+        L.rstd2[l] = sv.take<float>(R);
+        L.xout[l] = (l + 1 < layers) ? sv.take<float>(R * Dout) : nullptr;
+    }
+    L.saved_bytes = sv.used();
+    Carver sc(scratch);
+    const int dmax = std::max(D, Dout);
+    L.wqkv = sc.take<float>((size_t)3 * D * D);
+    L.wt = sc.take<float>((size_t)TR_DFF * dmax > (size_t)3 * D * D ? (size_t)TR_DFF * dmax : (size_t)3 * D * D);
+    L.o = sc.take<float>(R * dmax);
+    L.u = sc.take<float>(R * dmax);
+    L.da = sc.take<float>(R * dmax);
+    L.db = sc.take<float>(R * dmax);
+    L.dc = sc.take<float>(R * dmax);
+    L.dh = sc.take<float>(R * TR_DFF);
+    L.dqkv = sc.take<float>(R * 3 * D);
+    L.part = sc.take<float>((size_t)LN_BWD_BLOCKS * 4 * rows_per_wave(std::min(D, Dout)) * 2 * dmax);
+    L.krel_part = sc.take<float>(nchunk * L.dk * SS);
+    L.cs = sc.take<float>(colsum_rows_scratch_bytes(TR_DFF) / sizeof(float));
+    L.tn_bytes = std::max(gemm_tn_scratch_bytes(TR_DFF, dmax, L.rows), gemm_tn_scratch_bytes(dmax, TR_DFF, L.rows));
+    L.tn_bytes = std::max(L.tn_bytes, gemm_tn_scratch_bytes(dmax, dmax, L.rows));
+    L.tn = sc.take<float>(L.tn_bytes / sizeof(float));
+    L.scratch_bytes = sc.used();
+    const size_t ldk = L.dk + 1, ldp = SS + 1;
+    L.lds_fwd = sizeof(float) * (2 * SS * ldk + L.dk * ldp + TR_QT * ldk + TR_QT * ldp);
+    L.lds_bwd = sizeof(float) * (3 * SS * ldk + L.dk * ldp + TR_QT * ldp + TR_QT * ldk);
+    CPC_REQUIRE(L.lds_bwd <= 160 * 1024, "transformer: attention tile needs %zu B of LDS", L.lds_bwd);
+    return CPC_OK;
+}
+
+template <typename K> static int allow_lds_tr(K kern, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return CPC_OK;
+}
+
+static int launch_ln_fwd(const float *a, const float *b, const float *w, const float *bias, float *y, float *xhat, float *rstd,
+                         long rows, int D, float eps, hipStream_t st)
+{
+    LnArgs la{};
+    la.a = a; la.b = b; la.w = w; la.bias = bias; la.y = y; la.xhat = xhat; la.rstd = rstd; la.rows = rows; la.eps = eps;
+    const int rpb = 4 * rows_per_wave(D);
+    const int blocks = (int)std::min<long>(cdiv(rows, rpb), 4096);
+    CPC_DISPATCH_H(D, hipLaunchKernelGGL(ln_fwd_kernel<HH>, dim3(blocks), dim3(256), 0, st, la));
+    CPC_CHECK_LAUNCH("ln_fwd_kernel");
+    return CPC_OK;
+}
+
+static int launch_ln_bwd(const float *dy, const float *xhat, const float *rstd, const float *w, float *dx, float *dw, float *db,
+                         float *part, long rows, int D, hipStream_t st)
+{
+    LnArgs la{};
+    la.dy = dy; la.xhat = const_cast<float *>(xhat); la.rstd = const_cast<float *>(rstd); la.w = w; la.dx = dx; la.part = part;
+    la.rows = rows;
+    CPC_DISPATCH_H(D, hipLaunchKernelGGL(ln_bwd_kernel<HH>, dim3(LN_BWD_BLOCKS), dim3(256), 0, st, la));
+    CPC_CHECK_LAUNCH("ln_bwd_kernel");
+    const long slots = (long)LN_BWD_BLOCKS * 4 * rows_per_wave(D);
+    CPC_TRY(colsum(part, slots, 2L * D, D, dw, st));
+    CPC_TRY(colsum(part + D, slots, 2L * D, D, db, st));
+    return CPC_OK;
+}
+
+static uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0); }
+
+static int transformer_forward(const float *x, const float *const *prm, float *out, void *saved, void *scratch, int N, int S,
+                               int D, int Dout, int SS, int layers, float p_drop, uint64_t seed, hipStream_t st)
+{
+    TrLayout L;
+    CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, saved, scratch));
+    const long R = L.rows;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const uint32_t thresh = drop_thresh(p_drop);
+    RowMap none{};
+    const float *xin = x;
+    for (int l = 0; l < layers; ++l) {
+        const float *const *p = prm + (size_t)l * P_COUNT;
+        const uint64_t lseed = seed + 0x1000ull * (uint64_t)l;
+        // Q | K | V = x [Wq; Wk; Wv]^T                                     (transformers.py:99-102)
+        for (int i = 0; i < 3; ++i)
+            CPC_TRY(gemm_nt(xin, D, p[P_WQ + i], D, L.qkv[l] + (size_t)i * D, 3L * D, nullptr, R, D, D, none, st));
+        AttnArgs aa{};
+        aa.qkv = L.qkv[l]; aa.krel = p[P_KREL]; aa.probs = L.probs[l]; aa.ctx = L.ctx[l];
+        aa.N = N; aa.S = S; aa.D = D; aa.dk = L.dk; aa.SS = SS; aa.chunks = L.chunks;
+        aa.seed = lseed; aa.thresh = thresh; aa.scale = scale; aa.inv_sqrt_dk = 1.f / std::sqrt((float)L.dk);
+        CPC_TRY(allow_lds_tr(attn_fwd_kernel, L.lds_fwd));
+        const int tiles = (SS + TR_QT - 1) / TR_QT;
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(N * TR_HEADS * L.chunks * tiles)), dim3(256), L.lds_fwd, st, aa);
+        CPC_CHECK_LAUNCH("attn_fwd_kernel");
+        CPC_TRY(gemm_nt(L.ctx[l], D, p[P_WO], D, L.o, D, nullptr, R, D, D, none, st));                       // Wo (:104)
+        CPC_TRY(launch_ln_fwd(xin, L.o, p[P_LN1W], p[P_LN1B], L.y[l], L.xh1[l], L.rstd1[l], R, D, 1e-5f, st));  // :133
+        CPC_TRY(gemm_nt(L.y[l], D, p[P_W1], D, L.hdrop[l], TR_DFF, p[P_B1], R, TR_DFF, D, none, st));           // lin1 (:116)
+        hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(4096), dim3(256), 0, st, L.hdrop[l], R * TR_DFF, lseed ^ 0xFFull, thresh, scale);
+        CPC_CHECK_LAUNCH("relu_dropout_fwd_kernel");
+        CPC_TRY(gemm_nt(L.hdrop[l], TR_DFF, p[P_W2], TR_DFF, L.u, D, p[P_B2], R, D, TR_DFF, none, st));        // lin2
+        CPC_TRY(launch_add2(L.t[l], L.y[l], L.u, R * D, st));                                                   // y + FFN(y) (:134)
+        CPC_TRY(gemm_nt(L.t[l], D, p[P_WL], D, L.u, Dout, p[P_BL], R, Dout, D, none, st));                       // last_linear
+        float *yo = (l + 1 < layers) ? L.xout[l] : out;
+        CPC_TRY(launch_ln_fwd(L.u, nullptr, p[P_LN2W], p[P_LN2B], yo, L.xh2[l], L.rstd2[l], R, Dout, 1e-5f, st));
+        xin = yo;
+    }
+    return CPC_OK;
+}
+
+static int transformer_backward(const float *x, const float *const *prm, const float *dout, void *saved, void *scratch, float *dx,
+                                float *const *grads, int N, int S, int D, int Dout, int SS, int layers, float p_drop,
+                                uint64_t seed, hipStream_t st)
+{
+    TrLayout L;
+    CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, saved, scratch));
+    const long R = L.rows;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const uint32_t thresh = drop_thresh(p_drop);
+    RowMap none{};
+    const float *dcur = dout;
+    for (int l = layers - 1; l >= 0; --l) {
+        const float *const *p = prm + (size_t)l * P_COUNT;
+        float *const *g = grads + (size_t)l * P_COUNT;
+        const float *xin = (l == 0) ? x : L.xout[l - 1];
+        const uint64_t lseed = seed + 0x1000ull * (uint64_t)l;
+        // LN2
+        CPC_TRY(launch_ln_bwd(dcur, L.xh2[l], L.rstd2[l], p[P_LN2W], L.da, g[P_LN2W], g[P_LN2B], L.part, R, Dout, st));   // da = du
+        // last_linear: u = t Wl^T + bl
+        CPC_TRY(gemm_tn(L.da, Dout, L.t[l], D, g[P_WL], D, Dout, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(colsum_rows(L.da, Dout, R, Dout, g[P_BL], L.cs, st));
+        CPC_TRY(transpose2d(p[P_WL], L.wt, Dout, D, st));                                            // [D][Dout]
+        CPC_TRY(gemm_nt(L.da, Dout, L.wt, Dout, L.db, D, nullptr, R, D, Dout, none, st));            // db = dt (= dy_a = df)
+        // lin2: f = h W2^T + b2
+        CPC_TRY(gemm_tn(L.db, D, L.hdrop[l], TR_DFF, g[P_W2], TR_DFF, D, TR_DFF, R, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(colsum_rows(L.db, D, R, D, g[P_B2], L.cs, st));
+        CPC_TRY(transpose2d(p[P_W2], L.wt, D, TR_DFF, st));                                          // [dff][D]
+        CPC_TRY(gemm_nt(L.db, D, L.wt, D, L.dh, TR_DFF, nullptr, R, TR_DFF, D, none, st));
+        hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(4096), dim3(256), 0, st, L.dh, L.hdrop[l], R * TR_DFF, scale);
+        CPC_CHECK_LAUNCH("relu_dropout_bwd_kernel");
+        // lin1: h = y W1^T + b1
+        CPC_TRY(gemm_tn(L.dh, TR_DFF, L.y[l], D, g[P_W1], D, TR_DFF, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(colsum_rows(L.dh, TR_DFF, R, TR_DFF, g[P_B1], L.cs, st));
+        CPC_TRY(transpose2d(p[P_W1], L.wt, TR_DFF, D, st));                                          // [D][dff]
+        CPC_TRY(gemm_nt(L.dh, TR_DFF, L.wt, TR_DFF, L.dc, D, nullptr, R, D, TR_DFF, none, st));      // dc = dy_b
+        CPC_TRY(launch_add2(L.dc, L.dc, L.db, R * D, st));                                            // dy = dy_a + dy_b
+        // LN1: y = LN(x + o)
+        CPC_TRY(launch_ln_bwd(L.dc, L.xh1[l], L.rstd1[l], p[P_LN1W], L.da, g[P_LN1W], g[P_LN1B], L.part, R, D, st));      // da = d(x+o)
+        // Wo: o = ctx Wo^T
+        CPC_TRY(gemm_tn(L.da, D, L.ctx[l], D, g[P_WO], D, D, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(transpose2d(p[P_WO], L.wt, D, D, st));
+        CPC_TRY(gemm_nt(L.da, D, L.wt, D, L.db, D, nullptr, R, D, D, none, st));                     // db = dctx
+        // attention
+        AttnArgs aa{};
+        aa.qkv = L.qkv[l]; aa.krel = p[P_KREL]; aa.probs = L.probs[l];
+        aa.N = N; aa.S = S; aa.D = D; aa.dk = L.dk; aa.SS = SS; aa.chunks = L.chunks;
+        aa.seed = lseed; aa.thresh = thresh; aa.scale = scale; aa.inv_sqrt_dk = 1.f / std::sqrt((float)L.dk);
+        aa.dctx = L.db; aa.dqkv = L.dqkv; aa.dkrel_part = L.krel_part;
+        const int nchunk = N * TR_HEADS * L.chunks;
+        int status = CPC_OK;
+        switch (L.dk / 2) {
+#define TR_CASE(X) case X: status = allow_lds_tr(attn_bwd_kernel<X>, L.lds_bwd); \
+        if (status == CPC_OK) hipLaunchKernelGGL(attn_bwd_kernel<X>, dim3((unsigned)nchunk), dim3(256), L.lds_bwd, st, aa); break;
+            TR_CASE(2) TR_CASE(4) TR_CASE(8) TR_CASE(16) TR_CASE(32)
+#undef TR_CASE
+        default: set_error("transformer: head size %d not supported", L.dk); return CPC_ERR_INVALID;
+        }
+        CPC_TRY(status);
+        CPC_CHECK_LAUNCH("attn_bwd_kernel");
+        if (p[P_KREL] != nullptr) CPC_TRY(colsum(L.krel_part, nchunk, (long)L.dk * SS, L.dk * SS, g[P_KREL], st));
+        // Q/K/V projections
+        for (int i = 0; i < 3; ++i)
+            CPC_TRY(gemm_tn(L.dqkv + (size_t)i * D, 3L * D, xin, D, g[P_WQ + i], D, D, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        float *dxl = (l == 0) ? dx : L.dc;
+        if (dxl != nullptr) {
+            for (int i = 0; i < 3; ++i) CPC_CHECK_HIP(hipMemcpyAsync(L.wqkv + (size_t)i * D * D, p[P_WQ + i], sizeof(float) * D * D,
+                                                                     hipMemcpyDeviceToDevice, st));
+            CPC_TRY(transpose2d(L.wqkv, L.wt, 3 * D, D, st));                                         // [D][3D]
+            CPC_TRY(gemm_nt(L.dqkv, 3L * D, L.wt, 3L * D, L.u, D, nullptr, R, D, 3 * D, none, st));
+            CPC_TRY(launch_add2(dxl, L.u, L.da, R * D, st));                                           // + residual path
+        }
+        dcur = dxl;
+    }
+    return CPC_OK;
+}
+
+}  // namespace cpc
+
+extern "C" int cpc_transformer_param_count(void) { return cpc::P_COUNT; }
+
+extern "C" size_t cpc_transformer_saved_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers)
+{
+    cpc::TrLayout L;
+    if (cpc::tr_layout(L, n, s, d_model, d_out, size_seq, layers, nullptr, nullptr) != CPC_OK) return 0;
+    return L.saved_bytes;
+}
+
+extern "C" size_t cpc_transformer_scratch_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers)
+{
+    cpc::TrLayout L;
+    if (cpc::tr_layout(L, n, s, d_model, d_out, size_seq, layers, nullptr, nullptr) != CPC_OK) return 0;
+    return L.scratch_bytes;
+}
+
+extern "C" int cpc_transformer_forward(const float *x, const float *const *params, float *out, void *saved, void *scratch, int n,
+                                       int s, int d_model, int d_out, int size_seq, int layers, float dropout_p,
+                                       unsigned long long seed, cpc_stream_t stream)
+{
+    return cpc::transformer_forward(x, params, out, saved, scratch, n, s, d_model, d_out, size_seq, layers, dropout_p, seed,
+                                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_transformer_backward(const float *x, const float *const *params, const float *dout, void *saved, void *scratch,
+                                        float *dx, float *const *grads, int n, int s, int d_model, int d_out, int size_seq,
+                                        int layers, float dropout_p, unsigned long long seed, cpc_stream_t stream)
+{
+    return cpc::transformer_backward(x, params, dout, saved, scratch, dx, grads, n, s, d_model, d_out, size_seq, layers, dropout_p,
+                                     seed, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,143 @@
+"""Drop-in counterpart of the reference's light transformer used as autoregressive network.
+
+Mirrors /root/reference/cpc/transformers.py: ScaledDotProductAttention (:10-70), MultiHeadAttention
+(:73-104), FFNetwork (:107-116), TransformerLayer (:119-134), buildTransformerAR (:176-187) -- same
+class names, constructor signatures, parameter/buffer names (so state dicts are interchangeable:
+`multihead.{Wo,Wk,Wq,Wv}.weight`, `multihead.Att.{Krelpos,z,mask}`, `ln_multihead.*`,
+`ffnetwork.lin{1,2}.*`, `last_linear.*`, `ln_ffnetwork.*`) and the same construction order (identical
+default initialisation under a given torch seed).  The sub-modules are parameter containers: the whole
+layer runs as ONE fused call into libcpc2_hip.so (cpc_transformer_forward / _backward).
+
+Not supported on the MI355X path: abspos=True (StaticPositionEmbedding), sequence lengths that are not a
+multiple of sizeSeq (the reference zero-pads them, transformers.py:41-48).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, f32c, ptr, ptr_array, require_gpu, scratch, stream_ptr
+
+
+class ScaledDotProductAttention(nn.Module):
+    def __init__(self, sizeSeq, dk, dropout, relpos=False):
+        super(ScaledDotProductAttention, self).__init__()
+        self.drop = nn.Dropout(dropout)
+        self.softmax = nn.Softmax(dim=2)
+        self.relpos = relpos
+        self.sizeSeq = sizeSeq
+        if relpos:
+            self.Krelpos = nn.Parameter(torch.Tensor(dk, sizeSeq))
+            self.initmat_(self.Krelpos)
+            self.register_buffer('z', torch.zeros(1, sizeSeq, 1))
+        mask = torch.tril(torch.ones(sizeSeq, sizeSeq), diagonal=0)
+        mask = 1 - mask
+        mask[mask == 1] = -float('inf')
+        self.register_buffer('mask', mask.unsqueeze(0))
+
+    def initmat_(self, mat, dim=0):
+        stdv = 1. / math.sqrt(mat.size(dim))
+        mat.data.uniform_(-stdv, stdv)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, sizeSeq, dropout, dmodel, nheads, abspos):
+        super(MultiHeadAttention, self).__init__()
+        self.Wo = nn.Linear(dmodel, dmodel, bias=False)
+        self.Wk = nn.Linear(dmodel, dmodel, bias=False)
+        self.Wq = nn.Linear(dmodel, dmodel, bias=False)
+        self.Wv = nn.Linear(dmodel, dmodel, bias=False)
+        self.nheads = nheads
+        self.dk = dmodel // nheads
+        self.Att = ScaledDotProductAttention(sizeSeq, self.dk, dropout, not abspos)
+
+
+class FFNetwork(nn.Module):
+    def __init__(self, din, dout, dff, dropout):
+        super(FFNetwork, self).__init__()
+        self.lin1 = nn.Linear(din, dff, bias=True)
+        self.lin2 = nn.Linear(dff, dout, bias=True)
+        self.relu = nn.ReLU()
+        self.drop = nn.Dropout(dropout)
+
+
+class _TransformerFn(torch.autograd.Function):
+    """`layers` stacked TransformerLayers in one call; params = 15 tensors per layer in the C-ABI order."""
+
+    @staticmethod
+    def forward(ctx, x, size_seq, n_layers, dropout_p, seed, *params):
+        require_gpu(x, *[p for p in params if p is not None])
+        lib = _lib.load()
+        x = f32c(x)
+        params = tuple(f32c(p) for p in params)
+        n, s, d_model = x.shape
+        per = lib.cpc_transformer_param_count()
+        d_out = params[(n_layers - 1) * per + 11].shape[0]            # last layer's last_linear.weight [d_out, d]
+        nsaved = lib.cpc_transformer_saved_bytes(n, s, d_model, d_out, size_seq, n_layers)
+        nscratch = lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers)
+        if nsaved == 0:
+            check(-1, "transformer shape query")
+        out = torch.empty(n, s, d_out, dtype=torch.float32, device=x.device)
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
+        sc = scratch(nscratch, x.device)
+        check(lib.cpc_transformer_forward(ptr(x), ptr_array(params), ptr(out), ptr(saved), ptr(sc), n, s, d_model, d_out,
+                                          size_seq, n_layers, dropout_p, seed, stream_ptr(x.device)), "transformer_forward")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.cfg = (n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, saved, *params = ctx.saved_tensors
+        n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed = ctx.cfg
+        dout = f32c(dout)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        grads = [torch.empty_like(p) for p in params]
+        sc = scratch(lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers), x.device)
+        check(lib.cpc_transformer_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
+                                           n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed, stream_ptr(x.device)),
+              "transformer_backward")
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, sizeSeq=32, dmodel=512, dout=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
+        super(TransformerLayer, self).__init__()
+        if abspos:
+            raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
+        if nheads != 8 or dff != 2048:
+            raise NotImplementedError("the MI355X transformer kernels are built for nheads=8, dff=2048 (the reference's values)")
+        self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
+        self.ln_multihead = nn.LayerNorm(dmodel)
+        self.ffnetwork = FFNetwork(dmodel, dmodel, dff, dropout)
+        self.last_linear = nn.Linear(dmodel, dout)
+        self.ln_ffnetwork = nn.LayerNorm(dout)
+        self.sizeSeq = sizeSeq
+        self.dropout_p = float(dropout)
+        self._calls = 0
+
+    def _param_list(self):
+        m = self.multihead
+        return [m.Wq.weight, m.Wk.weight, m.Wv.weight, m.Wo.weight, m.Att.Krelpos,
+                self.ln_multihead.weight, self.ln_multihead.bias,
+                self.ffnetwork.lin1.weight, self.ffnetwork.lin1.bias,
+                self.ffnetwork.lin2.weight, self.ffnetwork.lin2.bias,
+                self.last_linear.weight, self.last_linear.bias,
+                self.ln_ffnetwork.weight, self.ln_ffnetwork.bias]
+
+    def forward(self, x):
+        p = self.dropout_p if self.training else 0.0
+        # a fresh dropout stream per call, derived from torch's CPU generator (so torch.manual_seed governs it)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+        return _TransformerFn.apply(x, self.sizeSeq, 1, p, seed, *self._param_list())
+
+
+def buildTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos):
+    """transformers.py:176-187."""
+    if abspos:
+        raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
+    layerSequence = [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
+                     for _ in range(nLayers)]
+    return nn.Sequential(*layerSequence)

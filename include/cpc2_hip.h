@@ -114,6 +114,32 @@ int cpc_gru_backward(const float *x, const float *const *params, const float *do
                      int hidden, int layers, cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Transformer autoregressive network (arMode="transformer", cpc/transformers.py:10-134,176-187):
+ * `layers` TransformerLayers, each   y = LN1(x + Wo.MHA(x)),  out = LN2(Wl (y + FFN(y)) + bl),
+ * 8 heads, causal mask, relative-position bias q_i.Krelpos[:, S-1-(i-j)], dff = 2048, ReLU.
+ *   x       [n, s, d_model];  out [n, s, d_out];  s must be a multiple of size_seq (<= 128): longer
+ *           inputs are attended in independent blocks of size_seq (transformers.py:38-50)
+ *   params  cpc_transformer_param_count() = 15 pointers per layer, in THIS order:
+ *           Wq, Wk, Wv, Wo [d,d]; Krelpos [d/8, size_seq] (NULL: no relative positions);
+ *           ln_multihead.weight, .bias [d]; lin1.weight [2048,d], lin1.bias [2048];
+ *           lin2.weight [d,2048], lin2.bias [d]; last_linear.weight [d_out,d], .bias [d_out];
+ *           ln_ffnetwork.weight, .bias [d_out]
+ *   dropout_p  0 in eval mode; in training the masks come from a counter-based hash of (seed, index):
+ *           pass the same (dropout_p, seed) to backward.
+ *   backward: dout -> dx (may be NULL), grads (same order/shapes as params, overwritten).
+ * ------------------------------------------------------------------------------------------ */
+int cpc_transformer_param_count(void);
+size_t cpc_transformer_saved_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers);
+size_t cpc_transformer_scratch_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers);
+int cpc_transformer_forward(const float *x, const float *const *params, float *out, void *saved,
+                            void *scratch, int n, int s, int d_model, int d_out, int size_seq, int layers,
+                            float dropout_p, unsigned long long seed, cpc_stream_t stream);
+int cpc_transformer_backward(const float *x, const float *const *params, const float *dout, void *saved,
+                             void *scratch, float *dx, float *const *grads, int n, int s, int d_model,
+                             int d_out, int size_seq, int layers, float dropout_p, unsigned long long seed,
+                             cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Negative-index sampler of CPCUnsupersivedCriterion.sampleClean (criterion.py:247-266), HOST
  * side, bit-exact with torch's CPU generator: 32-bit MT19937, one draw per element,
  * batchIdx = draw % batch (all n first), then seqIdx = draw % (T-1) + 1;

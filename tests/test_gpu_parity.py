@@ -285,6 +285,96 @@ def test_criterion_properties_at_full_size():
     assert torch.equal(l2, l3)
 
 
+# ----------------------------------------------------------------------------- transformer AR (config 4)
+def load_transformer(d_model, d_out, size_seq, params, n_layers=1):
+    from cpc2_amd.transformers import buildTransformerAR
+    net = buildTransformerAR(d_out, d_model, n_layers, size_seq, False)
+    sd = {k[len("gAR."):]: v for k, v in params.items()}
+    sd.update({k: v for k, v in net.state_dict().items() if k.endswith(".z") or k.endswith(".mask")})
+    net.load_state_dict(sd)
+    return net.to(DEV)
+
+
+def test_transformer_vs_reference_golden(golden):
+    g = golden("g7_transformer.npz")
+    d_model, s, n = (int(v) for v in g["cfg"])
+    net = load_transformer(d_model, d_model, s, synth.transformer_params(d_model, d_model, s, 71)).eval()
+    x = synth.features((n, s, d_model), 72, relu=True).to(DEV).requires_grad_(True)
+    out = net(x)
+    assert_close(out, t(g["out"]), 2e-5, "transformer out")
+    (out * synth.features((n, s, d_model), 73).to(DEV)).sum().backward()
+    assert_close(x.grad, t(g["dx"]), 1e-4, "transformer dx")
+    for name, p in net.named_parameters():
+        assert_close(p.grad, t(g["grad." + name]), 2e-4, f"transformer grad {name}")
+
+
+@pytest.mark.parametrize("d_model,size_seq,s,n", [(256, 128, 128, 3), (64, 32, 96, 2), (512, 128, 128, 1)])
+def test_transformer_vs_oracle_fp64(d_model, size_seq, s, n):
+    params = synth.transformer_params(d_model, d_model, size_seq, 81)
+    net = load_transformer(d_model, d_model, size_seq, params).eval()
+    x = synth.features((n, s, d_model), 82, relu=True)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x.double().requires_grad_(True)
+    # sequences longer than sizeSeq are attended in independent blocks (transformers.py:38-50)
+    ref = O.transformer_layer_forward(x64.view(n * (s // size_seq), size_seq, d_model), p64, "gAR.0.").view(n, s, d_model)
+    gout = synth.features((n, s, d_model), 83)
+    (ref * gout.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = net(xd)
+    assert_close(out, ref, 2e-5, "transformer out")
+    (out * gout.to(DEV)).sum().backward()
+    assert_close(xd.grad, x64.grad, 1e-4, "transformer dx")
+    for name, p in net.named_parameters():
+        assert_close(p.grad, p64["gAR." + name].grad, 2e-4, f"transformer grad {name}")
+
+
+def test_transformer_dropout_training_mode():
+    """p = 0.1 in training mode: masks come from a hash (not torch's stream), so only properties are checked:
+    deterministic for a fixed seed, different from eval, finite gradients, E[out] close to eval output."""
+    params = synth.transformer_params(64, 64, 32, 91)
+    net = load_transformer(64, 64, 32, params)
+    x = synth.features((4, 32, 64), 92, relu=True).to(DEV).requires_grad_(True)
+    net.eval()
+    ref = net(x).detach()
+    net.train()
+    torch.manual_seed(5)
+    a = net(x)
+    torch.manual_seed(5)
+    b = net(x)
+    assert torch.equal(a, b)
+    assert not torch.allclose(a, ref, atol=1e-4)
+    a.sum().backward()
+    assert torch.isfinite(x.grad).all()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_model_with_transformer_ar_train_step_vs_oracle():
+    hidden, b, k, nn = 64, 2, 12, 16
+    mp = synth.encoder_params(hidden, 21)
+    mp.update(synth.transformer_params(hidden, hidden, 128, 25))
+    from cpc2_amd.transformers import buildTransformerAR
+    ar = buildTransformerAR(hidden, hidden, 1, 128, False)
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), ar)
+    sd = dict(mp)
+    sd.update({kk: v for kk, v in model.state_dict().items() if kk.endswith(".z") or kk.endswith(".mask")})
+    model.load_state_dict(sd)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, hidden, hidden, nn, rnnMode="linear", sizeInputSeq=128)
+    cp = synth.predictor_params(k, hidden, hidden, 23)
+    crit.load_state_dict(cp)
+    model, crit = model.to(DEV).eval(), crit.to(DEV)          # eval: dropout off (parity is defined at p = 0)
+    x = synth.audio_windows(b, 20480, 24)
+    crit.seed(77)
+    tot, losses, _ = cpcStep(x.to(DEV), x.to(DEV), torch.zeros(b, dtype=torch.long, device=DEV), model, crit)
+    tot.backward()
+    p64 = {kk: v.double().requires_grad_(True) for kk, v in list(mp.items()) + list(cp.items())}
+    ref_tot, ref_losses, _ = O.train_step_loss(x.double(), x.double(), {kk: p64[kk] for kk in mp}, {kk: p64[kk] for kk in cp},
+                                               MT19937(77), k, nn, 1, ar="transformer")
+    ref_tot.backward()
+    assert_close(losses, ref_losses, 1e-5, "losses")
+    for name, p in list(model.named_parameters()) + list(crit.named_parameters()):
+        assert_close(p.grad, p64[name].grad, 5e-4, f"grad {name}")
+
+
 # ----------------------------------------------------------------------------- Adam + full train steps
 def test_fused_adam_vs_oracle():
     g = torch.Generator().manual_seed(0)
