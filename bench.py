@@ -36,11 +36,11 @@ CONFIGS = {
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
 
-def gemm_nt_algorithmic_flops(b, cfg):
+def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
     """Algorithmic FLOPs (2 per MAC) of everything that runs on gemm_nt_kernel in ONE step, and the
     number of launches: conv1..4 forward + backward-data (s phase launches each), GRU input projection
     + its dX, predictor GEMM + its dC.  Padding / junk virtual rows are NOT counted."""
-    h, n = cfg["hidden"], 2 * b
+    h, n = cfg["hidden"], (b if dedup else 2 * b)
     lens = [WINDOW]
     for k, s, p in CONV:
         lens.append((lens[-1] + 2 * p - k) // s + 1)
@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="skip the in-situ kernel timing")
+    ap.add_argument("--dedup", action="store_true",
+                    help="one encoder/AR pass when past is future (identical results; NOT the reference's 2b-window step)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -171,7 +173,7 @@ def main():
     label = torch.zeros(args.batch, dtype=torch.long, device=device)
 
     def step():
-        tot, losses, _acc = cpcStep(x, x, label, model, crit)
+        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=args.dedup)
         tot.backward()
         dp.reduce_and_step()
         opt.zero_grad()
@@ -225,13 +227,15 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
                                    f"{cfg['npred']}, {cfg['nneg']} negatives, linear predictors), {args.batch} x 1.28 s "
-                                   f"windows per GPU, reference trainStep semantics (encoder+AR on 2b windows), "
-                                   f"fwd+bwd+allreduce+Adam",
+                                   f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
+                                                             if args.dedup else
+                                                             "reference trainStep semantics (encoder+AR on 2b windows), ")
+                                   + "fwd+bwd+allreduce+Adam",
                        "windows_per_gpu": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "final_losses": final_loss},
         }
         if "gemm_nt" in kernels:
-            flops, launches = gemm_nt_algorithmic_flops(args.batch, cfg)
+            flops, launches = gemm_nt_algorithmic_flops(args.batch, cfg, args.dedup)
             k = kernels["gemm_nt"]
             achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (conv1-4 fwd + bwd-data, GRU/predictor projections)",

@@ -12,11 +12,14 @@
 // ds_read_b128 fragment reads are bank-conflict free.
 #include "common.h"
 
+#include <algorithm>
+
 namespace cpc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;
+constexpr int BM = 128;          // TN kernel tile; the NT kernel derives its own from MI
 constexpr int LDS_NT = BK + 4;    // 36 floats per LDS row (NT: k contiguous)
 constexpr int LDS_TN = BM + 4;    // 132 floats per LDS row (TN: i/j contiguous)
 
@@ -28,6 +31,7 @@ struct GemmNTArgs {
     long M; int N; int K;
     RowMap map;
     int aligned;   // K%4==0, lda%4==0, ldb%4==0, bases 16-B aligned
+    int kchunk;    // K range per blockIdx.y (multiple of BK); gridDim.y > 1: partial products are atomically added
 };
 
 // 4 consecutive elements k..k+3 of row `row` (k < K or zero).  Rows beyond row_max are CLAMPED, not zeroed:
@@ -55,8 +59,11 @@ __device__ __forceinline__ float4 ld4(const float *base, long row, long row_max,
     }
 }
 
-template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
+// MI = 32-row MFMA tiles per wave along M: block tile (64*MI) x 128.  MI = 2 is the default 128x128 tile;
+// MI = 1 (64x128) is picked when the 128-row grid would leave CUs with a single workgroup.
+template <bool ALIGNED, int MI> __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
 {
+    constexpr int BM = 64 * MI;
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_NT];
     float *As = lds;                  // [BM][LDS_NT]
     float *Bs = lds + BM * LDS_NT;    // [BN][LDS_NT]
@@ -72,45 +79,45 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_nt_kernel(Ge
     const long m0 = (long)(blockIdx.x / tiles_n) * BM;
     const int n0 = (int)(blockIdx.x % tiles_n) * BN;
 
-    // loader: 4 float4 of A and 4 of B per thread; slot = tid + 256*q -> row = slot/8, c4 = slot%8
+    // loader: 2*MI float4 of A and 4 of B per thread; slot = tid + 256*q -> row = slot/8, c4 = slot%8
     const int lrow = tid >> 3;        // + 32*q
     const int lc4 = (tid & 7) * 4;
-    float4 ra[4], rb[4];
+    constexpr int QA = 2 * MI;
+    float4 ra[QA], rb[4];
 
-    const int nk_full = p.K / BK;              // K tiles that need no tail handling
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk_full = (kend - kbeg) / BK;    // K tiles that need no tail handling
     auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kbeg + kt * BK;
         if (ALIGNED && kt < nk_full) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ra[q] = ld4<ALIGNED, false>(p.A, m0 + lrow + 32 * q, p.M, p.lda, k0 + lc4, p.K);
-                rb[q] = ld4<ALIGNED, false>(p.B, n0 + lrow + 32 * q, p.N, p.ldb, k0 + lc4, p.K);
-            }
+            for (int q = 0; q < QA; ++q) ra[q] = ld4<ALIGNED, false>(p.A, m0 + lrow + 32 * q, p.M, p.lda, k0 + lc4, kend);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[q] = ld4<ALIGNED, false>(p.B, n0 + lrow + 32 * q, p.N, p.ldb, k0 + lc4, kend);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ra[q] = ld4<ALIGNED, true>(p.A, m0 + lrow + 32 * q, p.M, p.lda, k0 + lc4, p.K);
-                rb[q] = ld4<ALIGNED, true>(p.B, n0 + lrow + 32 * q, p.N, p.ldb, k0 + lc4, p.K);
-            }
+            for (int q = 0; q < QA; ++q) ra[q] = ld4<ALIGNED, true>(p.A, m0 + lrow + 32 * q, p.M, p.lda, k0 + lc4, kend);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[q] = ld4<ALIGNED, true>(p.B, n0 + lrow + 32 * q, p.N, p.ldb, k0 + lc4, kend);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (kend - kbeg + BK - 1) / BK;
     load_tiles(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<float4 *>(&As[(lrow + 32 * q) * LDS_NT + lc4]) = ra[q];
-            *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * q) * LDS_NT + lc4]) = rb[q];
-        }
+        for (int q = 0; q < QA; ++q) *reinterpret_cast<float4 *>(&As[(lrow + 32 * q) * LDS_NT + lc4]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * q) * LDS_NT + lc4]) = rb[q];
         __syncthreads();
         if (kt + 1 < nk) load_tiles(kt + 1);
 
@@ -118,14 +125,15 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_nt_kernel(Ge
         for (int kk = 0; kk < BK / 8; ++kk) {
             // lane (r32, h) takes k = kk*8 + 4h + {0,1,2,3}; MFMA step e pairs k-slot (h, e) of A
             // with the same k of B, so any k permutation shared by both operands is valid.
-            float4 a[2], b[2];
+            float4 a[MI], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const float4 *>(&As[(wm * 64 + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
-                b[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
-            }
+            for (int i = 0; i < MI; ++i)
+                a[i] = *reinterpret_cast<const float4 *>(&As[(wm * 32 * MI + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
+                b[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
@@ -137,19 +145,19 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_nt_kernel(Ge
         __syncthreads();
     }
 
-    // epilogue: acc[i][j][e] is C[m][n], m = m0 + wm*64 + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
+    // epilogue: acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
     float bias_v[2];
     int ncol[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         ncol[j] = n0 + wn * 64 + j * 32 + r32;
-        bias_v[j] = (p.bias != nullptr && ncol[j] < p.N) ? p.bias[ncol[j]] : 0.f;
+        bias_v[j] = (p.bias != nullptr && ncol[j] < p.N && blockIdx.y == 0) ? p.bias[ncol[j]] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const long m = m0 + wm * 32 * MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (m >= p.M) continue;
             long crow = m;
             if (p.map.enabled) {
@@ -162,7 +170,10 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_nt_kernel(Ge
             float *crowp = p.C + crow * p.ldc;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                if (ncol[j] < p.N) crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
+                if (ncol[j] < p.N) {
+                    if (gridDim.y > 1) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
+                    else crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
+                }
         }
     }
 }
@@ -176,12 +187,24 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     a.M = M; a.N = N; a.K = K; a.map = map;
     a.aligned = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
-    const long blocks = cdiv(M, BM) * cdiv(N, BN);
+    // 128-row tiles unless that grid cannot give every CU at least two workgroups (256 CUs)
+    const long blocks128 = cdiv(M, 128) * cdiv(N, BN);
+    const int mi = (a.aligned && blocks128 < 2 * 256) ? 1 : 2;
+    const long blocks = cdiv(M, 64 * mi) * cdiv(N, BN);
     CPC_REQUIRE(blocks <= 2147483647L, "gemm_nt: grid too large (%ld blocks)", blocks);
-    dim3 grid((unsigned)blocks);
+    // few tiles but a long K (e.g. dC = dP . W, K = 12 H): split K over blockIdx.y, partial products are
+    // atomically added into a zeroed C (dense, unmapped outputs only)
+    int splits = 1;
+    if (a.aligned && !map.enabled && ldc == N && blocks < 2 * 256 && K >= 8 * BK)
+        splits = (int)std::min<long>(cdiv(3 * 256, blocks), K / (4 * BK));
+    a.kchunk = (int)(cdiv(cdiv(K, splits), BK) * BK);
+    splits = (int)cdiv(K, a.kchunk);
+    if (splits > 1) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
+    dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);
-    if (a.aligned) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, st, a);
+    if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
+    else if (mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
     return CPC_OK;
 }

@@ -151,10 +151,18 @@ class DataParallelContext:
 
 
 # --------------------------------------------------------------------------- the step
-def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None):
+def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False):
     """train.py:95-108: model on cat([past, future]); context from the past half, targets from the
-    future half; returns (totLoss, allLosses [1,K], allAcc [1,K])."""
+    future half; returns (totLoss, allLosses [1,K], allAcc [1,K]).
+
+    dedup=True: when `future` IS `past` (no augmentation: dataset.py:308-321 yields the same window twice) the
+    two halves of the reference's 2b-window batch are identical and every op up to the criterion is per
+    window, so one pass over b windows gives bit-identical c_feature / encoded_data at half the work."""
     b = past.size(0)
+    if dedup and (future is past or (future.data_ptr() == past.data_ptr() and future.shape == past.shape)):
+        c_feature, encoded_data, label = cpcModel(past, label)
+        allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
+        return allLosses.sum(), allLosses, allAcc
     combined = torch.cat([past, future], dim=0)
     label = torch.cat([label, label])
     c_feature, encoded_data, label = cpcModel(combined, label)
