@@ -168,6 +168,7 @@ def main():
     model, crit, opt = build(cfg, device)
     dp = DataParallelContext(opt)
     crit.seed(1234 + rank)                                  # per-rank negative stream
+    crit.sampler.prefetch = True                            # host draws step i+1's MT19937 words during step i
     g = torch.Generator().manual_seed(1000 + rank)          # per-rank shard of the synthetic utterances
     x = (0.05 * torch.randn(args.batch, 1, WINDOW, generator=g)).to(device)
     label = torch.zeros(args.batch, dtype=torch.long, device=device)

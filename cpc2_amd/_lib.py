@@ -49,6 +49,11 @@ SIGNATURES = {
     "cpc_mt_get_state": (c_int, [c_ptr, c_ptr, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cpc_mt_set_state": (c_int, [c_ptr, c_ptr, c_int, c_int]),
     "cpc_negidx_sample_host": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "cpc_negidx_sample_host_async": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_negidx_wait": (c_int, [c_ptr]),
+    "cpc_mt_draw_host": (c_int, [c_ptr, c_ptr, c_size_t]),
+    "cpc_mt_draw_host_async": (c_int, [c_ptr, c_ptr, c_size_t]),
+    "cpc_negidx_expand": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_infonce_saved_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_forward": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),

@@ -33,6 +33,8 @@ class NegativeSampler:
             raise MemoryError("cpc_mt_create failed")
         self.follow_torch = True      # consume torch's global CPU generator (reference semantics)
         self._ring, self._events, self._slot = {}, {}, 0
+        self._prefetched = None
+        self.prefetch = False         # opt-in: draw step i+1's words during step i (private stream, fixed shapes)
 
     def __del__(self):
         try:
@@ -46,6 +48,7 @@ class NegativeSampler:
         """Private stream seeded like torch.manual_seed(seed); stops following the global generator."""
         check(self._lib.cpc_mt_seed(self._h, ctypes.c_uint32(int(seed) & 0xFFFFFFFF)), "mt_seed")
         self.follow_torch = False
+        self._prefetched = None       # (cpc_mt_seed waited for any draw in flight; its words are discarded)
 
     # torch CPU generator legacy state: u64 seed, i32 left, i32 seeded, u64 next, u64 mt[624], ...
     def _pull_torch_state(self):
@@ -83,25 +86,48 @@ class NegativeSampler:
         return (out, bidx, sidx) if want_parts else out
 
     def sample(self, batch, seq_len, window, n_neg, device, time_major=True):
-        """Device int32 extIdx (time-major by default: what the fused kernels read); staged through a
-        small ring of pinned buffers (async copy)."""
+        """Device int32 extIdx.  time_major (the fused kernels' layout): the host only draws the raw MT19937
+        words into a pinned buffer (on a worker thread, one step ahead, when the stream is private), the
+        device does the integer arithmetic (cpc_negidx_expand).  Otherwise: full host path, reference order."""
         n = batch * n_neg * window
+        if not time_major:
+            host = self.sample_host(batch, seq_len, window, n_neg)
+            return host.to(device)
         key = (n, str(device))
         if key not in self._ring:
-            self._ring[key] = [torch.empty(n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+            self._ring[key] = [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
             self._events[key] = [None] * self.RING
+            self._prefetched = None
+        ring, events = self._ring[key], self._events[key]
         slot = self._slot % self.RING
         self._slot += 1
-        ev = self._events[key][slot]
-        if ev is not None:
-            ev.synchronize()          # the copy that last used this staging buffer has finished
-        host = self._ring[key][slot]
-        self.sample_host(batch, seq_len, window, n_neg, out=host, time_major=time_major)
-        dev = host.to(device, non_blocking=True)
+        host = ring[slot]
+        if self._prefetched == (key, slot):
+            check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")           # drawn while the GPU was busy
+        else:
+            if events[slot] is not None:
+                events[slot].synchronize()     # the copy that last used this staging buffer has finished
+            st = self._pull_torch_state() if self.follow_torch else None
+            check(self._lib.cpc_mt_draw_host(self._h, ptr(host), 2 * n), "mt_draw_host")
+            if st is not None:
+                self._push_torch_state(st)
+        raw = host.to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
-        self._events[key][slot] = ev
-        return dev
+        events[slot] = ev
+        ext = torch.empty(n, dtype=torch.int32, device=device)
+        check(self._lib.cpc_negidx_expand(ptr(raw), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
+              "negidx_expand")
+        self._prefetched = None
+        if self.prefetch and not self.follow_torch:
+            # private stream: draw the NEXT step's words now, on the library's worker thread (the caller promises
+            # that the next call has the same shape -- the words are consumed from the stream either way)
+            nslot = self._slot % self.RING
+            if events[nslot] is not None:
+                events[nslot].synchronize()
+            check(self._lib.cpc_mt_draw_host_async(self._h, ptr(ring[nslot]), 2 * n), "mt_draw_host_async")
+            self._prefetched = (key, nslot)
+        return ext
 
 
 # --------------------------------------------------------------------------- fused InfoNCE

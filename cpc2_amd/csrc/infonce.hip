@@ -286,6 +286,23 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
     }
 }
 
+// raw[0..n) -> batchIdx = raw % b, raw[n..2n) -> seqIdx = raw % (T-1) + 1 (draw order i = (bb*Nneg + nn)*W + t);
+// ext[(bb*W + t)*Nneg + nn] = (seqIdx + t) mod T + batchIdx*T      (criterion.py:247-266, integer-exact)
+__global__ void negidx_expand_kernel(const uint32_t *raw, int32_t *ext, int b, int T, int W, int Nneg)
+{
+    const long n = (long)b * Nneg * W;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        const int nn = (int)(o % Nneg);
+        const long bt = o / Nneg;
+        const int t = (int)(bt % W), bb = (int)(bt / W);
+        const long i = ((long)bb * Nneg + nn) * W + t;
+        const uint32_t bi = raw[i] % (uint32_t)b;
+        uint32_t seq = raw[n + i] % (uint32_t)(T - 1) + 1u + (uint32_t)t;
+        if (seq >= (uint32_t)T) seq -= (uint32_t)T;
+        ext[o] = (int32_t)(seq + bi * (uint32_t)T);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct NceLayout {
     int b, T, K, W, Har, Henc, Nneg, lw;
@@ -399,6 +416,19 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
 }
 
 }  // namespace cpc
+
+extern "C" int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
+                                 cpc_stream_t stream)
+{
+    CPC_REQUIRE(raw != nullptr && ext_idx != nullptr && batch >= 1 && seq_len >= 2 && window >= 1 && window <= seq_len && n_neg >= 1 &&
+                    (long long)batch * seq_len <= 2147483647LL,
+                "cpc_negidx_expand: bad arguments (batch=%d seq_len=%d window=%d n_neg=%d)", batch, seq_len, window, n_neg);
+    const long n = (long)batch * n_neg * window;
+    hipLaunchKernelGGL(cpc::negidx_expand_kernel, dim3((unsigned)std::min<long>(cpc::cdiv(n, 256), 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), raw, ext_idx, batch, seq_len, window, n_neg);
+    CPC_CHECK_LAUNCH("negidx_expand_kernel");
+    return CPC_OK;
+}
 
 extern "C" size_t cpc_infonce_saved_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg)
 {

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/cpc2_hip.h"
@@ -20,6 +21,8 @@ struct cpc_mt19937 {
     int left;   // torch: twist when --left == 0
     int next;
     std::vector<uint32_t> tmp;
+    std::thread worker;        // at most one asynchronous sample in flight (cpc_negidx_sample_host_async)
+    int worker_status = 0;
 };
 
 namespace {
@@ -72,11 +75,16 @@ extern "C" cpc_mt19937 *cpc_mt_create(uint32_t seed)
     return g;
 }
 
-extern "C" void cpc_mt_destroy(cpc_mt19937 *g) { delete g; }
+extern "C" void cpc_mt_destroy(cpc_mt19937 *g)
+{
+    if (g != nullptr && g->worker.joinable()) g->worker.join();
+    delete g;
+}
 
 extern "C" int cpc_mt_seed(cpc_mt19937 *g, uint32_t seed)
 {
     if (g == nullptr) { cpc::set_error("cpc_mt_seed: null generator"); return CPC_ERR_INVALID; }
+    if (g->worker.joinable()) g->worker.join();
     g->mt[0] = seed;
     for (int i = 1; i < N; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
     g->left = 1;
@@ -105,10 +113,56 @@ extern "C" int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left,
     return CPC_OK;
 }
 
-extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major,
-                                      int32_t *ext_idx_host, int64_t *batch_idx_host_opt, int64_t *seq_idx_host_opt)
+namespace {
+// a % d for 32-bit a, exact: quotient estimate in double (53-bit mantissa, error <= 1) + one correction.
+// Branch-free and auto-vectorisable, unlike the hardware 32-bit divide.
+struct FastMod {
+    uint32_t d;
+    double inv;
+    explicit FastMod(uint32_t dd) : d(dd), inv(1.0 / (double)dd) {}
+    inline uint32_t operator()(uint32_t a) const
+    {
+        const uint32_t q = (uint32_t)((double)a * inv);
+        int64_t r = (int64_t)a - (int64_t)q * d;
+        r += (r < 0) ? (int64_t)d : 0;
+        r -= (r >= (int64_t)d) ? (int64_t)d : 0;
+        return (uint32_t)r;
+    }
+};
+
+int sample_impl(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major, int32_t *ext,
+                int64_t *batch_idx_opt, int64_t *seq_idx_opt)
 {
-    if (g == nullptr || ext_idx_host == nullptr || batch < 1 || seq_len < 2 || window < 1 || window > seq_len || n_neg < 1) {
+    const size_t n = (size_t)n_neg * window * batch;
+    g->tmp.resize(2 * n);
+    uint32_t *raw_b = g->tmp.data(), *raw_s = raw_b + n;
+    draw(g, raw_b, n);      // batchIdx stream first (criterion.py:247-250)
+    draw(g, raw_s, n);      // then seqIdx (criterion.py:253-256)
+    const FastMod mod_b((uint32_t)batch), mod_s((uint32_t)(seq_len - 1));
+    const uint32_t T = (uint32_t)seq_len;
+    // in place: raw_b <- batchIdx * T, raw_s <- seqIdx (two flat, vectorisable passes)
+    for (size_t i = 0; i < n; ++i) raw_b[i] = mod_b(raw_b[i]);
+    for (size_t i = 0; i < n; ++i) raw_s[i] = mod_s(raw_s[i]) + 1u;
+    if (batch_idx_opt) for (size_t i = 0; i < n; ++i) batch_idx_opt[i] = (int64_t)raw_b[i];
+    if (seq_idx_opt) for (size_t i = 0; i < n; ++i) seq_idx_opt[i] = (int64_t)raw_s[i];
+    // draw order: i = (bb*n_neg + nn)*window + t   (criterion.py:259-263)
+    size_t i = 0;
+    for (size_t row = 0; row < (size_t)n_neg * batch; ++row) {
+        const size_t bb = row / (size_t)n_neg, nn = row % (size_t)n_neg;
+        int32_t *dst = time_major ? ext + bb * (size_t)window * n_neg + nn : ext + i;
+        const size_t step = time_major ? (size_t)n_neg : 1;
+        for (uint32_t t = 0; t < (uint32_t)window; ++t, ++i) {
+            uint32_t seq = raw_s[i] + t;
+            seq -= (seq >= T) ? T : 0u;                      // seqIdx <= T-1, t <= T-1 -> one wrap at most
+            dst[t * step] = (int32_t)(seq + raw_b[i] * T);
+        }
+    }
+    return CPC_OK;
+}
+
+int check_args(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, const int32_t *ext)
+{
+    if (g == nullptr || ext == nullptr || batch < 1 || seq_len < 2 || window < 1 || window > seq_len || n_neg < 1) {
         cpc::set_error("cpc_negidx_sample_host: bad arguments (batch=%d seq_len=%d window=%d n_neg=%d)", batch, seq_len, window, n_neg);
         return CPC_ERR_INVALID;
     }
@@ -116,25 +170,54 @@ extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, in
         cpc::set_error("cpc_negidx_sample_host: batch*seq_len exceeds int32");
         return CPC_ERR_INVALID;
     }
-    const size_t n = (size_t)n_neg * window * batch;
-    g->tmp.resize(2 * n);
-    uint32_t *raw_b = g->tmp.data(), *raw_s = raw_b + n;
-    draw(g, raw_b, n);      // batchIdx stream first (criterion.py:247-250)
-    draw(g, raw_s, n);      // then seqIdx (criterion.py:253-256)
-    const uint32_t ub = (uint32_t)batch, us = (uint32_t)(seq_len - 1);
-    size_t i = 0;                   // draw order: i = (bb*n_neg + nn)*window + t   (criterion.py:259-263)
-    for (size_t row = 0; row < (size_t)n_neg * batch; ++row) {
-        const size_t bb = row / (size_t)n_neg, nn = row % (size_t)n_neg;
-        for (int t = 0; t < window; ++t, ++i) {
-            const uint32_t bi = raw_b[i] % ub;
-            const uint32_t si = raw_s[i] % us + 1u;
-            uint32_t seq = si + (uint32_t)t;
-            if (seq >= (uint32_t)seq_len) seq -= (uint32_t)seq_len;     // si <= T-1, t <= T-1 -> one wrap at most
-            const size_t o = time_major ? (bb * (size_t)window + (size_t)t) * (size_t)n_neg + nn : i;
-            ext_idx_host[o] = (int32_t)(seq + bi * (uint32_t)seq_len);
-            if (batch_idx_host_opt) batch_idx_host_opt[i] = (int64_t)bi;
-            if (seq_idx_host_opt) seq_idx_host_opt[i] = (int64_t)si;
-        }
-    }
+    return CPC_OK;
+}
+}  // namespace
+
+extern "C" int cpc_negidx_wait(cpc_mt19937 *g)
+{
+    if (g == nullptr) { cpc::set_error("cpc_negidx_wait: null generator"); return CPC_ERR_INVALID; }
+    if (g->worker.joinable()) g->worker.join();
+    const int st = g->worker_status;
+    g->worker_status = 0;
+    return st;
+}
+
+extern "C" int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major,
+                                      int32_t *ext_idx_host, int64_t *batch_idx_host_opt, int64_t *seq_idx_host_opt)
+{
+    const int st = check_args(g, batch, seq_len, window, n_neg, ext_idx_host);
+    if (st != CPC_OK) return st;
+    cpc_negidx_wait(g);      // an asynchronous sample (if any) owns the generator until it is done
+    return sample_impl(g, batch, seq_len, window, n_neg, time_major, ext_idx_host, batch_idx_host_opt, seq_idx_host_opt);
+}
+
+// Raw generator outputs (tempered 32-bit words, the values torch.randint reduces modulo its range): the
+// sequential, bit-exact part of the sampler.  cpc_negidx_expand (device) turns 2*n of them into extIdx.
+extern "C" int cpc_mt_draw_host(cpc_mt19937 *g, uint32_t *raw_host, size_t n)
+{
+    if (g == nullptr || raw_host == nullptr) { cpc::set_error("cpc_mt_draw_host: null argument"); return CPC_ERR_INVALID; }
+    cpc_negidx_wait(g);
+    draw(g, raw_host, n);
+    return CPC_OK;
+}
+
+extern "C" int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t n)
+{
+    if (g == nullptr || raw_host == nullptr) { cpc::set_error("cpc_mt_draw_host_async: null argument"); return CPC_ERR_INVALID; }
+    cpc_negidx_wait(g);
+    g->worker = std::thread([=] { draw(g, raw_host, n); g->worker_status = CPC_OK; });
+    return CPC_OK;
+}
+
+// Same as cpc_negidx_sample_host but on a worker thread: returns at once, ext_idx_host is valid after
+// cpc_negidx_wait(g).  Lets the host draw step i+1's indices while the GPU is busy with step i.
+extern "C" int cpc_negidx_sample_host_async(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major,
+                                            int32_t *ext_idx_host)
+{
+    const int st = check_args(g, batch, seq_len, window, n_neg, ext_idx_host);
+    if (st != CPC_OK) return st;
+    cpc_negidx_wait(g);
+    g->worker = std::thread([=] { g->worker_status = sample_impl(g, batch, seq_len, window, n_neg, time_major, ext_idx_host, nullptr, nullptr); });
     return CPC_OK;
 }

