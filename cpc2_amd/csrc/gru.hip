@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace cpc {
 
@@ -44,6 +45,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 struct GruArgs {
     const float *gi;      // [N*T][3H]   input projections incl. b_ih
     const float4 *wpack;  // packed W_hh
+    const float *whh;     // W_hh [3H][H] as stored (cooperative kernel)
     const float *bhh;     // [3H]
     const float *h0;      // [N][H] or null
     float *out;           // [N][T][H]
@@ -192,6 +194,267 @@ __global__ void gru_bwd_kernel(GruArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// On-chip recurrence for H = 256: W_hh never leaves the register file.  A GROUP of 4 workgroups (512 threads
+// each, one per CU) shares COOP_NB windows; member m owns hidden units [64m, 64m+64) = 192 gate rows of W_hh,
+// 96 weights per thread (thread (u, q): unit u, K slice q of 32).  Per step every member multiplies its slice
+// by the full h (LDS), finishes the K reduction with 3 wave shuffles, applies the gates for its 64 units and
+// publishes them; the four members exchange the new h through 8-byte {epoch, value} granules in L2
+// (one sc1 store each, polled with relaxed agent-scope loads: MI355X guide, Guideline 16 R2).  A member can be
+// at most one step ahead of another, so two granule sets (epoch parity) suffice.  Every spin is bounded: on
+// time-out the workgroup poisons its outputs with NaN and leaves.
+constexpr int COOP_G = 4;            // workgroups per group
+constexpr int COOP_H = 256;
+constexpr int COOP_U = COOP_H / COOP_G;     // units per member
+constexpr int COOP_LDH = 8 * 36;            // padded h row: chunk q of 32 floats at q*36
+
+typedef unsigned long long gu64_t;
+#define COOP_GLOBAL __attribute__((address_space(1)))
+
+__device__ __forceinline__ int coop_pad(int k) { return (k >> 5) * 36 + (k & 31); }
+
+struct GruCoopArgs {
+    GruArgs g;
+    gu64_t *comm;          // [groups][2][NB][H] granules, zeroed before the launch
+    int groups, xcd_map;
+};
+
+template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(GruCoopArgs ca)
+{
+    __shared__ __attribute__((aligned(16))) float hs[2][NB][COOP_LDH];
+    const GruArgs &a = ca.g;
+    constexpr int H = COOP_H;
+    const int T = a.T;
+    int group, member;
+    if (ca.xcd_map) {                       // members of a group on one XCD (speed only: blocks b, b+8 share one)
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        group = xcd * (ca.groups / 8) + (i >> 2);
+        member = i & 3;
+    } else {
+        group = blockIdx.x >> 2;
+        member = blockIdx.x & 3;
+    }
+    const int tid = threadIdx.x;
+    const int q = tid & 7, u = tid >> 3;
+    const int j = member * COOP_U + u;
+    const int n0 = group * NB;
+
+    float w[3][32];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i4 = 0; i4 < 8; ++i4) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.whh + (long)(g * H + j) * H + q * 32 + 4 * i4);
+            w[g][4 * i4] = v.x; w[g][4 * i4 + 1] = v.y; w[g][4 * i4 + 2] = v.z; w[g][4 * i4 + 3] = v.w;
+        }
+    const float bh0 = a.bhh[j], bh1 = a.bhh[H + j], bh2 = a.bhh[2 * H + j];
+
+    for (int idx = tid; idx < NB * H; idx += 512) {
+        const int s = idx / H, k = idx - s * H;
+        const int n = n0 + s;
+        const float v = (n < a.N && a.h0 != nullptr) ? a.h0[(long)n * H + k] : 0.f;
+        hs[0][s][coop_pad(k)] = v;
+        if (n < a.N && (k / COOP_U) == member) a.hall[((long)n * (T + 1)) * H + k] = v;
+    }
+    __syncthreads();
+
+    bool dead = false;
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // this lane finishes sample q (if q < NB): fetch its input projections early
+        const int ns = n0 + q;
+        const bool mine = q < NB && ns < a.N;
+        float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f;
+        if (mine) {
+            const float *gp = a.gi + ((long)ns * T + t) * 3 * H;
+            gi0 = gp[j]; gi1 = gp[H + j]; gi2 = gp[2 * H + j];
+        }
+        float acc[NB][3];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const float4 h4 = *reinterpret_cast<const float4 *>(&hs[cur][s][q * 36 + 4 * i4]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[s][g] = fmaf(w[g][4 * i4], h4.x, fmaf(w[g][4 * i4 + 1], h4.y,
+                                fmaf(w[g][4 * i4 + 2], h4.z, fmaf(w[g][4 * i4 + 3], h4.w, acc[s][g]))));
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                acc[s][g] += __shfl_xor(acc[s][g], 1, 64);
+                acc[s][g] += __shfl_xor(acc[s][g], 2, 64);
+                acc[s][g] += __shfl_xor(acc[s][g], 4, 64);
+            }
+        }
+        if (q < NB) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < NB; ++s)
+                if (s == q) { g0 = acc[s][0]; g1 = acc[s][1]; g2 = acc[s][2]; }
+            g0 += bh0; g1 += bh1; g2 += bh2;
+            const float hp = hs[cur][q][coop_pad(j)];
+            const float r = sigmoidf_(gi0 + g0);
+            const float z = sigmoidf_(gi1 + g1);
+            const float c = tanhf(gi2 + r * g2);
+            float hv = (1.f - z) * c + z * hp;
+            if (dead) hv = NAN;
+            if (mine) {
+                const long row = (long)ns * T + t;
+                float *gs = a.gates + row * 3 * H;
+                gs[j] = r; gs[H + j] = z; gs[2 * H + j] = c;
+                a.hn[row * H + j] = g2;
+                a.out[row * H + j] = hv;
+                a.hall[((long)ns * (T + 1) + t + 1) * H + j] = hv;
+            }
+            // publish (also for padding windows, so that every granule of the epoch gets written)
+            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
+            __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // gather the whole new h (all four members) into the other LDS buffer
+        if (t + 1 < T) {
+            for (int idx = tid; idx < NB * H; idx += 512) {
+                const int s = idx / H, k = idx - s * H;
+                COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + s) * H + k);
+                gu64_t x = 0;
+                unsigned spins = dead ? (1u << 22) : 0u;       // once timed out, never wait again
+                for (;;) {
+                    x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(x >> 32) == (unsigned)(t + 1)) break;
+                    if (++spins > (1u << 22)) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                hs[nxt][s][coop_pad(k)] = __uint_as_float((unsigned)x);
+            }
+            dead = __syncthreads_or(dead);
+        }
+    }
+    if (a.hlast != nullptr && q < NB && n0 + q < a.N)
+        a.hlast[(long)(n0 + q) * H + j] = a.hall[((long)(n0 + q) * (T + 1) + T) * H + j];
+}
+
+// Backward twin of gru_fwd_coop_kernel: member m keeps the SAME 192 rows of W_hh (its 64 units x 3 gates) in
+// registers, now one COLUMN j' per thread (thread (j', half): 96 rows), forms its partial W_hh^T dGH for all 256
+// columns and the four members exchange the 64-column pieces the others own.
+//   comm: [groups][2][COOP_G (sender)][NB][H] granules, zeroed before the launch.
+template <int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(GruCoopArgs ca)
+{
+    __shared__ __attribute__((aligned(16))) float dgs[NB][3 * COOP_U];     // this member's dGH rows (gate, unit)
+    __shared__ float part[2][NB][COOP_H];
+    const GruArgs &a = ca.g;
+    constexpr int H = COOP_H, U = COOP_U;
+    const int T = a.T;
+    int group, member;
+    if (ca.xcd_map) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        group = xcd * (ca.groups / 8) + (i >> 2);
+        member = i & 3;
+    } else {
+        group = blockIdx.x >> 2;
+        member = blockIdx.x & 3;
+    }
+    const int tid = threadIdx.x;
+    const int jc = tid & (H - 1), half = tid >> 8;            // column jc, rows half*96 .. +96 of the member's 192
+    const int n0 = group * NB;
+
+    float w[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) {
+        const int lr = half * 96 + i;                          // local row = gate*64 + unit
+        w[i] = a.whh[(long)((lr / U) * H + member * U + (lr % U)) * H + jc];
+    }
+    // elementwise role: thread (es, eu) for tid < NB*U
+    const int es = tid / U, eu = tid - es * U;
+    const int ej = member * U + eu;
+    const int en = n0 + es;
+    const bool ew = tid < NB * U;
+    const bool emine = ew && en < a.N;
+    float carry = 0.f;
+    if (emine) {                                               // zero junk row T of dGH
+        float *zr = a.dgh + ((long)en * (T + 1) + T) * 3 * H;
+        zr[ej] = 0.f; zr[H + ej] = 0.f; zr[2 * H + ej] = 0.f;
+    }
+    bool dead = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
+        float keep = 0.f;
+        if (ew) {
+            float dpr = 0.f, dpz = 0.f, dhn = 0.f;
+            if (emine) {
+                const long row = (long)en * T + t;
+                const float dh = a.dout[row * H + ej] + carry;
+                const float *gs = a.gates + row * 3 * H;
+                const float r = gs[ej], z = gs[H + ej], c = gs[2 * H + ej];
+                const float hnv = a.hn[row * H + ej];
+                const float hp_ = a.hall[((long)en * (T + 1) + t) * H + ej];
+                const float dc = dh * (1.f - z);
+                const float dz = dh * (hp_ - c);
+                const float dpn = dc * (1.f - c * c);
+                dpr = dpn * hnv * r * (1.f - r);
+                dpz = dz * z * (1.f - z);
+                dhn = dpn * r;
+                keep = dh * z;
+                float *gi = a.dgi + row * 3 * H;
+                gi[ej] = dpr; gi[H + ej] = dpz; gi[2 * H + ej] = dpn;
+                float *gh = a.dgh + ((long)en * (T + 1) + t) * 3 * H;
+                gh[ej] = dpr; gh[H + ej] = dpz; gh[2 * H + ej] = dhn;
+            }
+            dgs[es][eu] = dpr; dgs[es][U + eu] = dpz; dgs[es][2 * U + eu] = dhn;
+        }
+        __syncthreads();
+        // partial[jc] over this thread's 96 rows, all NB windows
+        float acc[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) acc[s] = 0.f;
+#pragma unroll
+        for (int i4 = 0; i4 < 24; ++i4) {
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(&dgs[s][half * 96 + 4 * i4]);
+                acc[s] = fmaf(w[4 * i4], d4.x, fmaf(w[4 * i4 + 1], d4.y, fmaf(w[4 * i4 + 2], d4.z, fmaf(w[4 * i4 + 3], d4.w, acc[s]))));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s];
+        __syncthreads();
+        // publish the columns other members own (this member's own columns stay in LDS)
+        if (t > 0) {
+            for (int idx = tid; idx < NB * H; idx += 512) {
+                const int s = idx / H, k = idx - s * H;
+                if (k / U == member) continue;
+                const float v = part[0][s][k] + part[1][s][k];
+                COOP_GLOBAL gu64_t *slot =
+                    (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * COOP_G + member) * NB + s) * H + k);
+                __hip_atomic_store(slot, ((gu64_t)epoch << 32) | (gu64_t)__float_as_uint(dead ? NAN : v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (ew) {
+                float sum = keep + part[0][es][ej] + part[1][es][ej];
+#pragma unroll
+                for (int d = 1; d < COOP_G; ++d) {
+                    const int src = (member + d) & (COOP_G - 1);
+                    COOP_GLOBAL gu64_t *slot =
+                        (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * COOP_G + src) * NB + es) * H + ej);
+                    gu64_t x = 0;
+                    unsigned spins = dead ? (1u << 22) : 0u;
+                    for (;;) {
+                        x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(x >> 32) == epoch) break;
+                        if (++spins > (1u << 22)) { dead = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    sum += __uint_as_float((unsigned)x);
+                }
+                carry = sum;
+            }
+            dead = __syncthreads_or(dead);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct GruLayout {
     int N, T, Din, H, layers;
     // saved, per layer
@@ -200,6 +463,8 @@ struct GruLayout {
     // scratch
     float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn;
     float4 *wpack;
+    unsigned long long *comm;
+    size_t comm_bytes;
     size_t tn_bytes, scratch_bytes;
 };
 
@@ -227,6 +492,8 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     g.wt = sc.take<float>((size_t)3 * H * dmax);
     g.wpack = sc.take<float4>((size_t)3 * H * H / 4);
     g.cs = sc.take<float>(colsum_rows_scratch_bytes(3 * H) / sizeof(float));
+    g.comm_bytes = sizeof(unsigned long long) * 256 * 2 * COOP_G * (size_t)COOP_H;   // groups*NB <= 256 windows, 2 parities
+    g.comm = sc.take<unsigned long long>(g.comm_bytes / sizeof(unsigned long long));
     g.tn_bytes = std::max(gemm_tn_scratch_bytes(3 * H, H, (long)N * (T + 1)), gemm_tn_scratch_bytes(3 * H, dmax, (long)N * T));
     g.tn_bytes = std::max(g.tn_bytes, gemm_tn_scratch_bytes(3 * H, Din, (long)N * T));
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
@@ -255,8 +522,27 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         a.out = (l + 1 < layers) ? g.outl[l] : out;
         a.hall = g.hall[l]; a.gates = g.gates[l]; a.hn = g.hn[l];
         a.hlast = h_last ? h_last + (size_t)l * N * H : nullptr;
-        a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
-        {
+        a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
+        static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
+        const int nb = N <= 64 ? 1 : (N <= 128 ? 2 : (N <= 256 ? 4 : 0));
+        static const int n_cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+            return v;
+        }();
+        // the cooperative kernel needs every workgroup resident at once (1 per CU)
+        if (H == COOP_H && nb != 0 && !coop_off && (int)cdiv(N, nb) * COOP_G <= n_cus) {
+            GruCoopArgs ca{};
+            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * nb * COOP_H, st));
+            ProfScope prof(PROF_GRU_FWD, st);
+            const dim3 grid((unsigned)(ca.groups * COOP_G));
+            if (nb == 1) hipLaunchKernelGGL(gru_fwd_coop_kernel<1>, grid, dim3(512), 0, st, ca);
+            else if (nb == 2) hipLaunchKernelGGL(gru_fwd_coop_kernel<2>, grid, dim3(512), 0, st, ca);
+            else hipLaunchKernelGGL(gru_fwd_coop_kernel<4>, grid, dim3(512), 0, st, ca);
+        } else {
             ProfScope prof(PROF_GRU_FWD, st);
             const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * 3 * hp);
             hipLaunchKernelGGL(gru_fwd_kernel, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
@@ -280,13 +566,31 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1];
         const float *xin = (l == 0) ? x : g.outl[l - 1];
         const int din = (l == 0) ? Din : H;
-        hipLaunchKernelGGL(gru_pack_bwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);
-        CPC_CHECK_LAUNCH("gru_pack_bwd_kernel");
         GruArgs a{};
         a.wpack = g.wpack; a.hall = g.hall[l]; a.gates = g.gates[l]; a.hn = g.hn[l];
-        a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
+        a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
-        {
+        static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
+        static const int n_cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+            return v;
+        }();
+        const int nb = N <= 64 ? 1 : (N <= 128 ? 2 : (N <= 256 ? 4 : 0));
+        if (H == COOP_H && nb != 0 && !coop_off && (int)cdiv(N, nb) * COOP_G <= n_cus) {
+            GruCoopArgs ca{};
+            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * COOP_G * nb * COOP_H, st));
+            ProfScope prof(PROF_GRU_BWD, st);
+            const dim3 grid((unsigned)(ca.groups * COOP_G));
+            if (nb == 1) hipLaunchKernelGGL(gru_bwd_coop_kernel<1>, grid, dim3(512), 0, st, ca);
+            else if (nb == 2) hipLaunchKernelGGL(gru_bwd_coop_kernel<2>, grid, dim3(512), 0, st, ca);
+            else hipLaunchKernelGGL(gru_bwd_coop_kernel<4>, grid, dim3(512), 0, st, ca);
+        } else {
+            hipLaunchKernelGGL(gru_pack_bwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);
+            CPC_CHECK_LAUNCH("gru_pack_bwd_kernel");
             ProfScope prof(PROF_GRU_BWD, st);
             const size_t lds = sizeof(float) * ((size_t)3 * H + (size_t)kq * hp);
             hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)N), dim3(kq * hp), lds, st, a);

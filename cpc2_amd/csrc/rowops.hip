@@ -53,8 +53,18 @@ __global__ void colsum_kernel(const float *part, long rows, long ld, int width, 
     __shared__ float red[16][65];
     const int c = blockIdx.x * 64 + threadIdx.x;
     float s = 0.f;
-    if (c < width)
-        for (long r = threadIdx.y; r < rows; r += 16) s += part[r * ld + c];
+    if (c < width) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // 4 independent chains: loads of a thread overlap
+        long r = threadIdx.y;
+        for (; r + 48 < rows; r += 64) {
+            s0 += part[r * ld + c];
+            s1 += part[(r + 16) * ld + c];
+            s2 += part[(r + 32) * ld + c];
+            s3 += part[(r + 48) * ld + c];
+        }
+        for (; r < rows; r += 16) s0 += part[r * ld + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && c < width) {
