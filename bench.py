@@ -241,7 +241,10 @@ def main():
             achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (conv1-4 fwd + bwd-data, GRU/predictor projections)",
                                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                               # HBM bytes per launch from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE KiB,
+                               # profiles/r01_v2_pmc_summary.md), valid for the default workload only
+                               "traffic": 4.46e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
                                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
                                "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
         out["kernels"] = kernels
