@@ -127,3 +127,19 @@ def scratch(nbytes, device):
         buf = torch.empty(int(nbytes) + 4096, dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf
+
+
+def grad_buffers(params):
+    """Output buffers for parameter gradients.  A parameter re-homed by FlatAdam(direct_grads=True) carries
+    `_cpc_flat` = (flat_grad, offset): its gradient is then written straight into the flat gradient buffer (a
+    FRESH view each time, so autograd adopts it as .grad instead of adding it) -- but only while .grad is None;
+    otherwise (accumulation across backward passes) a private buffer is returned and autograd adds it."""
+    out = []
+    for p in params:
+        home = getattr(p, "_cpc_flat", None)
+        if home is not None and p.grad is None:
+            flat, off = home
+            out.append(flat[off:off + p.numel()].view(p.shape))
+        else:
+            out.append(torch.empty_like(p))
+    return out

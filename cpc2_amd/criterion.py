@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import check, f32c, ptr, require_gpu, scratch, stream_ptr
+from ._lib import check, f32c, grad_buffers, ptr, require_gpu, scratch, stream_ptr
 
 
 # --------------------------------------------------------------------------- index sampler
@@ -131,12 +131,32 @@ class NegativeSampler:
 
 
 # --------------------------------------------------------------------------- fused InfoNCE
+def _packed_view(tensors):
+    """[K, *shape] view over K equally shaped tensors that sit back to back in memory (the predictors of a
+    FlatAdam-managed criterion do), else None."""
+    first = tensors[0]
+    step = first.numel() * first.element_size()
+    need = first.storage_offset() * first.element_size() + len(tensors) * step
+    if first.untyped_storage().nbytes() < need:          # adjacent by accident, not one allocation
+        return None
+    for i, t in enumerate(tensors):
+        if not t.is_contiguous() or t.shape != first.shape or t.data_ptr() != first.data_ptr() + i * step:
+            return None
+    k = len(tensors)
+    return torch.as_strided(first, (k,) + tuple(first.shape), (first.numel(),) + tuple(first.stride()))
+
+
 class _InfoNCEFn(torch.autograd.Function):
+    """inputs: c, z, ext_idx, weights, n_neg, then the K predictor weights [dim_enc, dim_ar]."""
+
     @staticmethod
-    def forward(ctx, c, z, wpred, ext_idx, weights, n_neg):
-        require_gpu(c, z, wpred, ext_idx)
+    def forward(ctx, c, z, ext_idx, weights, n_neg, *wk):
+        require_gpu(c, z, ext_idx, *wk)
         lib = _lib.load()
-        c, z, wpred = f32c(c), f32c(z), f32c(wpred)
+        c, z = f32c(c), f32c(z)
+        wpred = _packed_view([w.detach() for w in wk])
+        if wpred is None:
+            wpred = torch.stack([f32c(w.detach()) for w in wk], dim=0)
         b, t, dim_ar = c.shape
         k, dim_enc, _ = wpred.shape
         if z.shape != (b, t, dim_enc) or wpred.shape[2] != dim_ar:
@@ -156,6 +176,7 @@ class _InfoNCEFn(torch.autograd.Function):
                                       ptr(saved), ptr(sc), b, t, k, dim_ar, dim_enc, n_neg, stream_ptr(c.device)),
               "infonce_forward")
         ctx.save_for_backward(c, z, wpred, ext_idx, w, saved)
+        ctx.param_refs = wk
         ctx.dims = (b, t, k, dim_ar, dim_enc, n_neg)
         ctx.mark_non_differentiable(acc)
         return losses, acc
@@ -166,12 +187,19 @@ class _InfoNCEFn(torch.autograd.Function):
         c, z, wpred, ext_idx, w, saved = ctx.saved_tensors
         b, t, k, dim_ar, dim_enc, n_neg = ctx.dims
         dlosses = f32c(dlosses)
-        dc, dz, dw = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wpred)
+        dc, dz = torch.empty_like(c), torch.empty_like(z)
+        gw = grad_buffers(ctx.param_refs)
+        dw = _packed_view(gw)                 # contiguous in the flat gradient buffer -> written in place
+        direct = dw is not None
+        if not direct:
+            dw = torch.empty_like(wpred)
         sc = scratch(lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg), c.device)
         check(lib.cpc_infonce_backward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
                                        ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
                                        stream_ptr(c.device)), "infonce_backward")
-        return dc, dz, dw, None, None, None
+        if not direct:
+            gw = list(dw.unbind(0))
+        return (dc, dz, None, None, None) + tuple(gw)
 
 
 # --------------------------------------------------------------------------- modules
@@ -281,7 +309,7 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         else:
             quality_weighting = None                    # ones (criterion.py:340)
         extIdx = self.sampleIndices(batchSize, seqSize, windowSize, cFeature.device)
-        losses, acc = _InfoNCEFn.apply(cFeature, encodedData, self.wPrediction.packed_weight(), extIdx,
-                                       quality_weighting, self.negativeSamplingExt)
+        losses, acc = _InfoNCEFn.apply(cFeature, encodedData, extIdx, quality_weighting, self.negativeSamplingExt,
+                                       *[p.weight for p in self.wPrediction.predictors])
         losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
         return losses.view(1, -1), acc.view(1, -1)

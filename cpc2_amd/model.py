@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import check, f32c, ptr, ptr_array, require_gpu, scratch, stream_ptr
+from ._lib import check, f32c, grad_buffers, ptr, ptr_array, require_gpu, scratch, stream_ptr
 
 
 # --------------------------------------------------------------------------- ChannelNorm
@@ -86,6 +86,7 @@ class _EncoderFn(torch.autograd.Function):
         require_gpu(x, *params)
         lib = _lib.load()
         x = f32c(x)
+        ctx.param_refs = params
         params = tuple(f32c(p) for p in params)
         n, cin, length = x.shape
         if cin != 1:
@@ -112,7 +113,7 @@ class _EncoderFn(torch.autograd.Function):
         x, saved, *params = ctx.saved_tensors
         n, length, hidden = ctx.dims
         dz = f32c(dz)
-        grads = [torch.empty_like(p) for p in params]
+        grads = grad_buffers(ctx.param_refs)
         sc = scratch(lib.cpc_encoder_scratch_bytes(n, length, hidden), x.device)
         check(lib.cpc_encoder_backward(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
                                        n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward")
@@ -165,6 +166,7 @@ class _GruFn(torch.autograd.Function):
         require_gpu(x, *params)
         lib = _lib.load()
         x = f32c(x)
+        ctx.param_refs = params
         params = tuple(f32c(p) for p in params)
         n, t, dim_in = x.shape
         hidden = params[1].shape[1]
@@ -194,7 +196,7 @@ class _GruFn(torch.autograd.Function):
         dout = f32c(dout)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
-        grads = [torch.empty_like(p) for p in params]
+        grads = grad_buffers(ctx.param_refs)
         sc = scratch(lib.cpc_gru_scratch_bytes(n, t, dim_in, hidden, n_layers), x.device)
         check(lib.cpc_gru_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
                                    ptr_array(grads), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),

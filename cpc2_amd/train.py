@@ -67,8 +67,9 @@ class FlatAdam:
     torch.optim.Adam is kept through `state_dict()` / `load_state_dict()` (per-parameter
     exp_avg / exp_avg_sq / step)."""
 
-    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, direct_grads=True):
         self.params = [p for p in params]
+        self.direct_grads = direct_grads
         if not self.params:
             raise ValueError("FlatAdam got an empty parameter list")
         dev = self.params[0].device
@@ -86,18 +87,38 @@ class FlatAdam:
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
-            p.grad = self.flat_grad[off:off + n].view(p.shape)
+            if direct_grads:
+                # the fused backward kernels write each gradient straight into flat_grad and autograd adopts
+                # that view as .grad (no per-parameter add kernels); see _lib.grad_buffers
+                p._cpc_flat = (self.flat_grad, off)
+                p.grad = None
+            else:
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
             self.offsets.append(off)
             off += n
         self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "params": self.params}]
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
+        if self.direct_grads:
+            for p in self.params:
+                p.grad = None
+            return
         for p, off in zip(self.params, self.offsets):      # re-attach if someone replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
+    def _gather_stray_grads(self):
+        """direct mode: a gradient that autograd did NOT adopt from flat_grad (accumulated or produced by a
+        torch op) lives in its own tensor: copy it home before the fused update."""
+        base = self.flat_grad.data_ptr()
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is not None and p.grad.data_ptr() != base + 4 * off:
+                self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
+
     def step(self, grad_scale=1.0):
+        if self.direct_grads:
+            self._gather_stray_grads()
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         check(_lib.load().cpc_adam_step(ptr(self.flat), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),

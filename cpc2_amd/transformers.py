@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import check, f32c, ptr, ptr_array, require_gpu, scratch, stream_ptr
+from ._lib import check, f32c, grad_buffers, ptr, ptr_array, require_gpu, scratch, stream_ptr
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -70,6 +70,7 @@ class _TransformerFn(torch.autograd.Function):
         require_gpu(x, *[p for p in params if p is not None])
         lib = _lib.load()
         x = f32c(x)
+        ctx.param_refs = params
         params = tuple(f32c(p) for p in params)
         n, s, d_model = x.shape
         per = lib.cpc_transformer_param_count()
@@ -94,7 +95,7 @@ class _TransformerFn(torch.autograd.Function):
         n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed = ctx.cfg
         dout = f32c(dout)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        grads = [torch.empty_like(p) for p in params]
+        grads = grad_buffers(ctx.param_refs)
         sc = scratch(lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers), x.device)
         check(lib.cpc_transformer_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
                                            n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed, stream_ptr(x.device)),

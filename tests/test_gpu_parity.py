@@ -401,8 +401,9 @@ def test_fused_adam_vs_oracle():
     for step in range(5):
         grads = {k: torch.randn(v.shape, generator=g) for k, v in p0.items()}
         for p, gr in zip(prm, grads.values()):
-            p.grad.copy_(gr.to(DEV))
+            p.grad = gr.to(DEV)              # a gradient produced outside the fused kernels: gathered by step()
         opt.step()
+        opt.zero_grad()
         ref.step({k: v.double() for k, v in grads.items()})
     for p, r in zip(prm, ref.params.values()):
         assert_close(p.data, r, 1e-6, "adam params")
