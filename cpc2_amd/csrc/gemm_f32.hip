@@ -347,7 +347,7 @@ __global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, fl
 static int tn_splits(int M, int N, long R, long *chunk_out)
 {
     const long tiles = cdiv(M, BM) * cdiv(N, BN);
-    long S = cdiv(1024, tiles);
+    long S = 768 / tiles;                     // one full wave of 3 workgroups per CU (256 CUs)
     const long max_s = cdiv(R, 4 * BK);      // at least 128 rows per split
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
