@@ -157,10 +157,14 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; CPC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
+    # distributed code path on a one-GPU box (ranks then share the device)
+    backend = os.environ.get("CPC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
 
     from cpc2_amd import _lib
     from cpc2_amd.train import DataParallelContext, cpcStep
