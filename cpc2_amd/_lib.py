@@ -58,6 +58,10 @@ SIGNATURES = {
     "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_forward": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_backward": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
+    "cpc_flac_info": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                              ctypes.POINTER(c_long)]),
+    "cpc_flac_decode_f32": (c_int, [ctypes.c_char_p, c_ptr, c_long, ctypes.POINTER(c_int)]),
+    "cpc_window_gather": (c_int, [c_ptr, c_long, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "cpc_adam_step": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_long, c_int, c_float, c_float, c_float, c_float, c_float, c_ptr]),
 }
 

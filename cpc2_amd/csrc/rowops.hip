@@ -242,6 +242,19 @@ __global__ void channelnorm_cf_bwd_kernel(const float *x, const float *w, const 
     }
 }
 
+// ---------------------------------------------------------------- window gather (feeder)
+// out[i][0..L) = audio[offsets[i] .. offsets[i]+L): the training windows are contiguous slices of ONE flat,
+// HBM-resident audio buffer (dataset.py:308-321 slices the same way on the host)
+__global__ void window_gather_kernel(const float *audio, long total, const long *offsets, float *out, int b, int L)
+{
+    const int i = blockIdx.y;
+    const long off = offsets[i];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < L; k += gridDim.x * blockDim.x) {
+        const long src = off + k;
+        out[(long)i * L + k] = (src >= 0 && src < total) ? audio[src] : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- Adam
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n, float lr_c1, float rsqrt_c2,
                             float beta1, float beta2, float eps, float grad_scale)
@@ -317,6 +330,17 @@ extern "C" int cpc_channelnorm_backward(const float *x, const float *w, const fl
     hipLaunchKernelGGL(cpc::channelnorm_cf_bwd_kernel, dim3((unsigned)cpc::cdiv(cols, 256)), dim3(256), 0, st, x, w, dy,
                        rstd_save, dx, dw, db, N, C, L);
     CPC_CHECK_LAUNCH("channelnorm_cf_bwd_kernel");
+    return CPC_OK;
+}
+
+extern "C" int cpc_window_gather(const float *audio, long total_samples, const long *offsets, float *out, int batch, int window,
+                                 cpc_stream_t stream)
+{
+    CPC_REQUIRE(audio != nullptr && offsets != nullptr && out != nullptr && batch > 0 && window > 0 && total_samples > 0,
+                "window_gather: bad arguments (batch=%d window=%d)", batch, window);
+    hipLaunchKernelGGL(cpc::window_gather_kernel, dim3((unsigned)std::min<long>(cpc::cdiv(window, 256), 64), (unsigned)batch), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), audio, total_samples, offsets, out, batch, window);
+    CPC_CHECK_LAUNCH("window_gather_kernel");
     return CPC_OK;
 }
 

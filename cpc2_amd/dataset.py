@@ -1,0 +1,277 @@
+"""Window feeder: the step in front of the hot path.
+
+Same names and behaviour as the reference's cpc/dataset.py for the parts the training loop uses --
+findAllSeqs (:771-948, format=None branch), filterSeqs (:963-978), AudioBatchData (:23-408: sequences sorted by
+(speaker, name) and concatenated into ONE flat audio vector, speaker / sequence interval tables, chunked
+"packs" of at most MAX_SIZE_LOADED samples, getDataLoader with the uniform / sequential / samespeaker /
+samesequence / temporalsamespeaker samplers :603-757 and the random window offset :395-403) -- but MI355X-first:
+the flat vector lives in HBM (288 GB: the reference's 4e9-sample pack is 16 GB) and a batch is cut out of it
+by one gather kernel (cpc_window_gather); the host only produces b int64 offsets per step.  Files are decoded
+by the library's own FLAC / WAV readers (cpc2_amd/audio.py).
+
+Not on this path: data augmentation (sox / WavAugment), phone labels, signal-quality side files.
+Without augmentation the reference yields past == future (dataset.py:308-321): batches are returned as an
+expanded [b, 2, 1, W] view whose two halves alias, which cpcStep(dedup=True) can exploit.
+"""
+import os
+import random
+from pathlib import Path
+
+import torch
+
+from . import _lib, audio
+from ._lib import check, ptr, stream_ptr
+
+
+def findAllSeqs(dirName, extension='.flac', speaker_level=1, **unused):
+    """(outSequences [(speaker_index, relative_path)], outSpeakers) -- dataset.py:771-948 with format=None."""
+    dirName = str(dirName)
+    if dirName[-1] != os.sep:
+        dirName += os.sep
+    prefixSize = len(dirName)
+    speakersTarget, outSequences = {}, []
+    for root, _dirs, filenames in os.walk(dirName, followlinks=True):
+        filtered_files = [f for f in filenames if f.endswith(extension)]
+        if filtered_files:
+            speakerStr = os.sep.join(root[prefixSize:].split(os.sep)[:speaker_level])
+            speaker = speakersTarget.setdefault(speakerStr, len(speakersTarget))
+            for filename in filtered_files:
+                outSequences.append((speaker, os.path.join(root[prefixSize:], filename)))
+    outSpeakers = [None] * len(speakersTarget)
+    for key, index in speakersTarget.items():
+        outSpeakers[index] = key
+    return outSequences, outSpeakers
+
+
+def filterSeqs(pathTxt, seqCouples):
+    """keep the sequences whose base name is listed in pathTxt -- dataset.py:963-978."""
+    with open(pathTxt, 'r') as f:
+        wanted = {p.strip() for p in f.readlines() if p.strip()}
+    seqCouples = sorted(seqCouples, key=lambda x: os.path.basename(os.path.splitext(x[1])[0]))
+    return [x for x in seqCouples if os.path.basename(os.path.splitext(x[1])[0]) in wanted]
+
+
+# --------------------------------------------------------------------------- samplers (dataset.py:603-757)
+def _uniform_batches(dataSize, sizeWindow, offset, batchSize):
+    n = dataSize // sizeWindow - (1 if offset > 0 else 0)
+    idx = (offset + sizeWindow * torch.randperm(max(n, 0))).tolist()
+    return [idx[i:i + batchSize] for i in range(0, len(idx) - batchSize + 1, batchSize)]      # drop_last=True
+
+
+def _sequential_batches(dataSize, sizeWindow, offset, batchSize):
+    n = (dataSize // sizeWindow) // batchSize - (1 if offset > 0 else 0)
+    starts = [x * (dataSize // batchSize) for x in range(batchSize)]
+    return [[offset + sizeWindow * i + s for s in starts] for i in range(max(n, 0))]
+
+
+def _same_interval_batches(intervals, sizeWindow, offset, batchSize):
+    """SameSpeakerSampler: every batch comes from one interval (speaker or sequence)."""
+    if intervals[0] != 0:
+        raise AttributeError("Sampling intervals should start at zero")
+    sizes = [(intervals[i + 1] - intervals[i]) // sizeWindow for i in range(len(intervals) - 1)]
+    if offset > 0:
+        sizes = [max(0, x - 1) for x in sizes]
+    batches = []
+    for i, val in enumerate(sizes):
+        if val <= 0:
+            continue
+        perm = torch.randperm(val).tolist()
+        for s in range(0, val, batchSize):
+            batches.append([offset + x * sizeWindow + intervals[i] for x in perm[s:s + batchSize]])
+    random.shuffle(batches)
+    return batches
+
+
+def _temporal_same_interval_batches(intervals, sizeWindow, offset, batchSize):
+    """TemporalSameSpeakerSampler: a batch is batchSize CONSECUTIVE windows of one interval."""
+    if intervals[0] != 0:
+        raise AttributeError("Sampling intervals should start at zero")
+    sizes = [(intervals[i + 1] - intervals[i]) // (sizeWindow * batchSize) for i in range(len(intervals) - 1)]
+    if offset > 0:
+        sizes = [max(0, x - 1) for x in sizes]
+    if sum(sizes) == 0:
+        raise ValueError("No sampling intervals can be found. Try to increase --max_size_loaded or to reduce the batch size.")
+    batches = []
+    for i, val in enumerate(sizes):
+        for x in torch.randperm(val).tolist():
+            beg = offset + x * sizeWindow * batchSize + intervals[i]
+            batches.append(list(range(beg, beg + sizeWindow * batchSize, sizeWindow)))
+    random.shuffle(batches)
+    return batches
+
+
+class AudioBatchData:
+    """dataset.py:23-408 (see the module docstring for what is and is not carried over)."""
+
+    def __init__(self, path, sizeWindow, seqNames, phoneLabelsDict, nSpeakers, nProcessLoader=10,
+                 MAX_SIZE_LOADED=4000000000, transform=None, augment_past=False, augment_future=False,
+                 augmentation=None, keep_temporality=True, past_equal_future=False, signal_quality_path=None,
+                 signal_quality_step=1600, signal_quality_mode=None, device=None):
+        if phoneLabelsDict is not None or signal_quality_path is not None:
+            raise NotImplementedError("phone labels / signal-quality files are not on the MI355X feeder path")
+        if transform is not None or augment_past or augment_future or augmentation is not None:
+            raise NotImplementedError("audio augmentation is not on the MI355X feeder path")
+        self.MAX_SIZE_LOADED = MAX_SIZE_LOADED
+        self.dbPath = Path(path)
+        self.sizeWindow = sizeWindow
+        self.seqNames = [(s, self.dbPath / x) for s, x in seqNames]
+        self.keep_temporality = keep_temporality
+        self.speakers = list(range(nSpeakers))
+        self.device = torch.device(device) if device is not None else \
+            torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.doubleLabels = False
+        self.phoneSize = 0
+        self.prepare()
+        self.loadNextPack(first=True)
+        self.loadNextPack()
+
+    # ---- pack bookkeeping (dataset.py:147-223)
+    def prepare(self):
+        if self.keep_temporality:
+            blocks, cur = [], None
+            for seq_id, seq_path in self.seqNames:
+                if cur != seq_id:
+                    blocks.append([])
+                    cur = seq_id
+                blocks[-1].append((seq_id, seq_path))
+            random.shuffle(blocks)
+            self.seqNames = [item for sub in blocks for item in sub]
+        else:
+            random.shuffle(self.seqNames)
+        lengths = [audio.info(p)[2] for _, p in self.seqNames]
+        self.packageIndex, self.totSize = [], 0
+        start, packageSize = 0, 0
+        for index, length in enumerate(lengths):
+            packageSize += length
+            if packageSize > self.MAX_SIZE_LOADED:
+                self.packageIndex.append([start, index])
+                self.totSize += packageSize
+                start, packageSize = index, 0
+        if packageSize > 0:
+            self.packageIndex.append([start, len(self.seqNames)])
+            self.totSize += packageSize
+        self.currentPack = -1
+        self.nextPack = 0
+
+    def getNPacks(self):
+        return len(self.packageIndex)
+
+    def _load_pack(self, pack):
+        start, end = self.packageIndex[pack]
+        items = []
+        for speaker, p in self.seqNames[start:end]:
+            wav = audio.load(p)[0].mean(dim=0)              # dataset.py:425: mono mix
+            items.append((speaker, os.path.splitext(os.path.basename(str(p)))[0], wav))
+        return items
+
+    def loadNextPack(self, first=False):
+        if not first:
+            self.currentPack = self.nextPack
+            self.parseNextDataBlock(self.nextData)
+            del self.nextData
+        self.nextPack = (self.currentPack + 1) % len(self.packageIndex)
+        if self.nextPack == 0 and len(self.packageIndex) > 1:
+            self.prepare()
+        self.nextData = self._load_pack(self.nextPack)
+
+    def parseNextDataBlock(self, nextData):
+        """dataset.py:225-268: sort by (speaker, name), concatenate, build the interval tables."""
+        self.speakerLabel, self.seqLabel = [0], [0]
+        speakerSize, indexSpeaker = 0, 0
+        nextData.sort(key=lambda x: (x[0], x[1]))
+        chunks = []
+        for speaker, _name, seq in nextData:
+            while self.speakers[indexSpeaker] < speaker:
+                indexSpeaker += 1
+                self.speakerLabel.append(speakerSize)
+            if self.speakers[indexSpeaker] != speaker:
+                raise ValueError(f'{speaker} invalid speaker')
+            chunks.append(seq)
+            self.seqLabel.append(self.seqLabel[-1] + seq.size(0))
+            speakerSize += seq.size(0)
+        self.speakerLabel.append(speakerSize)
+        self.data = torch.cat(chunks, dim=0).to(self.device)     # ONE flat vector, resident on the device
+
+    # ---- accessors
+    def getSpeakerLabel(self, idx):
+        return next(i for i, v in enumerate(self.speakerLabel) if v > idx) - 1
+
+    def __len__(self):
+        return self.totSize // self.sizeWindow
+
+    def getNSpeakers(self):
+        return len(self.speakers)
+
+    def getNSeqs(self):
+        return len(self.seqLabel) - 1
+
+    def getNLoadsPerEpoch(self):
+        return len(self.packageIndex)
+
+    def windows(self, offsets):
+        """[b, 2, 1, sizeWindow] batch (past and future alias: no augmentation) for int window offsets."""
+        b = len(offsets)
+        off = torch.tensor(offsets, dtype=torch.int64)
+        if self.data.is_cuda:
+            off = off.to(self.device)
+            out = torch.empty(b, 1, self.sizeWindow, dtype=torch.float32, device=self.device)
+            check(_lib.load().cpc_window_gather(ptr(self.data), self.data.numel(), ptr(off), ptr(out), b, self.sizeWindow,
+                                                stream_ptr(self.device)), "window_gather")
+        else:
+            out = torch.stack([self.data[o:o + self.sizeWindow] for o in offsets]).view(b, 1, self.sizeWindow)
+        return out.unsqueeze(1).expand(b, 2, 1, self.sizeWindow)
+
+    def getBaseSampler(self, type, batchSize, offset, batchSizePerGPU=None):
+        n = self.data.numel()
+        if type == "samespeaker":
+            return _same_interval_batches(self.speakerLabel, self.sizeWindow, offset, batchSize)
+        if type == "samesequence":
+            return _same_interval_batches(self.seqLabel, self.sizeWindow, offset, batchSize)
+        if type == "temporalsamespeaker":
+            return _temporal_same_interval_batches(self.speakerLabel, self.sizeWindow, offset, batchSize)
+        if type == "sequential":
+            return _sequential_batches(n, self.sizeWindow, offset, batchSize)
+        if type == "uniform":
+            return _uniform_batches(n, self.sizeWindow, offset, batchSize)
+        raise ValueError("--samplingType should belong to %s" % ["samespeaker", "samesequence", "temporalsamespeaker",
+                                                                "sequential", "uniform"])
+
+    def getDataLoader(self, batchSize, type, randomOffset, numWorkers=0, onLoop=-1, nLoops=-1, **unused):
+        """Iterable of (sequence [b,2,1,W] on the device, speaker label [b]) over nLoops packs -- dataset.py:366-408."""
+        if onLoop >= 0:
+            self.currentPack = onLoop - 1
+            self.loadNextPack()
+            nLoops = 1 if nLoops <= 0 else nLoops
+        elif nLoops <= 0:
+            nLoops = len(self.packageIndex)
+        return _AudioLoader(self, batchSize, type, randomOffset, nLoops)
+
+
+class _AudioLoader:
+    def __init__(self, dataset, batchSize, type, randomOffset, nLoops):
+        self.dataset, self.batchSize, self.type, self.randomOffset, self.nLoops = dataset, batchSize, type, randomOffset, nLoops
+
+    def _sampler(self):
+        d = self.dataset
+        if self.randomOffset:                                # dataset.py:395-403
+            offset = random.randint(0, d.sizeWindow * self.batchSize) if self.type == "temporalsamespeaker" \
+                else random.randint(0, d.sizeWindow // 2)
+        else:
+            offset = 0
+        return d.getBaseSampler(self.type, self.batchSize, offset)
+
+    def __len__(self):
+        return self.dataset.totSize // (self.dataset.sizeWindow * self.batchSize)
+
+    def __iter__(self):
+        d = self.dataset
+        for loop in range(self.nLoops):
+            limit = d.data.numel() - d.sizeWindow
+            for batch in self._sampler():
+                batch = [o for o in batch if 0 <= o <= limit]
+                if not batch:
+                    continue
+                label = torch.tensor([d.getSpeakerLabel(o) for o in batch], dtype=torch.long, device=d.device)
+                yield d.windows(batch), label
+            if loop + 1 < self.nLoops or len(d.packageIndex) > 1:
+                d.loadNextPack()

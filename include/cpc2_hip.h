@@ -198,6 +198,22 @@ int cpc_infonce_backward(const float *c, const float *z, const float *wpred, con
                          int dim_enc, int n_neg, cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Native FLAC reader for the window feeder (replaces torchaudio.load at cpc/dataset.py:411-437 and
+ * cpc/feature_loader.py:343; the image ships no audio library).  HOST side.  Output is float32
+ * [channels][total_samples] scaled to [-1, 1) like torchaudio.load; every decode is checked against
+ * the MD5 of the unencoded audio stored in STREAMINFO (md5_ok, and an error if it differs).
+ * ------------------------------------------------------------------------------------------ */
+int cpc_flac_info(const char *path, int *sample_rate, int *channels, int *bits_per_sample,
+                  long *total_samples);
+int cpc_flac_decode_f32(const char *path, float *out_host, long capacity_floats, int *md5_ok);
+
+/* Window feeder (cpc/dataset.py:308-321 __getitem__ slicing): out[i][0..window) =
+ * audio[offsets[i] .. offsets[i]+window) from one flat device-resident audio buffer (zeros outside it).
+ * audio, offsets (int64) and out are DEVICE pointers. */
+int cpc_window_gather(const float *audio, long total_samples, const long *offsets, float *out, int batch,
+                      int window, cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Adam on one flat fp32 buffer (torch.optim.Adam as built at train.py:477-479: no weight decay,
  * no amsgrad).  g is multiplied by grad_scale first (1/world_size after an all-reduce SUM).
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;

@@ -1,0 +1,102 @@
+"""Window feeder on CPU: the reference's own data-loader expectations (cpc/unit_tests.py:15-170, TestDataLoader)
+on the reference's own fixture (cpc/test_data: 9 LibriSpeech FLACs, copied under tests/golden/test_db), plus the
+native FLAC decoder (every file is verified against the MD5 stored in its STREAMINFO)."""
+import os
+from pathlib import Path
+
+import torch
+
+from cpc2_amd import audio
+from cpc2_amd.dataset import AudioBatchData, filterSeqs, findAllSeqs
+
+GOLD = Path(__file__).parent / "golden"
+DB = GOLD / "test_db"
+SEQ_LIST = GOLD / "seq_list.txt"
+EXPECTED = [(0, '2911/12359/2911-12359-0007.flac'), (1, '4051/11218/4051-11218-0044.flac'),
+            (2, '4397/15668/4397-15668-0003.flac'), (2, '4397/15668/4397-15668-0007.flac'),
+            (3, '5393/19218/5393-19218-0024.flac'), (4, '5678/43301/5678-43301-0021.flac'),
+            (4, '5678/43303/5678-43303-0024.flac'), (4, '5678/43303/5678-43303-0032.flac'),
+            (5, '6476/57446/6476-57446-0019.flac')]
+
+
+def test_flac_decoder_md5_and_lengths():
+    total = 0
+    for _spk, rel in EXPECTED:
+        wav, sr = audio.load(DB / rel)                 # raises if the MD5 of the decoded PCM differs
+        assert sr == 16000 and wav.shape[0] == 1 and wav.dtype == torch.float32
+        assert audio.info(DB / rel) == (16000, 1, wav.shape[1])
+        assert float(wav.abs().max()) < 1.0 and float(wav.std()) > 0.01
+        total += wav.shape[1]
+    assert total == 1864080                             # 116.505 s of 16 kHz audio = 91 windows of 20480
+
+
+def test_find_all_seqs():                               # unit_tests.py:32-66
+    seq_names, speakers = findAllSeqs(str(DB), extension=".flac")
+    assert len(speakers) == 6 and set(speakers) == {'2911', '4051', '4397', '5393', '5678', '6476'}
+    assert {x[0] for x in seq_names} == {x[0] for x in EXPECTED}
+    assert {x[1] for x in seq_names} == {x[1] for x in EXPECTED}
+    for index_speaker, seq_name in seq_names:
+        assert speakers[index_speaker] == str(Path(seq_name).stem).split('-')[0]
+
+
+def test_find_all_seqs_speaker_levels():                # unit_tests.py:68-105
+    seq_names, speakers = findAllSeqs(str(DB), extension=".flac", speaker_level=2)
+    assert set(speakers) == {'2911/12359', '4051/11218', '4397/15668', '5393/19218', '5678/43301', '5678/43303', '6476/57446'}
+    for index_speaker, seq_name in seq_names:
+        assert speakers[index_speaker] == '/'.join(str(Path(seq_name).stem).split('-')[:2])
+    assert findAllSeqs(str(DB / '2911/12359/'), extension=".flac")[1] == ['']
+    assert findAllSeqs(str(DB), extension=".flac", speaker_level=0)[1] == ['']
+
+
+def _filtered():
+    seq_names, speakers = findAllSeqs(str(DB), extension=".flac")
+    return filterSeqs(SEQ_LIST, seq_names), speakers
+
+
+def test_load_data():                                   # unit_tests.py:107-129
+    seq_names, _ = _filtered()
+    assert {x[1] for x in seq_names} == {x[1] for x in EXPECTED[2:]} and len(seq_names) == 7
+    data = AudioBatchData(DB, 20480, seq_names, None, 9, device="cpu")
+    assert data.getNSpeakers() == 9 and data.getNSeqs() == 7
+    assert data.data.numel() == sum(audio.info(DB / x[1])[2] for x in seq_names)
+
+
+def test_data_loader_samespeaker():                     # unit_tests.py:131-149
+    seq_names, speakers = _filtered()
+    data = AudioBatchData(DB, 20480, seq_names, None, len(speakers), device="cpu")
+    visited = set()
+    for seq, labels in data.getDataLoader(2, "samespeaker", True, numWorkers=2):
+        assert seq.shape[1:] == (2, 1, 20480) and seq.shape[0] == labels.shape[0]
+        assert torch.equal(seq[:, 0], seq[:, 1])        # no augmentation: past == future
+        p = labels[0].item()
+        visited.add(p)
+        assert int(torch.sum(labels == p)) == labels.size(0)
+    assert len(visited) == 4
+
+
+def test_partial_loader_two_packs():                    # unit_tests.py:151-170
+    seq_names, speakers = _filtered()
+    data = AudioBatchData(DB, 20480, seq_names, None, len(speakers), MAX_SIZE_LOADED=1000000, device="cpu")
+    assert data.getNPacks() == 2
+    visited = set()
+    for _seq, labels in data.getDataLoader(16, "samespeaker", True, numWorkers=2):
+        p = labels[0].item()
+        assert int(torch.sum(labels == p)) == labels.size(0)
+        visited.add(p)
+    assert len(visited) == 4
+
+
+def test_other_samplers_yield_valid_windows():
+    seq_names, speakers = _filtered()
+    data = AudioBatchData(DB, 20480, seq_names, None, len(speakers), device="cpu")
+    flat = data.data
+    for kind in ("uniform", "sequential", "samesequence", "temporalsamespeaker"):
+        n = 0
+        for seq, labels in data.getDataLoader(4, kind, False):
+            assert seq.shape[1:] == (2, 1, 20480) and labels.shape[0] == seq.shape[0] <= 4
+            assert kind == "samesequence" or seq.shape[0] == 4      # only interval samplers emit short last batches
+            n += 1
+        assert n >= 1, kind
+    # a window is a verbatim slice of the flat vector
+    w = data.windows([12345])
+    assert torch.equal(w[0, 0, 0], flat[12345:12345 + 20480])

@@ -468,3 +468,133 @@ def test_train_steps_reproduce_reference_loss_curve(golden):
     d_got, d_ref = (got - init).flatten().double(), (ref_w - init).flatten().double()
     cos = float(d_got @ d_ref / (d_got.norm() * d_ref.norm()))
     assert cos >= 0.98, f"update direction cos {cos:.4f}"
+
+
+# ----------------------------------------------------------------------------- feeder / features / checkpoints
+GOLD_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_db")
+SEQ_LIST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq_list.txt")
+
+
+def _feeder(device, **kw):
+    from cpc2_amd.dataset import AudioBatchData, filterSeqs, findAllSeqs
+    seq_names, speakers = findAllSeqs(GOLD_DB, extension=".flac")
+    seq_names = filterSeqs(SEQ_LIST, seq_names)
+    return AudioBatchData(GOLD_DB, 20480, seq_names, None, len(speakers), device=device, **kw)
+
+
+def test_feeder_windows_on_device_match_host_slices():
+    import random
+    random.seed(0)
+    dev_data = _feeder(DEV)
+    random.seed(0)
+    cpu_data = _feeder("cpu")
+    assert torch.equal(dev_data.data.cpu(), cpu_data.data)
+    offs = [0, 1, 20479, 123457, cpu_data.data.numel() - 20480]
+    assert torch.equal(dev_data.windows(offs).cpu(), cpu_data.windows(offs))
+    torch.manual_seed(3)
+    random.seed(3)
+    batches = list(dev_data.getDataLoader(8, "uniform", True))
+    assert len(batches) >= 5 and all(s.is_cuda and s.shape == (8, 2, 1, 20480) for s, _ in batches)
+
+
+def _small_model(hidden=64):
+    mp = synth.encoder_params(hidden, 21)
+    mp.update(synth.gru_params(hidden, hidden, 1, 22))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+    model.load_state_dict(mp)
+    return model.to(DEV), mp
+
+
+def test_build_feature_on_real_audio_vs_oracle():
+    from cpc2_amd import audio
+    from cpc2_amd.feature_loader import FeatureModule, buildFeature
+    model, mp = _small_model()
+    path = os.path.join(GOLD_DB, "4397", "15668", "4397-15668-0003.flac")
+    wav = audio.load(path)[0]
+    p64 = to64(mp)
+    for get_encoded in (False, True):
+        fm = FeatureModule(model, get_encoded).eval()
+        feats = buildFeature(fm, path, maxSizeSeq=64000)
+        ref = []
+        for start in range(0, wav.shape[1], 64000):
+            c, z = O.model_forward(wav[:, start:start + 64000].double().view(1, 1, -1), p64)
+            ref.append(z if get_encoded else c)
+        ref = torch.cat(ref, dim=1)
+        assert feats.shape == ref.shape == (1, 400 + 400 + 359, 64)
+        assert_close(feats, ref, 5e-5, f"features get_encoded={get_encoded}")
+    strict = buildFeature(FeatureModule(model, False).eval(), path, strict=True, maxSizeSeq=64000)
+    assert strict.shape[1] == wav.shape[1] // 160 - 1 or strict.shape[1] == wav.shape[1] // 160
+
+
+def test_checkpoint_roundtrip_in_reference_layout(tmp_path):
+    from cpc2_amd.feature_loader import getCheckpointData, loadModel, save_checkpoint
+    import json
+    model, _ = _small_model()
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, 64, 64, 16, rnnMode="linear", sizeInputSeq=128).to(DEV)
+    opt = buildOptimizer(model, crit)
+    x = synth.audio_windows(2, 20480, 24).to(DEV)
+    crit.seed(1)
+    tot, _, _ = cpcStep(x, x, torch.zeros(2, dtype=torch.long, device=DEV), model, crit)
+    tot.backward()
+    opt.step()
+    opt.zero_grad()
+    args = dict(hiddenEncoder=64, hiddenGar=64, normMode="layerNorm", arMode="GRU", samplingType="samespeaker",
+                nLevelsGRU=1, cpc_mode=None, sizeWindow=20480, abspos=False, encoder_type="cpc")
+    (tmp_path / "checkpoint_args.json").write_text(json.dumps(args))
+    (tmp_path / "checkpoint_logs.json").write_text(json.dumps({"epoch": [0]}))
+    path = str(tmp_path / "checkpoint_0.pt")
+    save_checkpoint(model.state_dict(), crit.state_dict(), opt.state_dict(), model.state_dict(), path)
+    blob = torch.load(path, "cpu")
+    assert set(blob) == {"gEncoder", "cpcCriterion", "optimizer", "best"}
+    assert "gEncoder.conv0.weight" in blob["gEncoder"] and "wPrediction.predictors.11.weight" in blob["cpcCriterion"]
+    assert set(blob["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    found, logs, loc_args = getCheckpointData(str(tmp_path))
+    assert os.path.basename(found) == "checkpoint_0.pt" and loc_args.hiddenGar == 64
+    model2, hg, he = loadModel([path])
+    model2 = model2.to(DEV)
+    assert (hg, he) == (64, 64)
+    c1, z1, _ = model(x, None)
+    c2, z2, _ = model2(x, None)
+    assert_close(c2, c1, 1e-5, "c after reload")       # (split-K GEMMs add partial sums atomically: not bit-equal)
+    assert_close(z2, z1, 1e-5, "z after reload")
+    crit2 = cpc2_amd.CPCUnsupersivedCriterion(12, 64, 64, 16, rnnMode="linear", sizeInputSeq=128)
+    crit2.load_state_dict(blob["cpcCriterion"])
+    opt2 = buildOptimizer(model2, crit2.to(DEV))
+    opt2.load_state_dict(blob["optimizer"])
+    assert opt2.step_count == 1 and torch.equal(opt2.exp_avg, opt.exp_avg)
+
+
+def test_training_steps_on_reference_test_data_vs_oracle():
+    """BASELINE config C1 in miniature: real LibriSpeech windows from the reference's cpc/test_data fixture,
+    sequential sampler (deterministic), 3 Adam steps; HIP loss curve vs the CPU oracle's."""
+    import random
+    hidden, b, k, nn, steps = 64, 4, 12, 32, 3
+    model, mp = _small_model(hidden)
+    cp = synth.predictor_params(k, hidden, hidden, 23)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, hidden, hidden, nn, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(cp)
+    crit = crit.to(DEV)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    random.seed(0)
+    data = _feeder(DEV)
+    loader = iter(data.getDataLoader(b, "sequential", False))
+    batches = [next(loader) for _ in range(steps)]
+    crit.seed(99)
+    curve = []
+    for seq, label in batches:
+        tot, losses, _ = cpcStep(seq[:, 0], seq[:, 1], label, model, crit, dedup=True)
+        tot.backward()
+        opt.step()
+        opt.zero_grad()
+        curve.append(losses.detach().cpu())
+    # oracle on the same windows
+    params = {n: v.clone().requires_grad_(True) for n, v in list(cp.items()) + list(mp.items())}
+    adam = O.Adam({n: v.data for n, v in params.items()}, lr=2e-4)
+    mt = MT19937(99)
+    for step, (seq, _label) in enumerate(batches):
+        xw = seq[:, 0].cpu()
+        tot, losses, _ = O.train_step_loss(xw, xw, {n: params[n] for n in mp}, {n: params[n] for n in cp}, mt, k, nn)
+        grads = torch.autograd.grad(tot, list(params.values()))
+        adam.step(dict(zip(params, grads)))
+        err = float(((curve[step] - losses.detach()).abs() / losses.detach().abs()).max())
+        assert err <= 1e-3, f"step {step}: loss differs by {err:.2e}"
