@@ -32,6 +32,8 @@ CONFIGS = {
     "small": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU"),
     "large": dict(hidden=512, layers=2, npred=12, nneg=256, ar="GRU"),
     "transformer": dict(hidden=256, layers=1, npred=12, nneg=128, ar="transformer"),    # BASELINE configs[3]
+    # the fork's default predictor (rnnMode='transformer', criterion.py:136-143) on the GRU model
+    "transformer_pred": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", rnn="transformer"),
 }
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
@@ -61,8 +63,12 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
             launches += 2
         din = h
     w = t_len - cfg["npred"]
-    flops += 2 * (2.0 * b * w * cfg["npred"] * h * h)   # P and dC
-    launches += 2
+    if cfg.get("rnn") == "transformer":                 # K one-layer transformer predictors on [b, W, H]
+        flops += cfg["npred"] * 2 * (2.0 * b * w * (5 * h * h + 2 * h * 2048))
+        launches += cfg["npred"] * 12
+    else:
+        flops += 2 * (2.0 * b * w * cfg["npred"] * h * h)   # P and dC
+        launches += 2
     return flops, launches
 
 
@@ -78,7 +84,7 @@ def build(cfg, device):
         ar = cpc2_amd.CPCAR(cfg["hidden"], cfg["hidden"], False, cfg["layers"], mode=cfg["ar"])
     model = cpc2_amd.CPCModel(enc, ar).to(device)
     crit = cpc2_amd.CPCUnsupersivedCriterion(cfg["npred"], cfg["hidden"], cfg["hidden"], cfg["nneg"],
-                                             rnnMode="linear", sizeInputSeq=WINDOW // 160).to(device)
+                                             rnnMode=cfg.get("rnn", "linear"), sizeInputSeq=WINDOW // 160).to(device)
     opt = buildOptimizer(model, crit, lr=2e-4)
     return model, crit, opt
 

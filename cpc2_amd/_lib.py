@@ -58,6 +58,8 @@ SIGNATURES = {
     "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_forward": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_backward": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
+    "cpc_infonce_forward_pred": (c_int, [c_ptr] * 8 + [c_int] * 5 + [c_ptr]),
+    "cpc_infonce_backward_pred": (c_int, [c_ptr] * 9 + [c_int] * 5 + [c_ptr]),
     "cpc_flac_info": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                               ctypes.POINTER(c_long)]),
     "cpc_flac_decode_f32": (c_int, [ctypes.c_char_p, c_ptr, c_long, ctypes.POINTER(c_int)]),

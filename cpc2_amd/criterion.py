@@ -202,23 +202,79 @@ class _InfoNCEFn(torch.autograd.Function):
         return (dc, dz, None, None, None) + tuple(gw)
 
 
+class _InfoNCEPredFn(torch.autograd.Function):
+    """Same criterion, predictions supplied by predictor modules: inputs z, ext_idx, weights, n_neg, then the K
+    prediction tensors [b, W, dim_enc]."""
+
+    @staticmethod
+    def forward(ctx, z, ext_idx, weights, n_neg, *preds):
+        require_gpu(z, ext_idx, *preds)
+        lib = _lib.load()
+        z = f32c(z)
+        preds = tuple(f32c(p) for p in preds)
+        b, t, dim_enc = z.shape
+        k = len(preds)
+        if any(p.shape != (b, t - k, dim_enc) for p in preds):
+            raise ValueError(f"predictions must be [b, W, dim_enc] = {(b, t - k, dim_enc)}")
+        if ext_idx.dtype != torch.int32 or ext_idx.numel() != b * n_neg * (t - k):
+            raise ValueError("ext_idx must be int32 [b, W, n_neg]")
+        w = f32c(weights) if weights is not None else None
+        nsaved = lib.cpc_infonce_saved_bytes(b, t, k, dim_enc, dim_enc, n_neg)
+        nscratch = lib.cpc_infonce_scratch_bytes(b, t, k, dim_enc, dim_enc, n_neg)
+        if nsaved == 0:
+            check(-1, "infonce shape query")
+        losses = torch.empty(k, dtype=torch.float32, device=z.device)
+        acc = torch.empty(k, dtype=torch.float32, device=z.device)
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=z.device)
+        sc = scratch(nscratch, z.device)
+        check(lib.cpc_infonce_forward_pred(_lib.ptr_array(preds), ptr(z), ptr(ext_idx), ptr(w), ptr(losses), ptr(acc),
+                                           ptr(saved), ptr(sc), b, t, k, dim_enc, n_neg, stream_ptr(z.device)),
+              "infonce_forward_pred")
+        ctx.save_for_backward(z, ext_idx, w, saved, *preds)
+        ctx.dims = (b, t, k, dim_enc, n_neg)
+        ctx.mark_non_differentiable(acc)
+        return losses, acc
+
+    @staticmethod
+    def backward(ctx, dlosses, _dacc):
+        lib = _lib.load()
+        z, ext_idx, w, saved, *preds = ctx.saved_tensors
+        b, t, k, dim_enc, n_neg = ctx.dims
+        dlosses = f32c(dlosses)
+        dz = torch.empty_like(z)
+        dpreds = [torch.empty_like(p) for p in preds]
+        sc = scratch(lib.cpc_infonce_scratch_bytes(b, t, k, dim_enc, dim_enc, n_neg), z.device)
+        check(lib.cpc_infonce_backward_pred(_lib.ptr_array(preds), ptr(z), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                            ptr(sc), _lib.ptr_array(dpreds), ptr(dz), b, t, k, dim_enc, n_neg,
+                                            stream_ptr(z.device)), "infonce_backward_pred")
+        return (dz, None, None, None) + tuple(dpreds)
+
+
 # --------------------------------------------------------------------------- modules
 class PredictionNetwork(nn.Module):
-    """criterion.py:97-173, linear predictors (the `else` branch :144-150).  Holds the K
-    nn.Linear(dimOutputAR, dimOutputEncoder, bias=False) under `predictors` (same keys/init)."""
+    """criterion.py:97-173: K predictors under `predictors` (same keys / init as the reference):
+    linear (the `else` branch :144-150, nn.Linear(dimOutputAR, dimOutputEncoder, bias=False)) or one-layer
+    transformers (rnnMode='transformer' :136-143, the fork's default; keys `predictors.{k}.0.*`)."""
 
     def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=None, dropout=False,
                  sizeInputSeq=116, transformer_pruning=0):
         super(PredictionNetwork, self).__init__()
-        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12", "transformer"):
+        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12"):
             raise NotImplementedError(
-                f"rnnMode={rnnMode!r}: only linear predictors (rnnMode='linear') have an MI355X kernel path")
+                f"rnnMode={rnnMode!r}: only 'linear' and 'transformer' predictors have an MI355X kernel path")
         if dropout:
             raise NotImplementedError("predictor dropout is not supported by the MI355X hot path")
         self.predictors = nn.ModuleList()
         self.RESIDUAL_STD = 0.01
         self.dimOutputAR = dimOutputAR
         self.dropout = None
+        self.rnnMode = rnnMode
+        if rnnMode == 'transformer':
+            from .transformers import buildTransformerAR
+            for _ in range(nPredicts):
+                self.predictors.append(buildTransformerAR(dimOutputEncoder, dimOutputAR, nLayers=1,
+                                                          sizeSeq=sizeInputSeq, abspos=False))
+            return
         for _ in range(nPredicts):
             self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
             if dimOutputEncoder > dimOutputAR:
@@ -309,7 +365,12 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         else:
             quality_weighting = None                    # ones (criterion.py:340)
         extIdx = self.sampleIndices(batchSize, seqSize, windowSize, cFeature.device)
-        losses, acc = _InfoNCEFn.apply(cFeature, encodedData, extIdx, quality_weighting, self.negativeSamplingExt,
-                                       *[p.weight for p in self.wPrediction.predictors])
+        if self.wPrediction.rnnMode == 'transformer':
+            cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
+            preds = [predictor(cW) for predictor in self.wPrediction.predictors]
+            losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
+        else:
+            losses, acc = _InfoNCEFn.apply(cFeature, encodedData, extIdx, quality_weighting, self.negativeSamplingExt,
+                                           *[p.weight for p in self.wPrediction.predictors])
         losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
         return losses.view(1, -1), acc.view(1, -1)

@@ -24,7 +24,13 @@ constexpr int NCE_ROWS = 16;   // MFMA M: predictions padded to 16 rows
 constexpr int NCE_POS = 16;    // positive-tile columns
 
 struct NceArgs {
-    const float *P;        // [b*T][K*H]  predictions
+    // predictions of step k for (bb, t): Pk[k] + (bb*p_rows + t)*p_stride  (H floats).
+    //   linear predictors : Pk[k] = P + k*H, p_stride = K*H, p_rows = T   (one GEMM output [b*T][K*H])
+    //   module predictors : Pk[k] = output of predictor k [b][W][H], p_stride = H, p_rows = W
+    const float *Pk[16];
+    float *dPk[16];        // same addressing, gradients
+    long p_stride;
+    int p_rows;
     const float *z;        // [b*T][H]
     const int32_t *ext;    // [b][W][Nneg]  TIME-MAJOR index layout (the negatives of one (b,t) are contiguous)
     const float *weights;  // [b*W] or null
@@ -36,7 +42,6 @@ struct NceArgs {
     int lw;                // LDS dS row length (floats), multiple of 4
     // backward
     const float *dloss;    // [K]
-    float *dP;             // [b*T][K*H]
     float *dz;             // [b*T][H]  (atomics)
     float inv_count;       // 1 / (b*W)
 };
@@ -65,7 +70,7 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
 
     float4 areg[KK];
     {
-        const float *prow = a.P + ((long)bb * a.T + t) * a.K * H + (long)r * H + 4 * q;
+        const float *prow = a.Pk[r < a.K ? r : 0] + ((long)bb * a.p_rows + t) * a.p_stride + 4 * q;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
             areg[kk] = r < a.K ? *reinterpret_cast<const float4 *>(prow + 16 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -180,11 +185,13 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
     float *dS = smem;                                              // [16][lw]
     int *rowidx = reinterpret_cast<int *>(dS + NCE_ROWS * a.lw);   // [lw]
 
-    const int bb = blockIdx.x / a.T, t = blockIdx.x - bb * a.T;
+    const int bb = blockIdx.x / a.p_rows, t = blockIdx.x - bb * a.p_rows;
     const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
-    float *dprow = a.dP + (long)blockIdx.x * a.K * H;
-    if (t >= a.W) {
-        for (int i = lane; i < a.K * H / 4; i += 64) reinterpret_cast<float4 *>(dprow)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= a.W) {            // only reached when p_rows == T: zero the unused rows of the GEMM-shaped dP
+        for (int k = 0; k < a.K; ++k) {
+            float *row = a.dPk[k] + ((long)bb * a.p_rows + t) * a.p_stride;
+            for (int i = lane; i < H / 4; i += 64) reinterpret_cast<float4 *>(row)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         return;
     }
     const long bt = (long)bb * a.W + t;
@@ -248,24 +255,25 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
     }
     // dp[T4][e][reg] = dP[k = r][d = 64*T4 + 4*(4q + reg) + e]  -> 16 consecutive d per (T4, lane)
     if (r < a.K) {
+        float *dprow = a.dPk[r] + ((long)bb * a.p_rows + t) * a.p_stride;
 #pragma unroll
         for (int T4 = 0; T4 < DG; ++T4)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 if (64 * T4 + 16 * q + 4 * reg < H)
-                    *reinterpret_cast<float4 *>(dprow + (long)r * H + 64 * T4 + 16 * q + 4 * reg) =
+                    *reinterpret_cast<float4 *>(dprow + 64 * T4 + 16 * q + 4 * reg) =
                         make_float4(dp[T4][0][reg], dp[T4][1][reg], dp[T4][2][reg], dp[T4][3][reg]);
     }
 
     // ---- dz ------------------------------------------------------------------------------------
     const int r32 = lane & 31, h = lane >> 5;
-    const float *pbase = a.P + ((long)bb * a.T + t) * a.K * H;
+    const long prow_off = ((long)bb * a.p_rows + t) * a.p_stride;
     for (int dt = 0; dt < DT32; ++dt) {
         float bvals[NCE_ROWS / 2];
 #pragma unroll
         for (int kp = 0; kp < NCE_ROWS / 2; ++kp) {
             const int k = 2 * kp + h;
-            bvals[kp] = k < a.K ? pbase[(long)k * H + dt * 32 + r32] : 0.f;
+            bvals[kp] = k < a.K ? a.Pk[k][prow_off + dt * 32 + r32] : 0.f;
         }
         for (int ct = 0; ct < npad / 32; ++ct) {
             f32x16 acc;
@@ -358,6 +366,44 @@ template <typename Kern> static int allow_lds(Kern kern, size_t bytes)
     default: break;                                             \
     }
 
+static void nce_common(NceArgs &a, const NceLayout &l, const float *z, const int32_t *ext, const float *weights)
+{
+    a.z = z; a.ext = ext; a.weights = weights; a.logits = l.logits; a.lse = l.lse; a.lossp = l.lossp; a.hit = l.hit;
+    a.b = l.b; a.T = l.T; a.W = l.W; a.K = l.K; a.Nneg = l.Nneg; a.lw = l.lw; a.inv_count = 1.f / ((float)l.b * l.W);
+}
+
+static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *acc, hipStream_t st)
+{
+    int status = CPC_OK;
+    {
+        ProfScope prof(PROF_NCE_FWD, st);
+        NCE_DISPATCH(l.Henc, {
+            status = allow_lds(infonce_fwd_kernel<HH>, l.lds_fwd);
+            if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_fwd, st, a);
+        });
+    }
+    CPC_TRY(status);
+    CPC_CHECK_LAUNCH("infonce_fwd_kernel");
+    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(2 * l.K), dim3(256), 0, st, l.lossp, l.hit, (long)l.b * l.W, l.K, a.inv_count, losses, acc);
+    CPC_CHECK_LAUNCH("infonce_reduce_kernel");
+    return CPC_OK;
+}
+
+static int nce_launch_bwd(NceArgs &a, const NceLayout &l, hipStream_t st)
+{
+    int status = CPC_OK;
+    {
+        ProfScope prof(PROF_NCE_BWD, st);
+        NCE_DISPATCH(l.Henc, {
+            status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
+            if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(l.b * a.p_rows)), dim3(64), l.lds_bwd, st, a);
+        });
+    }
+    CPC_TRY(status);
+    CPC_CHECK_LAUNCH("infonce_bwd_kernel");
+    return CPC_OK;
+}
+
 static int infonce_forward(const float *c, const float *z, const float *wpred, const int32_t *ext, const float *weights,
                            float *losses, float *acc, void *saved, void *scratch, int b, int T, int K, int Har, int Henc,
                            int Nneg, hipStream_t st)
@@ -368,21 +414,10 @@ static int infonce_forward(const float *c, const float *z, const float *wpred, c
     // all K predictors in one GEMM: P[(b,t)][k*Henc + e] = sum_a c[b,t,a] * W_k[e][a]     (criterion.py:163)
     CPC_TRY(gemm_nt(c, Har, wpred, Har, l.P, (long)K * Henc, nullptr, (long)b * T, K * Henc, Har, none, st));
     NceArgs a{};
-    a.P = l.P; a.z = z; a.ext = ext; a.weights = weights; a.logits = l.logits; a.lse = l.lse; a.lossp = l.lossp; a.hit = l.hit;
-    a.b = b; a.T = T; a.W = l.W; a.K = K; a.Nneg = Nneg; a.lw = l.lw; a.inv_count = 1.f / ((float)b * l.W);
-    int status = CPC_OK;
-    {
-        ProfScope prof(PROF_NCE_FWD, st);
-        NCE_DISPATCH(Henc, {
-            status = allow_lds(infonce_fwd_kernel<HH>, l.lds_fwd);
-            if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(b * l.W)), dim3(64), l.lds_fwd, st, a);
-        });
-    }
-    CPC_TRY(status);
-    CPC_CHECK_LAUNCH("infonce_fwd_kernel");
-    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(2 * K), dim3(256), 0, st, l.lossp, l.hit, (long)b * l.W, K, a.inv_count, losses, acc);
-    CPC_CHECK_LAUNCH("infonce_reduce_kernel");
-    return CPC_OK;
+    nce_common(a, l, z, ext, weights);
+    for (int k = 0; k < K; ++k) a.Pk[k] = l.P + (size_t)k * Henc;
+    a.p_stride = (long)K * Henc; a.p_rows = T;
+    return nce_launch_fwd(a, l, losses, acc, st);
 }
 
 static int infonce_backward(const float *c, const float *z, const float *wpred, const int32_t *ext, const float *weights,
@@ -393,19 +428,11 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
     CPC_TRY(nce_layout(l, b, T, K, Har, Henc, Nneg, saved, scratch));
     CPC_CHECK_HIP(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)b * T * Henc, st));
     NceArgs a{};
-    a.P = l.P; a.z = z; a.ext = ext; a.weights = weights; a.logits = l.logits; a.lse = l.lse;
-    a.b = b; a.T = T; a.W = l.W; a.K = K; a.Nneg = Nneg; a.lw = l.lw; a.inv_count = 1.f / ((float)b * l.W);
-    a.dloss = dlosses; a.dP = l.dP; a.dz = dz;
-    int status = CPC_OK;
-    {
-        ProfScope prof(PROF_NCE_BWD, st);
-        NCE_DISPATCH(Henc, {
-            status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
-            if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(b * T)), dim3(64), l.lds_bwd, st, a);
-        });
-    }
-    CPC_TRY(status);
-    CPC_CHECK_LAUNCH("infonce_bwd_kernel");
+    nce_common(a, l, z, ext, weights);
+    for (int k = 0; k < K; ++k) { a.Pk[k] = l.P + (size_t)k * Henc; a.dPk[k] = l.dP + (size_t)k * Henc; }
+    a.p_stride = (long)K * Henc; a.p_rows = T;
+    a.dloss = dlosses; a.dz = dz;
+    CPC_TRY(nce_launch_bwd(a, l, st));
     // dc = dP . W  (rows t >= W of dP are zero)
     CPC_TRY(transpose2d(wpred, l.wt, K * Henc, Har, st));                        // [Har][K*Henc]
     RowMap none{};
@@ -413,6 +440,34 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
     // dW_k[e][a] = sum_{b,t} dP[(b,t)][k*Henc + e] * c[b,t,a]
     CPC_TRY(gemm_tn(l.dP, (long)K * Henc, c, Har, dwpred, Har, K * Henc, Har, (long)b * T, l.tn, l.tn_bytes, 0, 0, st));
     return CPC_OK;
+}
+
+// ---- predictions supplied by the caller (non-linear predictor modules): pred[k] is [b][W][Henc]
+static int infonce_forward_pred(const float *const *pred, const float *z, const int32_t *ext, const float *weights, float *losses,
+                                float *acc, void *saved, void *scratch, int b, int T, int K, int Henc, int Nneg, hipStream_t st)
+{
+    NceLayout l;
+    CPC_TRY(nce_layout(l, b, T, K, Henc, Henc, Nneg, saved, scratch));
+    NceArgs a{};
+    nce_common(a, l, z, ext, weights);
+    for (int k = 0; k < K; ++k) a.Pk[k] = pred[k];
+    a.p_stride = Henc; a.p_rows = l.W;
+    return nce_launch_fwd(a, l, losses, acc, st);
+}
+
+static int infonce_backward_pred(const float *const *pred, const float *z, const int32_t *ext, const float *weights,
+                                 const float *dlosses, void *saved, void *scratch, float *const *dpred, float *dz, int b, int T, int K,
+                                 int Henc, int Nneg, hipStream_t st)
+{
+    NceLayout l;
+    CPC_TRY(nce_layout(l, b, T, K, Henc, Henc, Nneg, saved, scratch));
+    CPC_CHECK_HIP(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)b * T * Henc, st));
+    NceArgs a{};
+    nce_common(a, l, z, ext, weights);
+    for (int k = 0; k < K; ++k) { a.Pk[k] = pred[k]; a.dPk[k] = dpred[k]; }
+    a.p_stride = Henc; a.p_rows = l.W;
+    a.dloss = dlosses; a.dz = dz;
+    return nce_launch_bwd(a, l, st);
 }
 
 }  // namespace cpc
@@ -458,4 +513,20 @@ extern "C" int cpc_infonce_backward(const float *c, const float *z, const float 
 {
     return cpc::infonce_backward(c, z, wpred, ext_idx, weights, dlosses, saved, scratch, dc, dz, dwpred, b, t, k, dim_ar, dim_enc,
                                  n_neg, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_infonce_forward_pred(const float *const *pred, const float *z, const int32_t *ext_idx, const float *weights,
+                                        float *losses, float *acc, void *saved, void *scratch, int b, int t, int k, int dim_enc,
+                                        int n_neg, cpc_stream_t stream)
+{
+    return cpc::infonce_forward_pred(pred, z, ext_idx, weights, losses, acc, saved, scratch, b, t, k, dim_enc, n_neg,
+                                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_infonce_backward_pred(const float *const *pred, const float *z, const int32_t *ext_idx, const float *weights,
+                                         const float *dlosses, void *saved, void *scratch, float *const *dpred, float *dz, int b,
+                                         int t, int k, int dim_enc, int n_neg, cpc_stream_t stream)
+{
+    return cpc::infonce_backward_pred(pred, z, ext_idx, weights, dlosses, saved, scratch, dpred, dz, b, t, k, dim_enc, n_neg,
+                                      static_cast<hipStream_t>(stream));
 }

@@ -197,6 +197,18 @@ int cpc_infonce_backward(const float *c, const float *z, const float *wpred, con
                          float *dc, float *dz, float *dwpred, int b, int t, int k, int dim_ar,
                          int dim_enc, int n_neg, cpc_stream_t stream);
 
+/* The same criterion when the K predictions come from predictor MODULES instead of linear maps
+ * (rnnMode="transformer": criterion.py:136-143; the predictions are produced by cpc_transformer_*):
+ *   pred   K pointers, each [b, W, dim_enc] (W = t - k): output of predictor k on c[:, :W]
+ *   dpred  K pointers, same shapes (overwritten);  saved/scratch sizes: cpc_infonce_*_bytes with dim_ar = dim_enc */
+int cpc_infonce_forward_pred(const float *const *pred, const float *z, const int32_t *ext_idx, const float *weights,
+                             float *losses, float *acc, void *saved, void *scratch, int b, int t, int k,
+                             int dim_enc, int n_neg, cpc_stream_t stream);
+int cpc_infonce_backward_pred(const float *const *pred, const float *z, const int32_t *ext_idx,
+                              const float *weights, const float *dlosses, void *saved, void *scratch,
+                              float *const *dpred, float *dz, int b, int t, int k, int dim_enc, int n_neg,
+                              cpc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Native FLAC reader for the window feeder (replaces torchaudio.load at cpc/dataset.py:411-437 and
  * cpc/feature_loader.py:343; the image ships no audio library).  HOST side.  Output is float32

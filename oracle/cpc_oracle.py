@@ -160,9 +160,14 @@ def quality_weights(signal_quality, growth_rate, inflection_point_x, window):
     return w.unsqueeze(1).repeat(1, window).reshape(-1)
 
 
+def transformer_predictors(p, k_steps, prefix="wPrediction.predictors."):
+    """rnnMode='transformer' (criterion.py:136-143): K one-layer transformers applied to c[:, :W]."""
+    return [(lambda c, i=i: transformer_layer_forward(c, p, f"{prefix}{i}.0.")) for i in range(k_steps)]
+
+
 def criterion_forward(c, z, predictors, ext_idx, n_neg, mode=None, n_skipped=0, weights=None):
     """c [b,T,Har], z [b,T,Henc], predictors = list of K matrices [Henc, Har] (nn.Linear
-    weights, no bias), ext_idx int64 [n_neg*W*b] from negative_indices().
+    weights, no bias) or of K callables (predictor modules), ext_idx int64 [n_neg*W*b] from negative_indices().
 
     Returns (losses [1, K-n_skipped], acc [1, K-n_skipped]).
 
@@ -183,7 +188,8 @@ def criterion_forward(c, z, predictors, ext_idx, n_neg, mode=None, n_skipped=0, 
         weights = torch.ones(b * w_len, dtype=z.dtype)
     losses, accs = [], []
     for k in range(1, k_steps + 1):
-        pred = (c @ predictors[k - 1].t()).unsqueeze(1)             # [b,1,W,H]
+        wk = predictors[k - 1]
+        pred = (wk(c) if callable(wk) else c @ wk.t()).unsqueeze(1)  # [b,1,W,H]; callable: a predictor module
         pos = z[:, k:k + w_len].unsqueeze(1)                        # [b,1,W,H]
         cand = torch.cat([pos, neg], dim=1)                         # [b,1+n,W,H]
         logits = (pred * cand).mean(dim=3)                          # [b,1+n,W]

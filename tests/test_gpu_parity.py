@@ -250,6 +250,31 @@ def test_criterion_full_shape_vs_reference_golden(golden):
         assert_close(w[:4, :8], t(g[f"dW{i}_head"]), 2e-4, f"dW{i} head")
 
 
+def test_criterion_transformer_predictors_vs_reference_golden(golden):
+    """rnnMode='transformer' (the fork's default predictors, criterion.py:136-143), eval mode."""
+    g = golden("g8_criterion_transformer_pred.npz")
+    b, t_len, h, k, nn, seed = (int(v) for v in g["cfg"])
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, h, h, nn, rnnMode="transformer", sizeInputSeq=t_len)
+    assert sorted(n for n, _ in crit.named_parameters()) == [str(x) for x in g["param_names"]]
+    sd = crit.state_dict()
+    for i in range(k):
+        sd.update(synth.transformer_params(h, h, t_len - k, seed=80 + i, prefix=f"wPrediction.predictors.{i}.0."))
+    crit.load_state_dict(sd)
+    crit = crit.to(DEV).eval()
+    c = synth.features((b, t_len, h), 90).to(DEV).requires_grad_(True)
+    z = synth.features((b, t_len, h), 91, relu=True).to(DEV).requires_grad_(True)
+    torch.manual_seed(seed)
+    losses, acc = crit(c, z, None)
+    assert_close(losses, t(g["losses"]), 1e-5, "losses")
+    assert torch.allclose(acc.cpu(), t(g["acc"]), atol=1.5 / (b * (t_len - k)))
+    losses.sum().backward()
+    assert_close(c.grad, t(g["dc"]), 2e-4, "dc")
+    assert_close(z.grad, t(g["dz"]), 1e-4, "dz")
+    for name, prm in crit.named_parameters():
+        if "grad." + name in g.files:
+            assert_close(prm.grad, t(g["grad." + name]), 5e-4, f"grad {name}")
+
+
 def test_criterion_indices_on_device_are_bit_exact(golden):
     g = golden("g1_negidx.npz")
     seed, b, t_len, k, nn = (int(v) for v in g["mid_cfg"])

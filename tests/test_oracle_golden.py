@@ -218,3 +218,21 @@ def test_transformer_layer(golden):
     for k, v in p.items():
         ref = t(g["grad." + k[len("gAR."):]])
         assert torch.allclose(v.grad, ref, atol=2e-5 * float(ref.abs().max()) + 1e-7, rtol=1e-4), k
+
+
+# ----------------------------------------------------------------------------- G8
+def test_criterion_with_transformer_predictors(golden):
+    g = golden("g8_criterion_transformer_pred.npz")
+    b, t_len, h, k, nn, seed = (int(v) for v in g["cfg"])
+    p = {}
+    for i in range(k):
+        p.update(synth.transformer_params(h, h, t_len - k, seed=80 + i, prefix=f"wPrediction.predictors.{i}.0."))
+    p = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+    c = synth.features((b, t_len, h), 90).requires_grad_(True)
+    z = synth.features((b, t_len, h), 91, relu=True).requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(seed), b, t_len, t_len - k, nn)
+    losses, acc = O.criterion_forward(c, z, O.transformer_predictors(p, k), ext, nn)
+    losses.sum().backward()
+    assert torch.allclose(losses, t(g["losses"]), atol=0, rtol=1e-6)
+    assert torch.allclose(c.grad, t(g["dc"]), atol=1e-8, rtol=1e-4)
+    assert torch.allclose(z.grad, t(g["dz"]), atol=1e-8, rtol=1e-4)

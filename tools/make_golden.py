@@ -290,7 +290,31 @@ def g7():
     save("g7_transformer.npz", **d)
 
 
+# ------------------------------------------------------------------ G8 criterion with transformer predictors
+def g8():
+    """rnnMode='transformer' (the fork's default predictor, criterion.py:136-143), eval mode (dropout off)."""
+    b, t_len, h, k, nn, seed = 3, 32, 32, 4, 8, 5
+    crit = ref_crit.CPCUnsupersivedCriterion(k, h, h, nn, rnnMode="transformer", sizeInputSeq=t_len)
+    sd = crit.state_dict()
+    for i in range(k):
+        p = synth.transformer_params(h, h, t_len - k, seed=80 + i, prefix=f"wPrediction.predictors.{i}.0.")
+        sd.update(p)
+    crit.load_state_dict(sd)
+    crit.eval()
+    c = synth.features((b, t_len, h), seed=90).requires_grad_(True)
+    z = synth.features((b, t_len, h), seed=91, relu=True).requires_grad_(True)
+    torch.manual_seed(seed)
+    losses, acc = crit(c, z, None)
+    losses.sum().backward()
+    d = {"cfg": np.array([b, t_len, h, k, nn, seed]), "losses": losses, "acc": acc, "dc": c.grad, "dz": z.grad}
+    for name, prm in crit.named_parameters():
+        if name.startswith("wPrediction.predictors.0.") or name.endswith("Krelpos"):
+            d["grad." + name] = prm.grad
+    d["param_names"] = np.array(sorted(n for n, _ in crit.named_parameters()))
+    save("g8_criterion_transformer_pred.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name in which:
         globals()[name]()
