@@ -237,7 +237,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
-                                   f"{cfg['npred']}, {cfg['nneg']} negatives, linear predictors), {args.batch} x 1.28 s "
+                                   f"{cfg['npred']}, {cfg['nneg']} negatives, {cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
                                    f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
                                                              if args.dedup else
                                                              "reference trainStep semantics (encoder+AR on 2b windows), ")
