@@ -23,6 +23,7 @@ SIGNATURES = {
     "cpc_version": (c_int, []),
     "cpc_last_error": (ctypes.c_char_p, []),
     "cpc_prof_enable": (c_int, [c_int]),
+    "cpc_gemm_set_mode": (c_int, [c_int]),
     "cpc_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_long)]),
     "cpc_gemm_nt": (c_int, [c_ptr, c_long, c_ptr, c_long, c_ptr, c_long, c_ptr, c_int, c_int, c_int, c_ptr]),
     "cpc_gemm_tn_scratch_bytes": (c_size_t, [c_int, c_int, c_long]),

@@ -1,4 +1,9 @@
-// fp32 GEMMs on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 64 FLOP/clk/SIMD).
+// fp32 GEMMs for gfx950.  Two kernel families compute the same products:
+//   * gemm_*_x6_kernel (default): f32 operands are split exactly into three bf16 terms while they are staged
+//     into LDS and multiplied on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) as six
+//     partial products accumulated in f32 -- f32-GEMM accuracy (see the comment at gemm_nt_x6_kernel);
+//   * gemm_*_kernel: the f32 MFMA (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD); unaligned shapes, and the
+//     yardstick the split kernels' error is tested against (cpc_gemm_set_mode(1)).
 //
 //   gemm_nt : C[map(m)][n] = sum_k A[m*lda + k] * B[n*ldb + k] (+ bias[n])
 //             A rows may OVERLAP (lda < K): that is how the strided Conv1d layers run as
@@ -18,6 +23,9 @@ namespace cpc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 0: bf16x6 split kernels (default); 1: native f32-MFMA kernels (the accuracy yardstick; also CPC_GEMM_NATIVE_F32=1)
+static int g_gemm_mode = getenv("CPC_GEMM_NATIVE_F32") != nullptr ? 1 : 0;
+
 constexpr int BN = 128, BK = 32;
 constexpr int BM = 128;          // TN kernel tile; the NT kernel derives its own from MI
 constexpr int LDS_NT = BK + 4;    // 36 floats per LDS row (NT: k contiguous)
@@ -33,6 +41,43 @@ struct GemmNTArgs {
     int aligned;   // K%4==0, lda%4==0, ldb%4==0, bases 16-B aligned
     int kchunk;    // K range per blockIdx.y (multiple of BK); gridDim.y > 1: partial products are atomically added
 };
+
+// acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
+// (the C/D layout of every 32x32 MFMA on gfx950, f32- and bf16-input alike)
+template <int MI>
+__device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[MI][2], long m0, int n0, int wm, int wn, int r32, int h)
+{
+    float bias_v[2];
+    int ncol[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ncol[j] = n0 + wn * 64 + j * 32 + r32;
+        bias_v[j] = (p.bias != nullptr && ncol[j] < p.N && blockIdx.y == 0) ? p.bias[ncol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long m = m0 + wm * 32 * MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m >= p.M) continue;
+            long crow = m;
+            if (p.map.enabled) {
+                const long g = m / p.map.rv;
+                const int t = (int)(m - g * p.map.rv);
+                const long l = (long)t * p.map.out_stride + p.map.out_off;
+                if (l < 0 || l >= p.map.l_max) continue;
+                crow = g * p.map.rows_out + l;
+            }
+            float *crowp = p.C + crow * p.ldc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (ncol[j] < p.N) {
+                    if (gridDim.y > 1) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
+                    else crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
+                }
+        }
+    }
+}
 
 // 4 consecutive elements k..k+3 of row `row` (k < K or zero).  Rows beyond row_max are CLAMPED, not zeroed:
 // for the output dimensions (M, N) such rows only feed outputs the epilogue discards.
@@ -61,7 +106,7 @@ __device__ __forceinline__ float4 ld4(const float *base, long row, long row_max,
 
 // MI = 32-row MFMA tiles per wave along M: block tile (64*MI) x 128.  MI = 2 is the default 128x128 tile;
 // MI = 1 (64x128) is picked when the 128-row grid would leave CUs with a single workgroup.
-template <bool ALIGNED, int MI> __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p)
+template <bool ALIGNED, int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNTArgs p)
 {
     constexpr int BM = 64 * MI;
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_NT];
@@ -121,61 +166,186 @@ template <bool ALIGNED, int MI> __global__ __launch_bounds__(256) void gemm_nt_k
         __syncthreads();
         if (kt + 1 < nk) load_tiles(kt + 1);
 
+        // fragments of slice kk+1 are read while slice kk is multiplied (two register sets).
+        // lane (r32, h) takes k = kk*8 + 4h + {0,1,2,3}; MFMA step e pairs k-slot (h, e) of A with the same k of B,
+        // so any k permutation shared by both operands is valid.
+        float4 fa[2][MI], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const float4 *>(&As[(wm * 32 * MI + i * 32 + r32) * LDS_NT + h * 4]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fb[0][i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + r32) * LDS_NT + h * 4]);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            // lane (r32, h) takes k = kk*8 + 4h + {0,1,2,3}; MFMA step e pairs k-slot (h, e) of A
-            // with the same k of B, so any k permutation shared by both operands is valid.
-            float4 a[MI], b[2];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                a[i] = *reinterpret_cast<const float4 *>(&As[(wm * 32 * MI + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
+                for (int i = 0; i < MI; ++i)
+                    fa[nxt][i] = *reinterpret_cast<const float4 *>(&As[(wm * 32 * MI + i * 32 + r32) * LDS_NT + (kk + 1) * 8 + h * 4]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                b[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + r32) * LDS_NT + kk * 8 + h * 4]);
+                for (int i = 0; i < 2; ++i)
+                    fb[nxt][i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + r32) * LDS_NT + (kk + 1) * 8 + h * 4]);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                 }
         }
         __syncthreads();
     }
 
-    // epilogue: acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
-    float bias_v[2];
-    int ncol[2];
+    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe (16x the f32 MFMA rate on gfx950): every f32 operand is split
+// EXACTLY into three bf16 terms x = x0 + x1 + x2 (round-to-nearest residuals: |x - x0 - x1 - x2| <= 2^-27 |x|)
+// while it is staged into LDS, and a.b is accumulated in f32 from the six products whose weight is >= 2^-18:
+// a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 (the dropped a1b2, a2b1, a2b2 are <= 2^-26 |a||b|, below the rounding of
+// one f32 multiply).  bf16 x bf16 is exact in f32, so the result carries f32-GEMM accuracy (tests compare both
+// kernels with an fp64 product), at 6 bf16 MFMAs per 16 k instead of 8 f32 MFMAs of 1/16 the rate.
+//
+// LDS image per operand: three planes [rows][32 k] bf16 (64-byte rows, unpadded); the 16-byte chunk c of row r
+// lives at chunk c ^ ((r >> 2) & 3), which makes both the ds_write_b128 of the loader (4 lanes per row) and the
+// ds_read_b128 of the fragments (lane = row, 8 consecutive k) bank-conflict free.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b)
+{
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32, RNE
+}
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t &x0, uint32_t &x1, uint32_t &x2)
+{
+    x0 = pk_bf16(a, b);
+    a -= __uint_as_float(x0 << 16);
+    b -= __uint_as_float(x0 & 0xffff0000u);
+    x1 = pk_bf16(a, b);
+    a -= __uint_as_float(x1 << 16);
+    b -= __uint_as_float(x1 & 0xffff0000u);
+    x2 = pk_bf16(a, b);
+}
+
+// 8 consecutive k of one row -> one 16-byte chunk in each of the three planes
+__device__ __forceinline__ void split8_store(const float4 &u, const float4 &v, char *plane0, int plane_bytes, int off)
+{
+    uint4 w0, w1, w2;
+    split2(u.x, u.y, w0.x, w1.x, w2.x);
+    split2(u.z, u.w, w0.y, w1.y, w2.y);
+    split2(v.x, v.y, w0.z, w1.z, w2.z);
+    split2(v.z, v.w, w0.w, w1.w, w2.w);
+    *reinterpret_cast<uint4 *>(plane0 + off) = w0;
+    *reinterpret_cast<uint4 *>(plane0 + plane_bytes + off) = w1;
+    *reinterpret_cast<uint4 *>(plane0 + 2 * plane_bytes + off) = w2;
+}
+
+__device__ __forceinline__ int x6_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(GemmNTArgs p)
+{
+    constexpr int BM = 64 * MI;
+    constexpr int PA = BM * 64, PB = BN * 64;              // bytes per plane
+    __shared__ __attribute__((aligned(16))) char lds[3 * (PA + PB)];
+    char *As = lds;                   // [3][BM][64 B]
+    char *Bs = lds + 3 * PA;          // [3][BN][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long m0 = (long)(blockIdx.x / tiles_n) * BM;
+    const int n0 = (int)(blockIdx.x % tiles_n) * BN;
+
+    // loader: thread = (row tid/4 [+64 q], 8 consecutive k at (tid%4)*8): two float4 per row, MI rows of A, 2 of B
+    const int lrow = tid >> 2;
+    const int lchunk = tid & 3;
+    const int lk = lchunk * 8;
+    float4 ra[MI][2], rb[2][2];
+
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk_full = (kend - kbeg) / BK;
+    auto load_tiles = [&](int kt) {
+        const int k0 = kbeg + kt * BK + lk;
+        if (kt < nk_full) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        ncol[j] = n0 + wn * 64 + j * 32 + r32;
-        bias_v[j] = (p.bias != nullptr && ncol[j] < p.N && blockIdx.y == 0) ? p.bias[ncol[j]] : 0.f;
-    }
+            for (int q = 0; q < MI; ++q)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+                for (int c = 0; c < 2; ++c) ra[q][c] = ld4<true, false>(p.A, m0 + lrow + 64 * q, p.M, p.lda, k0 + 4 * c, kend);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const long m = m0 + wm * 32 * MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= p.M) continue;
-            long crow = m;
-            if (p.map.enabled) {
-                const long g = m / p.map.rv;
-                const int t = (int)(m - g * p.map.rv);
-                const long l = (long)t * p.map.out_stride + p.map.out_off;
-                if (l < 0 || l >= p.map.l_max) continue;
-                crow = g * p.map.rows_out + l;
-            }
-            float *crowp = p.C + crow * p.ldc;
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) rb[q][c] = ld4<true, false>(p.B, n0 + lrow + 64 * q, p.N, p.ldb, k0 + 4 * c, kend);
+        } else {
+#pragma unroll
+            for (int q = 0; q < MI; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) ra[q][c] = ld4<true, true>(p.A, m0 + lrow + 64 * q, p.M, p.lda, k0 + 4 * c, kend);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) rb[q][c] = ld4<true, true>(p.B, n0 + lrow + 64 * q, p.N, p.ldb, k0 + 4 * c, kend);
+        }
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int q = 0; q < MI; ++q) split8_store(ra[q][0], ra[q][1], As, PA, x6_off(lrow + 64 * q, lchunk));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) split8_store(rb[q][0], rb[q][1], Bs, PB, x6_off(lrow + 64 * q, lchunk));
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles(kt + 1);
+
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            // lane (r32, h) holds k = kk*16 + 8h .. +7 of its row: chunk 2 kk + h
+            bf16x8_t fa[MI][3], fb[2][3];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PA + x6_off(wm * 32 * MI + i * 32 + r32, 2 * kk + h));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                if (ncol[j] < p.N) {
-                    if (gridDim.y > 1) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
-                    else crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PB + x6_off(wn * 64 + j * 32 + r32, 2 * kk + h));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        __syncthreads();
     }
+    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
 }
 
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
@@ -202,9 +372,12 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     if (splits > 1) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
     dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);
+    const bool native = g_gemm_mode == 1;
     if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
-    else if (mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
+    else if (native && mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
+    else if (native) hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
+    else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_x6_kernel<2>), grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
     return CPC_OK;
 }
@@ -327,6 +500,121 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_tn_kernel(Ge
         }
 }
 
+// TN product on the bf16 pipe (same three-term split as gemm_nt_x6_kernel).  The reduction index r is the ROW
+// of both operands, so the loader transposes while it splits: a thread takes an 8(r) x 4(column) micro tile
+// (8 row loads of 16 bytes), and writes, for each of its 4 columns, the 8 consecutive r as one 16-byte chunk per
+// plane -> the LDS image is [column][32 r] bf16, the layout (and swizzle) the NT kernel reads its fragments from.
+__global__ __launch_bounds__(256, 3) void gemm_tn_x6_kernel(GemmTNArgs p)
+{
+    constexpr int PL = BM * 64;                            // bytes per plane (BM == BN)
+    __shared__ __attribute__((aligned(16))) char lds[6 * PL];
+    char *As = lds;                   // [3][BM][64 B]
+    char *Bs = lds + 3 * PL;          // [3][BN][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int i0 = blockIdx.y * BM;
+    const int j0 = blockIdx.x * BN;
+    const long rbeg = (long)blockIdx.z * p.chunk;
+    long rend = rbeg + p.chunk;
+    if (rend > p.R) rend = p.R;
+
+    // waves 0,1 stage A, waves 2,3 stage B: micro tile u -> rows 8*(u&3) .. +7, columns 4*(u>>2) .. +3
+    const bool isA = tid < 128;                                // wave uniform
+    const int u = tid & 127;
+    const int rg = u & 3, cg = u >> 2;
+    const float *src = isA ? p.A : p.B;
+    const long ld = isA ? p.lda : p.ldb;
+    const int ncols = isA ? p.M : p.N;
+    const int col = min((isA ? i0 : j0) + 4 * cg, ncols - 4);  // clamped columns only feed outputs never stored
+    char *dst = isA ? As : Bs;
+    float4 rv[8];
+    auto load_tiles = [&](long r0) {
+        const bool full = r0 + BK <= rend;              // uniform
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const long r = r0 + 8 * rg + d;
+            const long rc = (full || r < rend) ? r : rend - 1;
+            rv[d] = *reinterpret_cast<const float4 *>(src + rc * ld + col);
+        }
+        return full;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (rbeg < rend) {
+        bool full = load_tiles(rbeg);
+        for (long r0 = rbeg; r0 < rend; r0 += BK) {
+            if (!full) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (r0 + 8 * rg + d >= rend) rv[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            split8_store(make_float4(rv[0].x, rv[1].x, rv[2].x, rv[3].x), make_float4(rv[4].x, rv[5].x, rv[6].x, rv[7].x),
+                         dst, PL, x6_off(4 * cg + 0, rg));
+            split8_store(make_float4(rv[0].y, rv[1].y, rv[2].y, rv[3].y), make_float4(rv[4].y, rv[5].y, rv[6].y, rv[7].y),
+                         dst, PL, x6_off(4 * cg + 1, rg));
+            split8_store(make_float4(rv[0].z, rv[1].z, rv[2].z, rv[3].z), make_float4(rv[4].z, rv[5].z, rv[6].z, rv[7].z),
+                         dst, PL, x6_off(4 * cg + 2, rg));
+            split8_store(make_float4(rv[0].w, rv[1].w, rv[2].w, rv[3].w), make_float4(rv[4].w, rv[5].w, rv[6].w, rv[7].w),
+                         dst, PL, x6_off(4 * cg + 3, rg));
+            __syncthreads();
+            if (r0 + BK < rend) full = load_tiles(r0 + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8_t fa[2][3], fb[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PL + x6_off(wm * 64 + i * 32 + r32, 2 * kk + h));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PL + x6_off(wn * 64 + j * 32 + r32, 2 * kk + h));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+
+    // slab[z][i][j]: i = i0 + wm*64 + it*32 + (e&3) + 8*(e>>2) + 4h ; j = j0 + wn*64 + jt*32 + r32
+    float *slab = p.slab + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm * 64 + it * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i >= p.M) continue;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j = j0 + wn * 64 + jt * 32 + r32;
+                if (j < p.N) slab[(long)i * p.N + j] = acc[it][jt][e];
+            }
+        }
+}
+
 // out = sum over slabs; optional Conv1d weight re-layout (column jj*cin+ci -> [ci][jj])
 __global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k)
 {
@@ -381,7 +669,9 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
     dim3 grid((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM), (unsigned)S);
     ProfScope prof(PROF_GEMM_TN, st);
-    if (a.aligned) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
+    const bool native = g_gemm_mode == 1;
+    if (a.aligned && !native) hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, dim3(256), 0, st, a);
+    else if (a.aligned) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_tn_kernel");
     const long total = (long)M * N;
@@ -391,9 +681,18 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
     return CPC_OK;
 }
 
+int gemm_set_mode(int mode)
+{
+    const int prev = g_gemm_mode;
+    if (mode == 0 || mode == 1) g_gemm_mode = mode;
+    return prev;
+}
+
 }  // namespace cpc
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int cpc_gemm_set_mode(int mode) { return cpc::gemm_set_mode(mode); }
+
 extern "C" int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,
                            const float *bias, int M, int N, int K, cpc_stream_t stream)
 {

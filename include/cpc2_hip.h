@@ -50,11 +50,17 @@ int cpc_prof_enable(int on);
 int cpc_prof_read(const char *name, double *total_ms, long *count);
 
 /* ------------------------------------------------------------------------------------------
- * Dense fp32 GEMMs on the f32 MFMA (v_mfma_f32_32x32x2_f32).  Replace the ATen addmm/linear
- * calls behind nn.Linear / nn.GRU input projections (criterion.py:144-146,163; model.py:196).
+ * Dense fp32 GEMMs.  Replace the ATen addmm/linear calls behind nn.Linear / nn.GRU input
+ * projections (criterion.py:144-146,163; model.py:196) and, through the encoder entry points,
+ * the cuDNN convolutions of model.py:81-107.
  *   nt:  C[M,N] = A[M,K] . B[N,K]^T (+ bias[N])          (lda/ldb/ldc in elements)
  *   tn:  C[M,N] = sum_r A[r,M]^T . B[r,N], r < R   (split over R; scratch from the query)
+ * f32 in, f32 out, f32 accumulation.  Mode 0 (default) multiplies on the bf16 matrix pipe after an
+ * exact three-term bf16 split of every operand (six partial products, error <= that of the f32
+ * MFMA path, tests/test_gpu_parity.py::test_gemm_split_accuracy); mode 1 uses the f32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  cpc_gemm_set_mode returns the previous mode; other values only query.
  * ------------------------------------------------------------------------------------------ */
+int cpc_gemm_set_mode(int mode);
 int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,
                 const float *bias, int M, int N, int K, cpc_stream_t stream);
 size_t cpc_gemm_tn_scratch_bytes(int M, int N, long R);

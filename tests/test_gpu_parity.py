@@ -90,6 +90,79 @@ def test_gemm_tn(m, n, r):
     assert_close(c, ref, 2e-6 * max(1, r ** 0.5), "gemm_tn")
 
 
+def _gemm_rel_err(kind, a, b, mode):
+    """max and rms of |C - C64| / (|A| . |B|) with the GEMM family `mode` (0 bf16x6 split, 1 f32 MFMA)."""
+    lib = _lib.load()
+    prev = lib.cpc_gemm_set_mode(mode)
+    try:
+        ad, bd = a.to(DEV), b.to(DEV)
+        if kind == "nt":
+            m, k = a.shape
+            n = b.shape[0]
+            c = torch.empty(m, n, device=DEV)
+            _lib.check(lib.cpc_gemm_nt(_lib.ptr(ad), k, _lib.ptr(bd), k, _lib.ptr(c), n, None, m, n, k, _lib.stream_ptr(c.device)))
+            ref, mag = a.double() @ b.double().t(), a.double().abs() @ b.double().abs().t()
+        else:
+            r, m = a.shape
+            n = b.shape[1]
+            c = torch.empty(m, n, device=DEV)
+            nbytes = lib.cpc_gemm_tn_scratch_bytes(m, n, r)
+            sc = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.cpc_gemm_tn(_lib.ptr(ad), m, _lib.ptr(bd), n, _lib.ptr(c), n, m, n, r, _lib.ptr(sc), nbytes, _lib.stream_ptr(c.device)))
+            ref, mag = a.double().t() @ b.double(), a.double().abs().t() @ b.double().abs()
+    finally:
+        lib.cpc_gemm_set_mode(prev)
+    e = (c.cpu().double() - ref).abs() / mag.clamp_min(1e-300)
+    return float(e.max()), float(e.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("kind,shape,data", [("nt", (2048, 256, 2048), "randn"), ("nt", (2048, 256, 512), "relu"),
+                                             ("nt", (1024, 768, 256), "wide"), ("tn", (8192, 256, 1024), "randn"),
+                                             ("tn", (4000, 256, 512), "tiny")])
+def test_gemm_split_accuracy(kind, shape, data):
+    """The default GEMMs run on the bf16 pipe from an exact three-term split of the f32 operands; their error
+    against an fp64 product must be that of an f32 GEMM: no worse than the f32-MFMA kernels' (mode 1) on the
+    same data, and within a few f32 roundings of sum |a||b|."""
+    g = torch.Generator().manual_seed(sum(shape))
+    if kind == "nt":
+        m, n, k = shape
+        a, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
+    else:
+        r, m, n = shape
+        a, b = torch.randn(r, m, generator=g), torch.randn(r, n, generator=g)
+    if data == "relu":
+        a = a.clamp_min(0)
+    if data == "wide":        # magnitudes over 2^-20 .. 2^20 within one row: residual terms at every exponent
+        a = a * torch.exp2(torch.randint(-20, 21, a.shape, generator=g).float())
+    if data == "tiny":        # gradient-sized operands
+        a, b = a * 1e-9, b * 1e-7
+    split_max, split_rms = _gemm_rel_err(kind, a, b, 0)
+    f32_max, f32_rms = _gemm_rel_err(kind, a, b, 1)
+    assert split_rms <= 1.25 * f32_rms + 1e-10, (split_rms, f32_rms)
+    assert split_max <= 1.5 * f32_max + 1e-9, (split_max, f32_max)
+    assert split_max <= 16 * 2.0 ** -24
+
+
+def test_gemm_split_specials():
+    """inf / nan operands poison exactly the outputs they feed; zeros and denormal-range values are harmless."""
+    lib = _lib.load()
+    a = torch.randn(256, 64)
+    b = torch.randn(128, 64)
+    a[3, 5] = float("inf")
+    a[7, 9] = float("nan")
+    a[11, :] = 0.0
+    a[12, :] = 1e-41
+    c = torch.empty(256, 128, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    _lib.check(lib.cpc_gemm_nt(_lib.ptr(ad), 64, _lib.ptr(bd), 64, _lib.ptr(c), 128, None, 256, 128, 64, _lib.stream_ptr(c.device)))
+    c = c.cpu()
+    assert not torch.isfinite(c[3]).any() and torch.isnan(c[7]).all()
+    assert (c[11] == 0).all() and torch.isfinite(c[12]).all() and c[12].abs().max() < 1e-38
+    keep = torch.ones(256, dtype=torch.bool)
+    keep[[3, 7]] = False
+    assert torch.isfinite(c[keep]).all()
+
+
 # ----------------------------------------------------------------------------- ChannelNorm (standalone, channel-first)
 def test_channelnorm_module_vs_reference_golden(golden):
     g = golden("g3_channelnorm.npz")

@@ -1,5 +1,6 @@
 """GEMM-only probe (conv1 forward shape by default) for rocprofv3 --pmc runs.
-   python tools/gemm_probe.py [nt|tn] [reps]"""
+   python tools/gemm_probe.py [nt|tn] [reps]      env: PROBE_M rows, PROBE_TAPS k, PROBE_STRIDE s, PROBE_H channels
+   (A rows overlap: lda = s*H, K = k*H; the dgrad phase GEMMs are PROBE_TAPS=2 PROBE_STRIDE=1)"""
 import sys, os, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +9,8 @@ lib = _lib.load()
 kind = sys.argv[1] if len(sys.argv) > 1 else "nt"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda:0")
-N, H, k, s, L = 128, 256, 8, 4, 1024
+N, H, L = 128, int(os.environ.get("PROBE_H", 256)), 1024
+k, s = int(os.environ.get("PROBE_TAPS", 8)), int(os.environ.get("PROBE_STRIDE", 4))
 Rv = L + 2
 M = int(os.environ.get("PROBE_M", N * Rv))
 torch.manual_seed(0)
@@ -34,4 +36,4 @@ t0 = time.perf_counter()
 for _ in range(reps): run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-print(f"{kind}: {dt*1e3:.3f} ms  {flops/dt/1e12:.1f} TFLOP/s")
+print(f"{kind} M={M} K={k*H} lda={s*H}: {dt*1e3:.3f} ms  {flops/dt/1e12:.1f} TFLOP/s")
