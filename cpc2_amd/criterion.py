@@ -32,7 +32,7 @@ class NegativeSampler:
         if not self._h:
             raise MemoryError("cpc_mt_create failed")
         self.follow_torch = True      # consume torch's global CPU generator (reference semantics)
-        self._ring, self._events, self._slot = {}, {}, 0
+        self._ring, self._dev_ring, self._events, self._slot = {}, {}, {}, 0
         self._prefetched = None
         self.prefetch = False         # opt-in: draw step i+1's words during step i (private stream, fixed shapes)
 
@@ -93,31 +93,36 @@ class NegativeSampler:
         if not time_major:
             host = self.sample_host(batch, seq_len, window, n_neg)
             return host.to(device)
+        device = torch.device(device)
         key = (n, str(device))
         if key not in self._ring:
             self._ring[key] = [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+            self._dev_ring[key] = [torch.empty(2 * n, dtype=torch.int32, device=device) for _ in range(self.RING)]
             self._events[key] = [None] * self.RING
             self._prefetched = None
-        ring, events = self._ring[key], self._events[key]
+        ring, dev_ring, events = self._ring[key], self._dev_ring[key], self._events[key]
         slot = self._slot % self.RING
         self._slot += 1
         host = ring[slot]
         if self._prefetched == (key, slot):
-            check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")           # drawn while the GPU was busy
+            # drawn AND uploaded (on the worker's own stream) while the GPU was busy with the previous step
+            check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")
+            raw = dev_ring[slot]
         else:
             if events[slot] is not None:
-                events[slot].synchronize()     # the copy that last used this staging buffer has finished
+                events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
             st = self._pull_torch_state() if self.follow_torch else None
             check(self._lib.cpc_mt_draw_host(self._h, ptr(host), 2 * n), "mt_draw_host")
             if st is not None:
                 self._push_torch_state(st)
-        raw = host.to(device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        events[slot] = ev
+            raw = dev_ring[slot]
+            raw.copy_(host, non_blocking=True)
         ext = torch.empty(n, dtype=torch.int32, device=device)
         check(self._lib.cpc_negidx_expand(ptr(raw), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
               "negidx_expand")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        events[slot] = ev
         self._prefetched = None
         if self.prefetch and not self.follow_torch:
             # private stream: draw the NEXT step's words now, on the library's worker thread (the caller promises
@@ -125,7 +130,9 @@ class NegativeSampler:
             nslot = self._slot % self.RING
             if events[nslot] is not None:
                 events[nslot].synchronize()
-            check(self._lib.cpc_mt_draw_host_async(self._h, ptr(ring[nslot]), 2 * n), "mt_draw_host_async")
+            dev_index = device.index if device.index is not None else torch.cuda.current_device()
+            check(self._lib.cpc_mt_draw_device_async(self._h, ptr(ring[nslot]), ptr(dev_ring[nslot]), 2 * n, dev_index),
+                  "mt_draw_device_async")
             self._prefetched = (key, nslot)
         return ext
 

@@ -12,6 +12,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/cpc2_hip.h"
 
 namespace cpc { void set_error(const char *fmt, ...); }
@@ -207,6 +209,27 @@ extern "C" int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t
     if (g == nullptr || raw_host == nullptr) { cpc::set_error("cpc_mt_draw_host_async: null argument"); return CPC_ERR_INVALID; }
     cpc_negidx_wait(g);
     g->worker = std::thread([=] { draw(g, raw_host, n); g->worker_status = CPC_OK; });
+    return CPC_OK;
+}
+
+// Draw on the worker thread, then upload from the (pinned) staging buffer on a stream of the worker's own, so the
+// host-to-device copy (8 bytes per negative) overlaps whatever the training stream is doing; the words are on the
+// device when cpc_negidx_wait returns.
+extern "C" int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device)
+{
+    if (g == nullptr || raw_host == nullptr || raw_dev == nullptr) { cpc::set_error("cpc_mt_draw_device_async: null argument"); return CPC_ERR_INVALID; }
+    cpc_negidx_wait(g);
+    g->worker = std::thread([=] {
+        draw(g, raw_host, n);
+        hipStream_t st = nullptr;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(raw_dev, raw_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st != nullptr) (void)hipStreamDestroy(st);
+        if (e != hipSuccess) cpc::set_error("cpc_mt_draw_device_async: %s", hipGetErrorString(e));
+        g->worker_status = e == hipSuccess ? CPC_OK : CPC_ERR_HIP;
+    });
     return CPC_OK;
 }
 

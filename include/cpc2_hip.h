@@ -175,6 +175,9 @@ int cpc_negidx_wait(cpc_mt19937 *g);
  * Integer-exact: cpc_negidx_expand(raw) == cpc_negidx_sample_host(time_major = 1). */
 int cpc_mt_draw_host(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
 int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
+/* ... and uploaded by the worker on its own stream (raw_host pinned): raw_dev holds the words once
+ * cpc_negidx_wait returns, so no copy sits on the training stream. */
+int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device);
 int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
                       cpc_stream_t stream);
 
