@@ -348,6 +348,151 @@ template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(Ge
     nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised form of gemm_nt_x6_kernel.  Measured on the kernel above: its time is the SUM of the MFMA time
+// and of everything else (loads + split + LDS traffic) -- co-resident workgroups fall into lockstep and their
+// phases never overlap.  Here the overlap is built in: 8 waves per workgroup, waves 0-3 only multiply (64x64 each,
+// from LDS stage kt % 2), waves 4-7 only stage (global loads two tiles ahead, split, write stage (kt+1) % 2);
+// one barrier per K step.  One workgroup per CU (96 KiB LDS), two waves per SIMD: one of each role.
+// Workgroup barrier that publishes LDS writes only.  __syncthreads() also drains vmcnt to 0, which would make the
+// staging waves wait at every K step for the global loads they have just issued for the tile after next.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// MI: 32-row MFMA tiles per multiplying wave; WM: multiplying waves along M (x2 along N, 64 columns each);
+// LW: staging waves.  Block tile (32*MI*WM) x 128, 64*(2*WM + LW) threads.
+template <int MI, int WM, int LW> __global__ __launch_bounds__(64 * (2 * WM + LW)) void gemm_nt_x6s_kernel(GemmNTArgs p)
+{
+    constexpr int BM = 32 * MI * WM;
+    constexpr int PA = BM * 64, PB = BN * 64;              // bytes per plane
+    constexpr int STAGE = 3 * (PA + PB);
+    constexpr int NMUL = 2 * WM;                            // multiplying waves
+    constexpr int LROWS = 16 * LW;                          // rows staged per pass
+    constexpr int QA = BM / LROWS, QB = BN / LROWS;
+    static_assert(BM % LROWS == 0 && BN % LROWS == 0, "staging passes");
+    extern __shared__ __attribute__((aligned(16))) char lds[];     // [2][ A planes | B planes ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const bool loader = wave >= NMUL;                       // wave uniform
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long m0 = (long)(blockIdx.x / tiles_n) * BM;
+    const int n0 = (int)(blockIdx.x % tiles_n) * BN;
+
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk_full = (kend - kbeg) / BK;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    if (loader) {
+        // ---- staging waves: tile kt+1 is split and written while tile kt is multiplied; loads run two tiles ahead
+        const int ltid = tid - 64 * NMUL;
+        const int lrow = ltid >> 2;
+        const int lchunk = ltid & 3;
+        const int lk = lchunk * 8;
+        float4 ra[2][QA][2], rb[2][QB][2];
+        auto load_tile = [&](int kt, float4 (&a)[QA][2], float4 (&b)[QB][2]) {
+            const int k0 = kbeg + kt * BK + lk;
+#pragma unroll
+            for (int q = 0; q < QA; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) a[q][c] = ld4<true, true>(p.A, m0 + lrow + LROWS * q, p.M, p.lda, k0 + 4 * c, kend);
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) b[q][c] = ld4<true, true>(p.B, n0 + lrow + LROWS * q, p.N, p.ldb, k0 + 4 * c, kend);
+        };
+        auto load_full = [&](int kt, float4 (&a)[QA][2], float4 (&b)[QB][2]) {
+            const int k0 = kbeg + kt * BK + lk;
+#pragma unroll
+            for (int q = 0; q < QA; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) a[q][c] = ld4<true, false>(p.A, m0 + lrow + LROWS * q, p.M, p.lda, k0 + 4 * c, kend);
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) b[q][c] = ld4<true, false>(p.B, n0 + lrow + LROWS * q, p.N, p.ldb, k0 + 4 * c, kend);
+        };
+        auto store_tile = [&](int stage, const float4 (&a)[QA][2], const float4 (&b)[QB][2]) {
+            char *As = lds + stage * STAGE, *Bs = As + 3 * PA;
+#pragma unroll
+            for (int q = 0; q < QA; ++q) split8_store(a[q][0], a[q][1], As, PA, x6_off(lrow + LROWS * q, lchunk));
+#pragma unroll
+            for (int q = 0; q < QB; ++q) split8_store(b[q][0], b[q][1], Bs, PB, x6_off(lrow + LROWS * q, lchunk));
+        };
+        load_tile(0, ra[0], rb[0]);
+        if (nk > 1) load_tile(1, ra[1], rb[1]);
+        store_tile(0, ra[0], rb[0]);
+        lds_barrier();
+        int kt = 0;
+        // steady state, branch free (so that the compiler's vmcnt bookkeeping stays exact and the loads of tile
+        // kt+2 remain in flight while tile kt+1 is split): both tiles loaded in an iteration are full tiles
+        for (; kt + 3 < nk_full; kt += 2) {
+            load_full(kt + 2, ra[0], rb[0]);
+            store_tile(1, ra[1], rb[1]);
+            lds_barrier();
+            load_full(kt + 3, ra[1], rb[1]);
+            store_tile(0, ra[0], rb[0]);
+            lds_barrier();
+        }
+        for (; kt < nk; kt += 2) {
+            if (kt + 2 < nk) load_tile(kt + 2, ra[0], rb[0]);
+            if (kt + 1 < nk) store_tile(1, ra[1], rb[1]);
+            lds_barrier();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) load_tile(kt + 3, ra[1], rb[1]);
+            if (kt + 2 < nk) store_tile(0, ra[0], rb[0]);
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ---- multiplying waves (the same number of barriers as the staging waves: 1 + nk)
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto multiply = [&](int stage) {
+        const char *As = lds + stage * STAGE, *Bs = As + 3 * PA;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8_t fa[MI][3], fb[2][3];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PA + x6_off(wm * 32 * MI + i * 32 + r32, 2 * kk + h));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PB + x6_off(wn * 64 + j * 32 + r32, 2 * kk + h));
+            // the six partial products, smallest first; consecutive MFMAs go to different accumulators
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[t]], fb[j][TB[t]], acc[i][j], 0, 0, 0);
+        }
+    };
+    lds_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        multiply(kt & 1);
+        lds_barrier();
+    }
+    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
+}
+
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
             long M, int N, int K, const RowMap &map, hipStream_t st)
 {
@@ -377,7 +522,21 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     else if (native && mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
     else if (native) hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
     else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_x6_kernel<2>), grid, dim3(256), 0, st, a);
+    else if (getenv("CPC_X6_PLAIN") != nullptr) hipLaunchKernelGGL((gemm_nt_x6_kernel<2>), grid, dim3(256), 0, st, a);
+    else {
+        static const int variant = getenv("CPC_X6_VARIANT") ? atoi(getenv("CPC_X6_VARIANT")) : 0;
+        constexpr int lds_bytes = 2 * 3 * (256 + BN) * 64;
+        dim3 grid4((unsigned)(cdiv(M, 256) * cdiv(N, BN)), (unsigned)splits);
+        if (variant == 1) {
+            static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_nt_x6s_kernel<4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            CPC_CHECK_HIP(attr);
+            hipLaunchKernelGGL((gemm_nt_x6s_kernel<4, 2, 4>), grid4, dim3(512), lds_bytes, st, a);
+        } else {
+            static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_nt_x6s_kernel<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            CPC_CHECK_HIP(attr);
+            hipLaunchKernelGGL((gemm_nt_x6s_kernel<2, 4, 8>), grid4, dim3(1024), lds_bytes, st, a);
+        }
+    }
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
     return CPC_OK;
 }
