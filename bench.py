@@ -45,7 +45,7 @@ CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
 def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
     """Algorithmic FLOPs (2 per MAC) of everything that runs on gemm_nt_kernel in ONE step, and the
-    number of launches: conv1..4 forward + backward-data (s phase launches each), GRU input projection
+    number of launches: conv1..4 forward + backward-data (the s phases side by side in one launch), GRU input projection
     + its dX, predictor GEMM + its dC.  Padding / junk virtual rows are NOT counted."""
     h, n = cfg["hidden"], (b if dedup else 2 * b)
     lens = [WINDOW]
@@ -56,7 +56,7 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
         k, s, _p = CONV[i]
         conv = 2.0 * n * lens[i + 1] * k * h * h
         flops += 2 * conv                       # forward + backward-data
-        launches += 1 + s
+        launches += 2
     t_len = lens[5]
     din = h
     for _layer in range(cfg["layers"]):

@@ -86,6 +86,8 @@ struct RowMap {
     int out_off;
     int l_max;        // valid l in [0, l_max)
     int rows_out;     // output rows per group
+    int col_rows;     // > 0: output column n belongs to row l + n / col_rows (the s phases of a backward-data
+                      // product side by side: N = s * col_rows, ldc = col_rows); multiple of 32.  0: off
 };
 
 // ---- internal launchers (defined in gemm_f32.hip / rowops.hip) ----

@@ -539,15 +539,16 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         CPC_TRY(gemm_tn(e.dU + H, H, e.Y[i - 1], (long)s * H, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], e.tn,
                         e.tn_bytes, H, k, st));
 
-        // backward data, one GEMM per phase j: dY_{i-1}[n][t_hi*s + j - p] = [dU(t_hi-1), dU(t_hi)] . Bd[j]
+        // backward data: dY_{i-1}[n][t_hi*s + j - p] = [dU(t_hi-1), dU(t_hi)] . Bd[j] for the s phases j -- ONE GEMM
+        // with the phases side by side in N (Bd is [s*H][2H]); output column j*H + ci of virtual row t_hi is
+        // element ci of data row t_hi*s - p + j, i.e. the s*H outputs of a row are contiguous in dY_{i-1}
         CPC_TRY(permute_conv_dgrad(prm[4 * i], e.Wr, H, H, k, s, st));
         float *dprev = (i % 2 == 0) ? e.dYb : e.dYa;         // i=4 -> dYb, 3 -> dYa, 2 -> dYb, 1 -> dYa
-        for (int j = 0; j < s; ++j) {
+        {
             RowMap map{};
-            map.enabled = 1; map.rv = e.Rv[i]; map.out_stride = s; map.out_off = j - p;
-            map.l_max = e.L[i]; map.rows_out = e.L[i];
-            CPC_TRY(gemm_nt(e.dU, H, e.Wr + (size_t)j * H * 2 * H, 2L * H, dprev, H, nullptr, (long)N * e.Rv[i], H,
-                            2 * H, map, st));
+            map.enabled = 1; map.rv = e.Rv[i]; map.out_stride = s; map.out_off = -p;
+            map.l_max = e.L[i]; map.rows_out = e.L[i]; map.col_rows = H;
+            CPC_TRY(gemm_nt(e.dU, H, e.Wr, 2L * H, dprev, H, nullptr, (long)N * e.Rv[i], s * H, 2 * H, map, st));
         }
         dy = dprev;
     }

@@ -54,6 +54,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[M
         ncol[j] = n0 + wn * 64 + j * 32 + r32;
         bias_v[j] = (p.bias != nullptr && ncol[j] < p.N && blockIdx.y == 0) ? p.bias[ncol[j]] : 0.f;
     }
+    // column block of each 32-wide MFMA tile (backward-data phases side by side): 32 | col_rows
+    int jrow[2] = {0, 0};
+    if (p.map.enabled && p.map.col_rows > 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) jrow[j] = (n0 + wn * 64 + j * 32) / p.map.col_rows;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -61,20 +67,22 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[M
             const long m = m0 + wm * 32 * MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (m >= p.M) continue;
             long crow = m;
+            long l = 0;
             if (p.map.enabled) {
                 const long g = m / p.map.rv;
                 const int t = (int)(m - g * p.map.rv);
-                const long l = (long)t * p.map.out_stride + p.map.out_off;
-                if (l < 0 || l >= p.map.l_max) continue;
+                l = (long)t * p.map.out_stride + p.map.out_off;
                 crow = g * p.map.rows_out + l;
             }
             float *crowp = p.C + crow * p.ldc;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                if (p.map.enabled && (l + jrow[j] < 0 || l + jrow[j] >= p.map.l_max)) continue;
                 if (ncol[j] < p.N) {
                     if (gridDim.y > 1) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
                     else crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
                 }
+            }
         }
     }
 }
@@ -348,316 +356,6 @@ template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(Ge
     nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised form of gemm_nt_x6_kernel.  Measured on the kernel above: its time is the SUM of the MFMA time
-// and of everything else (loads + split + LDS traffic) -- co-resident workgroups fall into lockstep and their
-// phases never overlap.  Here the overlap is built in: 8 waves per workgroup, waves 0-3 only multiply (64x64 each,
-// from LDS stage kt % 2), waves 4-7 only stage (global loads two tiles ahead, split, write stage (kt+1) % 2);
-// one barrier per K step.  One workgroup per CU (96 KiB LDS), two waves per SIMD: one of each role.
-// Workgroup barrier that publishes LDS writes only.  __syncthreads() also drains vmcnt to 0, which would make the
-// staging waves wait at every K step for the global loads they have just issued for the tile after next.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// MI: 32-row MFMA tiles per multiplying wave; WM: multiplying waves along M (x2 along N, 64 columns each);
-// LW: staging waves.  Block tile (32*MI*WM) x 128, 64*(2*WM + LW) threads.
-template <int MI, int WM, int LW> __global__ __launch_bounds__(64 * (2 * WM + LW)) void gemm_nt_x6s_kernel(GemmNTArgs p)
-{
-    constexpr int BM = 32 * MI * WM;
-    constexpr int PA = BM * 64, PB = BN * 64;              // bytes per plane
-    constexpr int STAGE = 3 * (PA + PB);
-    constexpr int NMUL = 2 * WM;                            // multiplying waves
-    constexpr int LROWS = 16 * LW;                          // rows staged per pass
-    constexpr int QA = BM / LROWS, QB = BN / LROWS;
-    static_assert(BM % LROWS == 0 && BN % LROWS == 0, "staging passes");
-    extern __shared__ __attribute__((aligned(16))) char lds[];     // [2][ A planes | B planes ]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const bool loader = wave >= NMUL;                       // wave uniform
-    const int r32 = lane & 31, h = lane >> 5;
-
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const long m0 = (long)(blockIdx.x / tiles_n) * BM;
-    const int n0 = (int)(blockIdx.x % tiles_n) * BN;
-
-    const int kbeg = blockIdx.y * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
-    const int nk_full = (kend - kbeg) / BK;
-    const int nk = (kend - kbeg + BK - 1) / BK;
-
-    if (loader) {
-        // ---- staging waves: tile kt+1 is split and written while tile kt is multiplied; loads run two tiles ahead
-        const int ltid = tid - 64 * NMUL;
-        const int lrow = ltid >> 2;
-        const int lchunk = ltid & 3;
-        const int lk = lchunk * 8;
-        float4 ra[2][QA][2], rb[2][QB][2];
-        auto load_tile = [&](int kt, float4 (&a)[QA][2], float4 (&b)[QB][2]) {
-            const int k0 = kbeg + kt * BK + lk;
-#pragma unroll
-            for (int q = 0; q < QA; ++q)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) a[q][c] = ld4<true, true>(p.A, m0 + lrow + LROWS * q, p.M, p.lda, k0 + 4 * c, kend);
-#pragma unroll
-            for (int q = 0; q < QB; ++q)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) b[q][c] = ld4<true, true>(p.B, n0 + lrow + LROWS * q, p.N, p.ldb, k0 + 4 * c, kend);
-        };
-        auto load_full = [&](int kt, float4 (&a)[QA][2], float4 (&b)[QB][2]) {
-            const int k0 = kbeg + kt * BK + lk;
-#pragma unroll
-            for (int q = 0; q < QA; ++q)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) a[q][c] = ld4<true, false>(p.A, m0 + lrow + LROWS * q, p.M, p.lda, k0 + 4 * c, kend);
-#pragma unroll
-            for (int q = 0; q < QB; ++q)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) b[q][c] = ld4<true, false>(p.B, n0 + lrow + LROWS * q, p.N, p.ldb, k0 + 4 * c, kend);
-        };
-        auto store_tile = [&](int stage, const float4 (&a)[QA][2], const float4 (&b)[QB][2]) {
-            char *As = lds + stage * STAGE, *Bs = As + 3 * PA;
-#pragma unroll
-            for (int q = 0; q < QA; ++q) split8_store(a[q][0], a[q][1], As, PA, x6_off(lrow + LROWS * q, lchunk));
-#pragma unroll
-            for (int q = 0; q < QB; ++q) split8_store(b[q][0], b[q][1], Bs, PB, x6_off(lrow + LROWS * q, lchunk));
-        };
-        load_tile(0, ra[0], rb[0]);
-        if (nk > 1) load_tile(1, ra[1], rb[1]);
-        store_tile(0, ra[0], rb[0]);
-        lds_barrier();
-        int kt = 0;
-        // steady state, branch free (so that the compiler's vmcnt bookkeeping stays exact and the loads of tile
-        // kt+2 remain in flight while tile kt+1 is split): both tiles loaded in an iteration are full tiles
-        for (; kt + 3 < nk_full; kt += 2) {
-            load_full(kt + 2, ra[0], rb[0]);
-            store_tile(1, ra[1], rb[1]);
-            lds_barrier();
-            load_full(kt + 3, ra[1], rb[1]);
-            store_tile(0, ra[0], rb[0]);
-            lds_barrier();
-        }
-        for (; kt < nk; kt += 2) {
-            if (kt + 2 < nk) load_tile(kt + 2, ra[0], rb[0]);
-            if (kt + 1 < nk) store_tile(1, ra[1], rb[1]);
-            lds_barrier();
-            if (kt + 1 >= nk) break;
-            if (kt + 3 < nk) load_tile(kt + 3, ra[1], rb[1]);
-            if (kt + 2 < nk) store_tile(0, ra[0], rb[0]);
-            lds_barrier();
-        }
-        return;
-    }
-
-    // ---- multiplying waves (the same number of barriers as the staging waves: 1 + nk)
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    auto multiply = [&](int stage) {
-        const char *As = lds + stage * STAGE, *Bs = As + 3 * PA;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8_t fa[MI][3], fb[2][3];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PA + x6_off(wm * 32 * MI + i * 32 + r32, 2 * kk + h));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PB + x6_off(wn * 64 + j * 32 + r32, 2 * kk + h));
-            // the six partial products, smallest first; consecutive MFMAs go to different accumulators
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[t]], fb[j][TB[t]], acc[i][j], 0, 0, 0);
-        }
-    };
-    lds_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-        multiply(kt & 1);
-        lds_barrier();
-    }
-    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
-}
-
-// Global loads the compiler does not see, for the staging waves.  Its own s_waitcnt insertion loses count at the
-// first branch in the loop and then drains vmcnt to 0 before every split -- i.e. waits for the loads issued a few
-// instructions earlier.  With these, the wave waits explicitly (vm_wait<N>: until all but the N youngest loads have
-// returned; loads return in order), and the "+v" operands pin the consumers behind the wait.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gload16(f32x4_t &dst, const float *ptr)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
-}
-template <int N> __device__ __forceinline__ void vm_wait(f32x4_t &a, f32x4_t &b, f32x4_t &c, f32x4_t &d, f32x4_t &e, f32x4_t &f)
-{
-    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
-}
-__device__ __forceinline__ const float *row_ptr(const float *base, long row, long row_max, long ld, int k)
-{
-    return base + (row < row_max ? row : row_max - 1) * ld + k;
-}
-__device__ __forceinline__ float4 as_float4(const f32x4_t &v) { return make_float4(v[0], v[1], v[2], v[3]); }
-
-// ------------------------------------------------------------------------------------------------
-// Window form of the specialised kernel, for the strided-convolution products where row m of A is the window
-// [m*lda, m*lda + 2*lda) of one signal (K == 2*lda: kernel size = 2 x stride, every Conv1d after the first and
-// every backward-data phase).  Row m+1's first half IS row m's second half, so the signal S (rows of lda) is
-// staged ONCE per K block and multiplied twice:  C[m] = S[m] . B[:, 0:lda]^T + S[m+1] . B[:, lda:2lda]^T.
-// Half the global loads, splits and LDS writes of the A operand per MFMA.
-// Sub step u = (K block jb = u/2, half = u%2): multiplies rows (r + half) of S block jb (LDS buffer jb%2) with
-// the B tile of columns half*lda + 32 jb .. +31 (LDS buffer u%2).  While it runs, the staging waves write the
-// B tile of sub step u+1 and one half of S block jb+1, from registers loaded one sub step earlier.
-template <int MI, int WM, int LW> __global__ __launch_bounds__(64 * (2 * WM + LW)) void gemm_nt_x6w_kernel(GemmNTArgs p)
-{
-    constexpr int BM = 32 * MI * WM;
-    constexpr int LROWS = 16 * LW;                          // rows staged per pass
-    static_assert(BM == 2 * LROWS && BN == LROWS, "one S pass per half, one B pass per sub step");
-    constexpr int AR = BM + 16;                             // S rows held per block: BM + 1, padded
-    constexpr int PA = AR * 64, PB = BN * 64;               // bytes per plane
-    constexpr int NMUL = 2 * WM;
-    extern __shared__ __attribute__((aligned(16))) char lds[];     // S[2][3][AR][64] | B[2][3][BN][64]
-    char *const Sbuf = lds;
-    char *const Bbuf = lds + 2 * 3 * PA;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const bool loader = wave >= NMUL;                       // wave uniform
-    const int r32 = lane & 31, h = lane >> 5;
-
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const long m0 = (long)(blockIdx.x / tiles_n) * BM;
-    const int n0 = (int)(blockIdx.x % tiles_n) * BN;
-    const int Kh = p.K / 2;                                 // == lda, a multiple of BK
-    const int nkb = Kh / BK;
-    const int nsub = 2 * nkb;
-
-    if (loader) {
-        const int ltid = tid - 64 * NMUL;
-        const int lrow = ltid >> 2;
-        const int lchunk = ltid & 3;
-        const int lk = lchunk * 8;
-        // unit w (w >= 1): the B tile of sub step w and part (w+1)%2 of S block (w-1)/2 + 1; the extra S row BM
-        // rides with part 1 on the first four lanes
-        // unit w (w >= 1) = 6 loads: the B tile of sub step w (2), part (w+1)%2 of S block (w-1)/2 + 1 (2), and that
-        // block's extra row BM (2, every lane: a broadcast, so each unit is the same number of loads).  The last
-        // two units have no S block left: their S loads re-read block nkb-1 and are not stored.
-        f32x4_t rs[3][2], rx[3][2], rb[3][2];          // three units in flight
-        auto load_unit = [&](int w, f32x4_t (&s2)[2], f32x4_t (&x2)[2], f32x4_t (&b2)[2]) {
-            const int jb = w >> 1, half = w & 1;
-            const int kb = half * Kh + jb * BK + lk;
-            const int sb = min(((w - 1) >> 1) + 1, nkb - 1), part = (w + 1) & 1;
-            const int ks = sb * BK + lk;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) gload16(b2[c], row_ptr(p.B, n0 + lrow, p.N, p.ldb, kb + 4 * c));
-#pragma unroll
-            for (int c = 0; c < 2; ++c) gload16(s2[c], row_ptr(p.A, m0 + part * LROWS + lrow, p.M + 1, p.lda, ks + 4 * c));
-#pragma unroll
-            for (int c = 0; c < 2; ++c) gload16(x2[c], row_ptr(p.A, m0 + BM, p.M + 1, p.lda, ks + 4 * c));
-        };
-        auto store_unit = [&](int w, const f32x4_t (&s2)[2], const f32x4_t (&x2)[2], const f32x4_t (&b2)[2]) {
-            split8_store(as_float4(b2[0]), as_float4(b2[1]), Bbuf + (w & 1) * 3 * PB, PB, x6_off(lrow, lchunk));
-            const int sb = ((w - 1) >> 1) + 1, part = (w + 1) & 1;
-            if (sb < nkb) {
-                char *Ss = Sbuf + (sb & 1) * 3 * PA;
-                split8_store(as_float4(s2[0]), as_float4(s2[1]), Ss, PA, x6_off(part * LROWS + lrow, lchunk));
-                if (part == 1 && ltid < 4) split8_store(as_float4(x2[0]), as_float4(x2[1]), Ss, PA, x6_off(BM, lchunk));
-            }
-        };
-        // prologue: S block 0 (both parts + the extra row) and the B tile of sub step 0, then unit 1 in flight
-        {
-            f32x4_t a0[2], a1[2], ax[2], b0[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                gload16(a0[c], row_ptr(p.A, m0 + lrow, p.M + 1, p.lda, lk + 4 * c));
-                gload16(a1[c], row_ptr(p.A, m0 + LROWS + lrow, p.M + 1, p.lda, lk + 4 * c));
-                gload16(ax[c], row_ptr(p.A, m0 + BM, p.M + 1, p.lda, lk + 4 * c));
-                gload16(b0[c], row_ptr(p.B, n0 + lrow, p.N, p.ldb, lk + 4 * c));
-            }
-            load_unit(1, rs[1], rx[1], rb[1]);
-            load_unit(min(2, nsub - 1), rs[2], rx[2], rb[2]);
-            vm_wait<12>(a0[0], a0[1], a1[0], a1[1], ax[0], ax[1]);
-            vm_wait<12>(b0[0], b0[1], a1[0], a1[1], ax[0], ax[1]);
-            split8_store(as_float4(a0[0]), as_float4(a0[1]), Sbuf, PA, x6_off(lrow, lchunk));
-            split8_store(as_float4(a1[0]), as_float4(a1[1]), Sbuf, PA, x6_off(LROWS + lrow, lchunk));
-            if (ltid < 4) split8_store(as_float4(ax[0]), as_float4(ax[1]), Sbuf, PA, x6_off(BM, lchunk));
-            split8_store(as_float4(b0[0]), as_float4(b0[1]), Bbuf, PB, x6_off(lrow, lchunk));
-        }
-        lds_barrier();
-        // sub step u: the loads of unit u+3 go out (two sub steps of flight time: an L2 / HBM round trip under load is
-        // longer than one), unit u+1 is split and written.  Unit w lives in register set w % 3.  Loads are issued
-        // for every u (the last units re-read valid addresses and are dropped), so that exactly 12 younger loads
-        // are in flight at each wait.
-        auto sub_step = [&](int u, f32x4_t (&ls)[2], f32x4_t (&lx)[2], f32x4_t (&lb)[2], f32x4_t (&ss)[2], f32x4_t (&sx)[2], f32x4_t (&sb)[2]) {
-            load_unit(min(u + 3, nsub - 1), ls, lx, lb);
-            vm_wait<12>(ss[0], ss[1], sx[0], sx[1], sb[0], sb[1]);
-            if (u + 1 < nsub) store_unit(u + 1, ss, sx, sb);
-            lds_barrier();
-        };
-        for (int u = 0; u < nsub; u += 3) {
-            sub_step(u, rs[0], rx[0], rb[0], rs[1], rx[1], rb[1]);
-            if (u + 1 < nsub) sub_step(u + 1, rs[1], rx[1], rb[1], rs[2], rx[2], rb[2]);
-            if (u + 2 < nsub) sub_step(u + 2, rs[2], rx[2], rb[2], rs[0], rx[0], rb[0]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still target this wave's registers at exit
-        return;
-    }
-
-    // ---- multiplying waves: 1 + nsub barriers, like the staging waves
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    lds_barrier();
-    for (int u = 0; u < nsub; ++u) {
-        const char *As = Sbuf + ((u >> 1) & 1) * 3 * PA, *Bs = Bbuf + (u & 1) * 3 * PB;
-        const int half = u & 1;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8_t fa[MI][3], fb[2][3];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PA + x6_off(wm * 32 * MI + i * 32 + r32 + half, 2 * kk + h));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PB + x6_off(wn * 64 + j * 32 + r32, 2 * kk + h));
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[t]], fb[j][TB[t]], acc[i][j], 0, 0, 0);
-        }
-        lds_barrier();
-    }
-    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
-}
-
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
             long M, int N, int K, const RowMap &map, hipStream_t st)
 {
@@ -687,23 +385,7 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     else if (native && mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
     else if (native) hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
     else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1>), grid, dim3(256), 0, st, a);
-    else if (getenv("CPC_X6_PLAIN") != nullptr) hipLaunchKernelGGL((gemm_nt_x6_kernel<2>), grid, dim3(256), 0, st, a);
-    else {
-        static const int variant = getenv("CPC_X6_VARIANT") ? atoi(getenv("CPC_X6_VARIANT")) : 0;
-        dim3 grid4((unsigned)(cdiv(M, 256) * cdiv(N, BN)), (unsigned)splits);
-        const bool window = splits == 1 && (long)K == 2 * lda && (K / 2) % BK == 0 && variant == 0;
-        if (window) {
-            constexpr int lds_bytes = 2 * 3 * (256 + 16 + BN) * 64;
-            static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_nt_x6w_kernel<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            CPC_CHECK_HIP(attr);
-            hipLaunchKernelGGL((gemm_nt_x6w_kernel<2, 4, 8>), grid4, dim3(1024), lds_bytes, st, a);
-        } else {
-            constexpr int lds_bytes = 2 * 3 * (256 + BN) * 64;
-            static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_nt_x6s_kernel<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            CPC_CHECK_HIP(attr);
-            hipLaunchKernelGGL((gemm_nt_x6s_kernel<2, 4, 8>), grid4, dim3(1024), lds_bytes, st, a);
-        }
-    }
+    else hipLaunchKernelGGL((gemm_nt_x6_kernel<2>), grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
     return CPC_OK;
 }
