@@ -100,13 +100,15 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
 
 // out[c] = sum_r part[r*ld + c]
 int colsum(const float *part, long rows, long ld, int width, float *out, hipStream_t st);
+// two-stage form for tall partial matrices; column c goes to outs[c / seg][c % seg] (up to three outputs)
+constexpr int COLSUM_SPLIT = 32;
+size_t colsum_split_scratch_bytes(int width);
+int colsum_split(const float *part, long rows, long ld, int width, float *out0, float *out1, float *out2, int seg,
+                 void *scratch, hipStream_t st);
 // column sums of a [rows][width] matrix with row stride ld (two-stage; scratch >= colsum_scratch_bytes)
 size_t colsum_rows_scratch_bytes(int width);
 int colsum_rows(const float *a, long ld, long rows, int width, float *out, void *scratch, hipStream_t st);
 
-// weight re-layouts
-int permute_conv_fwd(const float *w, float *wr, int cout, int cin, int k, hipStream_t st);          // [co][j*cin+ci]
-int permute_conv_dgrad(const float *w, float *bd, int cout, int cin, int k, int s, hipStream_t st); // [j][ci][2*cout]
 int transpose2d(const float *a, float *at, int rows, int cols, hipStream_t st);                      // at[c][r]=a[r][c]
 
 }  // namespace cpc

@@ -169,9 +169,22 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
         }
 
     constexpr int ROWS_PER_PASS = 4 * RPW;
+    // the dy row and the statistics of pass it+1 are requested before pass it is worked on: with two or three
+    // waves per SIMD nothing else hides the HBM round trip of a load that is consumed right away
+    float4 gnext[VPL];
+    float mean_next = 0.f, rstd_next = 0.f;
+    auto request = [&](int n, int t) {
+        const bool ok = t < a.L1;
+        const long row = (long)n * a.L1 + (ok ? t : 0);
+        mean_next = a.stats[row * 2 + 0];
+        rstd_next = ok ? a.stats[row * 2 + 1] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) gnext[v] = reinterpret_cast<const float4 *>(a.dy + row * H)[v * G + gl];
+    };
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int n = tile / a.tiles_per_sample;
         const int t0 = (tile - n * a.tiles_per_sample) * C0_TB;
+        request(n, t0 + wave * RPW + gi);
         __syncthreads();
         conv0_load_segment<H>(xs, a, n, t0);
         __syncthreads();
@@ -182,19 +195,16 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
             float xr[C0_K];
 #pragma unroll
             for (int j = 0; j < C0_K; ++j) xr[j] = xs[C0_S * slot + j];
-            float mean = 0.f, rstd = 0.f;
-            if (valid) {
-                mean = a.stats[((long)n * a.L1 + t) * 2 + 0];
-                rstd = a.stats[((long)n * a.L1 + t) * 2 + 1];
-            }
-            const float *dyrow = a.dy + ((long)n * a.L1 + (valid ? t : 0)) * H;
+            const float mean = mean_next, rstd = rstd_next;     // rstd = 0 on rows past the end: du = 0 there
+            float4 gcur[VPL];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) gcur[v] = valid ? gnext[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it + 1 < C0_TB / ROWS_PER_PASS) request(n, t + ROWS_PER_PASS);
             float xh[VPL][4], gx[VPL][4];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
-                float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) g4 = reinterpret_cast<const float4 *>(dyrow)[v * G + gl];
-                const float gy[4] = {g4.x, g4.y, g4.z, g4.w};
+                const float gy[4] = {gcur[v].x, gcur[v].y, gcur[v].z, gcur[v].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float acc = breg[v][e];
@@ -225,19 +235,26 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
         }
     }
 
-    const int slot_id = (blockIdx.x * 4 + wave) * RPW + gi;
-    float *pp = a.part + (long)slot_id * 13 * H;
+    // block-level sum of the 4*RPW lane groups' partials, one row of part[] per block; the groups take turns on one
+    // 13 H float LDS row (a [groups][13 H] array would cost a workgroup per CU)
+    __shared__ float red[13 * H];
+    for (int turn = 0; turn < 4 * RPW; ++turn) {
+        if (turn == wave * RPW + gi) {
 #pragma unroll
-    for (int v = 0; v < VPL; ++v)
+            for (int v = 0; v < VPL; ++v)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = (v * G + gl) * 4 + e;
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (v * G + gl) * 4 + e;
 #pragma unroll
-            for (int j = 0; j < C0_K; ++j) pp[j * H + c] = dwacc[v][e][j];
-            pp[10 * H + c] = dbacc[v][e];
-            pp[11 * H + c] = dgacc[v][e];
-            pp[12 * H + c] = dbeacc[v][e];
+                    for (int j = 0; j < C0_K; ++j) red[j * H + c] = (turn ? red[j * H + c] : 0.f) + dwacc[v][e][j];
+                    red[10 * H + c] = (turn ? red[10 * H + c] : 0.f) + dbacc[v][e];
+                    red[11 * H + c] = (turn ? red[11 * H + c] : 0.f) + dgacc[v][e];
+                    red[12 * H + c] = (turn ? red[12 * H + c] : 0.f) + dbeacc[v][e];
+                }
         }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < 13 * H; c += 256) a.part[(long)blockIdx.x * 13 * H + c] = red[c];
 }
 
 // sums[13][H] -> conv0.weight grad [H][1][10], bias grad, norm weight/bias grads
@@ -342,7 +359,8 @@ template <int H> __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs
             bet[v][e] = a.beta[(v * G + gl) * 4 + e];
             dg[v][e] = dbe[v][e] = dbi[v][e] = 0.f;
         }
-    const long total = (long)a.N * a.Rv + 1;                 // rows of dU
+    const long total = (long)a.N * a.Rv + 2;                 // rows of dU, + one zero row: the weight-gradient GEMM
+                                                             // (A(m) = dU + (m+1) H) and backward-data (rows m, m+1) read it
     const long stride = (long)gridDim.x * 4 * RPW;
     for (long base = (long)blockIdx.x * 4 * RPW; base < total; base += stride) {
         const long row = base + wave * RPW + gi;
@@ -390,17 +408,60 @@ template <int H> __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs
             reinterpret_cast<float4 *>(durow)[v * G + gl] = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
-    const int slot_id = (blockIdx.x * 4 + wave) * RPW + gi;
-    float *pp = a.part + (long)slot_id * 3 * H;
+    // block-level sum of the 4*RPW lane groups' partials, one row of part[] per block
+    __shared__ float red[4 * RPW][3 * H];
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = (v * G + gl) * 4 + e;
-            pp[c] = dg[v][e];
-            pp[H + c] = dbe[v][e];
-            pp[2 * H + c] = dbi[v][e];
+            red[wave * RPW + gi][c] = dg[v][e];
+            red[wave * RPW + gi][H + c] = dbe[v][e];
+            red[wave * RPW + gi][2 * H + c] = dbi[v][e];
         }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * H; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * RPW; ++i) t += red[i][c];
+        a.part[(long)blockIdx.x * 3 * H + c] = t;
+    }
+}
+
+// Every Conv1d weight re-layout of a step in one launch (blockIdx.y = layer - 1, blockIdx.z = 0 forward operand
+// wf[co][j*H + ci], 1 backward-data operand bd[j][ci][kk] -- see rowops.hip permute_conv_*), H x H x k each.
+struct PermuteAll { const float *w[4]; float *wf[4]; float *wd[4]; int k[4]; int s[4]; int H; };
+__global__ void permute_conv_all_kernel(PermuteAll a)
+{
+    const int li = blockIdx.y, H = a.H, k = a.k[li], s = a.s[li];
+    const float *w = a.w[li];
+    const long total = (long)H * H * k;
+    if (blockIdx.z == 0) {
+        float *wr = a.wf[li];
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const int co = (int)(idx / ((long)H * k));
+            const int rem = (int)(idx - (long)co * H * k);
+            const int j = rem / H, ci = rem - j * H;
+            wr[idx] = w[((long)co * H + ci) * k + j];
+        }
+    } else {
+        float *bd = a.wd[li];
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const int kk = (int)(idx % (2 * H));
+            const long r = idx / (2 * H);
+            const int ci = (int)(r % H);
+            const int j = (int)(r / H);
+            const int co = kk < H ? kk : kk - H;
+            const int tap = kk < H ? j + s : j;
+            bd[idx] = w[((long)co * H + ci) * k + tap];
+        }
+    }
+}
+
+struct ZeroTails { float *p[4]; int n[4]; };
+__global__ void zero_tails_kernel(ZeroTails z)
+{
+    for (int i = threadIdx.x; i < z.n[blockIdx.x]; i += blockDim.x) z.p[blockIdx.x][i] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,16 +475,17 @@ struct EncLayout {
     float *Xh[5];    // index 1..4
     float *rstd[5];  // index 1..4
     float *stats0;
+    float *Wd[5];    // index 1..4: backward-data operand of layer i, [s*H][2H] (laid out by the forward pass)
     size_t saved_bytes;
     // scratch
-    float *Wr;       // permuted weights (fwd operand) / dgrad operand
-    float *dYa, *dYb, *dU, *part, *sums, *tn;
+    float *Wf[5];    // index 1..4: forward GEMM operand of layer i, [H][k*H]
+    float *dYa, *dYb, *dU, *part, *sums, *cs, *tn;
     size_t tn_bytes;
     size_t scratch_bytes;
 };
 
-constexpr int NORM_BWD_BLOCKS = 256;
-constexpr int CONV0_BWD_BLOCKS = 512;
+constexpr int NORM_BWD_BLOCKS = 2048;   // 8 per CU: the row loop is a load -> use chain, only occupancy hides its latency
+constexpr int CONV0_BWD_BLOCKS = 768;
 
 static bool supported_hidden(int H) { return H == 32 || H == 64 || H == 128 || H == 256 || H == 512; }
 
@@ -449,18 +511,20 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
         e.rstd[i] = sv.take<float>((size_t)N * e.Rv[i]);
     }
     e.stats0 = sv.take<float>((size_t)N * e.L[1] * 2);
+    e.Wd[0] = nullptr;
+    for (int i = 1; i < 5; ++i) e.Wd[i] = sv.take<float>((size_t)kConv[i].k * H * H);
     e.saved_bytes = sv.used();
 
     Carver sc(scratch);
-    e.Wr = sc.take<float>((size_t)8 * H * H);                         // max k*H*H (k = 8) == s*H*2H (s = 4)
+    e.Wf[0] = nullptr;
+    for (int i = 1; i < 5; ++i) e.Wf[i] = sc.take<float>((size_t)kConv[i].k * H * H);
     e.dYa = sc.take<float>((size_t)N * e.L[1] * H);
     e.dYb = sc.take<float>((size_t)N * e.L[2] * H);
     e.dU = sc.take<float>(((size_t)N * e.Rv[1] + 2) * H);
-    const size_t rpw = 64 / std::min(64, H / 4);            // lane groups (rows) per wave
-    const size_t part_floats = std::max((size_t)CONV0_BWD_BLOCKS * 4 * rpw * 13 * H,
-                                        (size_t)NORM_BWD_BLOCKS * 4 * rpw * 3 * H);
+    const size_t part_floats = std::max((size_t)CONV0_BWD_BLOCKS * 13 * H, (size_t)NORM_BWD_BLOCKS * 3 * H);
     e.part = sc.take<float>(part_floats);
     e.sums = sc.take<float>((size_t)13 * H);
+    e.cs = sc.take<float>(colsum_split_scratch_bytes(13 * H) / sizeof(float));
     e.tn_bytes = 0;
     for (int i = 1; i < 5; ++i)
         e.tn_bytes = std::max(e.tn_bytes, gemm_tn_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]));
@@ -488,13 +552,25 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
     }
     CPC_CHECK_LAUNCH("conv0_fwd_kernel");
 
+    // slack rows after each Y_{i-1}: read by junk GEMM rows and by the weight-gradient GEMM -> must be finite
+    {
+        ZeroTails zt{};
+        for (int i = 1; i < 5; ++i) { zt.p[i - 1] = e.Y[i - 1] + (size_t)N * e.R[i - 1] * H; zt.n[i - 1] = kConv[i].k * H; }
+        hipLaunchKernelGGL(zero_tails_kernel, dim3(4), dim3(256), 0, st, zt);
+        CPC_CHECK_LAUNCH("zero_tails_kernel");
+        PermuteAll pa{};
+        pa.H = H;
+        for (int i = 1; i < 5; ++i) {
+            CPC_REQUIRE(kConv[i].k == 2 * kConv[i].s, "encoder: layer %d needs kernel == 2 * stride", i);
+            pa.w[i - 1] = prm[4 * i]; pa.wf[i - 1] = e.Wf[i]; pa.wd[i - 1] = e.Wd[i]; pa.k[i - 1] = kConv[i].k; pa.s[i - 1] = kConv[i].s;
+        }
+        hipLaunchKernelGGL(permute_conv_all_kernel, dim3(256, 4, 2), dim3(256), 0, st, pa);
+        CPC_CHECK_LAUNCH("permute_conv_all_kernel");
+    }
     for (int i = 1; i < 5; ++i) {
         const int k = kConv[i].k, s = kConv[i].s;
-        // slack rows after Y_{i-1}: read by junk GEMM rows and by the weight-gradient GEMM -> must be finite
-        CPC_CHECK_HIP(hipMemsetAsync(e.Y[i - 1] + (size_t)N * e.R[i - 1] * H, 0, sizeof(float) * k * H, st));
-        CPC_TRY(permute_conv_fwd(prm[4 * i], e.Wr, H, H, k, st));
         RowMap none{};
-        CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wr, (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
+        CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wf[i], (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
                         k * H, none, st));
         NormArgs na{};
         na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
@@ -515,7 +591,6 @@ static int encoder_backward(const float *x, const float *const *prm, const float
 {
     EncLayout e;
     CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
-    const int rpw = 64 / std::min(64, H / 4);
 
     const float *dy = dz;                  // [N][L[i+1]][H] of the current layer
     for (int i = 4; i >= 1; --i) {
@@ -527,13 +602,8 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         na.dy = dy; na.du = e.dU; na.part = e.part;
         CPC_DISPATCH_H(H, hipLaunchKernelGGL(norm_bwd_kernel<HH>, dim3(NORM_BWD_BLOCKS), dim3(256), 0, st, na));
         CPC_CHECK_LAUNCH("norm_bwd_kernel");
-        // the row after the last one is read by the weight-gradient GEMM (A(m) = dU + (m+1)H, m+1 <= N*Rv)
-        // and by backward-data (rows m, m+1); row N*Rv is written (zero) by the kernel, one more for safety:
-        CPC_CHECK_HIP(hipMemsetAsync(e.dU + ((size_t)N * e.Rv[i] + 1) * H, 0, sizeof(float) * H, st));
-        const long slots = (long)NORM_BWD_BLOCKS * 4 * rpw;
-        CPC_TRY(colsum(e.part, slots, 3L * H, H, grads[4 * i + 2], st));            // dgamma
-        CPC_TRY(colsum(e.part + H, slots, 3L * H, H, grads[4 * i + 3], st));        // dbeta
-        CPC_TRY(colsum(e.part + 2 * H, slots, 3L * H, H, grads[4 * i + 1], st));    // conv bias
+        // part[block][dgamma | dbeta | dbias] -> the three gradients
+        CPC_TRY(colsum_split(e.part, NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1], H, e.cs, st));
 
         // weight gradient: dW[co][j*H+ci] = sum_m dU(m)[co] * Y_{i-1}(m)[j*H+ci]
         CPC_TRY(gemm_tn(e.dU + H, H, e.Y[i - 1], (long)s * H, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], e.tn,
@@ -542,13 +612,13 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         // backward data: dY_{i-1}[n][t_hi*s + j - p] = [dU(t_hi-1), dU(t_hi)] . Bd[j] for the s phases j -- ONE GEMM
         // with the phases side by side in N (Bd is [s*H][2H]); output column j*H + ci of virtual row t_hi is
         // element ci of data row t_hi*s - p + j, i.e. the s*H outputs of a row are contiguous in dY_{i-1}
-        CPC_TRY(permute_conv_dgrad(prm[4 * i], e.Wr, H, H, k, s, st));
+        // (Bd = e.Wd[i] was laid out by the forward pass)
         float *dprev = (i % 2 == 0) ? e.dYb : e.dYa;         // i=4 -> dYb, 3 -> dYa, 2 -> dYb, 1 -> dYa
         {
             RowMap map{};
             map.enabled = 1; map.rv = e.Rv[i]; map.out_stride = s; map.out_off = -p;
             map.l_max = e.L[i]; map.rows_out = e.L[i]; map.col_rows = H;
-            CPC_TRY(gemm_nt(e.dU, H, e.Wr, 2L * H, dprev, H, nullptr, (long)N * e.Rv[i], s * H, 2 * H, map, st));
+            CPC_TRY(gemm_nt(e.dU, H, e.Wd[i], 2L * H, dprev, H, nullptr, (long)N * e.Rv[i], s * H, 2 * H, map, st));
         }
         dy = dprev;
     }
@@ -565,7 +635,7 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         CPC_DISPATCH_H(H, hipLaunchKernelGGL(conv0_bwd_kernel<HH>, dim3(CONV0_BWD_BLOCKS), dim3(256), 0, st, c0));
     }
     CPC_CHECK_LAUNCH("conv0_bwd_kernel");
-    CPC_TRY(colsum(e.part, (long)CONV0_BWD_BLOCKS * 4 * rpw, 13L * H, 13 * H, e.sums, st));
+    CPC_TRY(colsum_split(e.part, CONV0_BWD_BLOCKS, 13L * H, 13 * H, e.sums, e.sums + 13 * H, e.sums + 13 * H, 13 * H, e.cs, st));
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), 0, st, e.sums, grads[0], grads[1],
                        grads[2], grads[3], H);
     CPC_CHECK_LAUNCH("conv0_finalize_kernel");

@@ -82,15 +82,79 @@ int colsum(const float *part, long rows, long ld, int width, float *out, hipStre
     return CPC_OK;
 }
 
-constexpr int CS_BLOCKS = 256;
+// Two-stage column sums for tall partial-sum matrices: stage 1 spreads the rows over COLSUM_SPLIT x (width/64)
+// blocks, stage 2 adds the COLSUM_SPLIT partial rows and scatters column c to outs[c / seg][c % seg] (the
+// gamma / beta / bias gradients of a layer leave one partial matrix for three different tensors).
+__global__ void colsum_stage1_kernel(const float *part, long rows, long ld, int width, float *scratch)
+{
+    __shared__ float red[16][65];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (c < width) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const long step = (long)gridDim.y * 16;
+        long r = (long)blockIdx.y * 16 + threadIdx.y;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            s0 += part[r * ld + c];
+            s1 += part[(r + step) * ld + c];
+            s2 += part[(r + 2 * step) * ld + c];
+            s3 += part[(r + 3 * step) * ld + c];
+        }
+        for (; r < rows; r += step) s0 += part[r * ld + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+        scratch[(long)blockIdx.y * width + c] = t;
+    }
+}
 
-// stage 1: block b sums rows b, b+CS_BLOCKS, ... ; threads over columns (coalesced)
+__global__ void colsum_stage2_kernel(const float *scratch, int split, int width, float *out0, float *out1, float *out2, int seg)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float t = 0.f;
+    for (int i = 0; i < split; ++i) t += scratch[(long)i * width + c];
+    const int which = c / seg, off = c - which * seg;
+    float *out = which == 0 ? out0 : (which == 1 ? out1 : out2);
+    out[off] = t;
+}
+
+size_t colsum_split_scratch_bytes(int width) { return align_up((size_t)COLSUM_SPLIT * width * sizeof(float), 256); }
+
+int colsum_split(const float *part, long rows, long ld, int width, float *out0, float *out1, float *out2, int seg,
+                 void *scratch, hipStream_t st)
+{
+    CPC_REQUIRE(seg > 0 && width <= 3 * seg, "colsum_split: width %d does not fit three segments of %d", width, seg);
+    float *sc = static_cast<float *>(scratch);
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)cdiv(width, 64), COLSUM_SPLIT), dim3(64, 16), 0, st, part, rows, ld, width, sc);
+    CPC_CHECK_LAUNCH("colsum_stage1_kernel");
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)cdiv(width, 256)), dim3(256), 0, st, sc, COLSUM_SPLIT, width, out0, out1, out2, seg);
+    CPC_CHECK_LAUNCH("colsum_stage2_kernel");
+    return CPC_OK;
+}
+
+constexpr int CS_BLOCKS = 1024;
+
+// stage 1: block b sums rows b, b+CS_BLOCKS, ... ; threads over columns (coalesced), four independent chains
 __global__ void colsum_rows_stage1(const float *a, long ld, long rows, int width, float *part)
 {
+    const long step = gridDim.x;
     for (int c = threadIdx.x; c < width; c += blockDim.x) {
-        float s = 0.f;
-        for (long r = blockIdx.x; r < rows; r += gridDim.x) s += a[r * ld + c];
-        part[(long)blockIdx.x * width + c] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long r = blockIdx.x;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            s0 += a[r * ld + c];
+            s1 += a[(r + step) * ld + c];
+            s2 += a[(r + 2 * step) * ld + c];
+            s3 += a[(r + 3 * step) * ld + c];
+        }
+        for (; r < rows; r += step) s0 += a[r * ld + c];
+        part[(long)blockIdx.x * width + c] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -104,53 +168,7 @@ int colsum_rows(const float *a, long ld, long rows, int width, float *out, void 
     return colsum(part, CS_BLOCKS, width, width, out, st);
 }
 
-// ---------------------------------------------------------------- weight re-layouts
-// Conv1d weight w[co][ci][j] -> wr[co][j*cin + ci]  (the B operand of the implicit GEMM)
-__global__ void permute_conv_fwd_kernel(const float *w, float *wr, int cout, int cin, int k)
-{
-    const long total = (long)cout * cin * k;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(idx / ((long)cin * k));
-        const int rem = (int)(idx - (long)co * cin * k);
-        const int j = rem / cin, ci = rem - j * cin;
-        wr[idx] = w[((long)co * cin + ci) * k + j];
-    }
-}
-
-int permute_conv_fwd(const float *w, float *wr, int cout, int cin, int k, hipStream_t st)
-{
-    const long total = (long)cout * cin * k;
-    hipLaunchKernelGGL(permute_conv_fwd_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, w, wr, cout, cin, k);
-    CPC_CHECK_LAUNCH("permute_conv_fwd_kernel");
-    return CPC_OK;
-}
-
-// Backward-data operand, kernel k == 2*s: for phase j in [0,s):
-//   bd[j][ci][kk] = w[kk][ci][j+s]        for kk <  cout   (pairs with du[t_hi-1])
-//                 = w[kk-cout][ci][j]      for kk >= cout   (pairs with du[t_hi])
-__global__ void permute_conv_dgrad_kernel(const float *w, float *bd, int cout, int cin, int k, int s)
-{
-    const long total = (long)s * cin * 2 * cout;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int kk = (int)(idx % (2 * cout));
-        const long r = idx / (2 * cout);
-        const int ci = (int)(r % cin);
-        const int j = (int)(r / cin);
-        const int co = kk < cout ? kk : kk - cout;
-        const int tap = kk < cout ? j + s : j;
-        bd[idx] = w[((long)co * cin + ci) * k + tap];
-    }
-}
-
-int permute_conv_dgrad(const float *w, float *bd, int cout, int cin, int k, int s, hipStream_t st)
-{
-    CPC_REQUIRE(k == 2 * s, "permute_conv_dgrad needs kernel == 2*stride (got k=%d s=%d)", k, s);
-    const long total = (long)s * cin * 2 * cout;
-    hipLaunchKernelGGL(permute_conv_dgrad_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, w, bd, cout, cin, k, s);
-    CPC_CHECK_LAUNCH("permute_conv_dgrad_kernel");
-    return CPC_OK;
-}
-
+// ---------------------------------------------------------------- transposes
 __global__ void transpose2d_kernel(const float *a, float *at, int rows, int cols)
 {
     __shared__ float tile[32][33];
