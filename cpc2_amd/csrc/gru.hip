@@ -257,16 +257,23 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
     }
     __syncthreads();
 
+    const int ns = n0 + q;
+    const bool mine = q < NB && ns < a.N;
+    float gin0 = 0.f, gin1 = 0.f, gin2 = 0.f;
+    if (mine) {
+        const float *gp = a.gi + (long)ns * T * 3 * H;
+        gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j];
+    }
     bool dead = false;
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        // this lane finishes sample q (if q < NB): fetch its input projections early
-        const int ns = n0 + q;
-        const bool mine = q < NB && ns < a.N;
-        float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f;
-        if (mine) {
-            const float *gp = a.gi + ((long)ns * T + t) * 3 * H;
-            gi0 = gp[j]; gi1 = gp[H + j]; gi2 = gp[2 * H + j];
+        // this lane finishes sample q (if q < NB); its input projections were requested one step ago, the next
+        // step's are requested now: a load consumed in the step that issues it puts an L2/HBM round trip on the
+        // serial path of every time step
+        const float gi0 = gin0, gi1 = gin1, gi2 = gin2;
+        if (mine && t + 1 < T) {
+            const float *gp = a.gi + ((long)ns * T + t + 1) * 3 * H;
+            gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j];
         }
         float acc[NB][3];
 #pragma unroll
@@ -299,6 +306,11 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
             const float c = tanhf(gi2 + r * g2);
             float hv = (1.f - z) * c + z * hp;
             if (dead) hv = NAN;
+            // publish first (also for padding windows, so that every granule of the epoch gets written): the other
+            // members wait for this store, nobody waits for the saved activations below
+            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
+            __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine) {
                 const long row = (long)ns * T + t;
                 float *gs = a.gates + row * 3 * H;
@@ -307,10 +319,6 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
                 a.out[row * H + j] = hv;
                 a.hall[((long)ns * (T + 1) + t + 1) * H + j] = hv;
             }
-            // publish (also for padding windows, so that every granule of the epoch gets written)
-            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
-            __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // gather the whole new h (all four members) into the other LDS buffer
         if (t + 1 < T) {
@@ -375,6 +383,17 @@ template <int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(Gru
         float *zr = a.dgh + ((long)en * (T + 1) + T) * 3 * H;
         zr[ej] = 0.f; zr[H + ej] = 0.f; zr[2 * H + ej] = 0.f;
     }
+    // the saved activations of step t-1 are requested while step t runs (same reason as in the forward kernel)
+    float p_dout = 0.f, p_r = 0.f, p_z = 0.f, p_c = 0.f, p_hn = 0.f, p_hp = 0.f;
+    auto request = [&](int t) {
+        const long row = (long)en * T + t;
+        const float *gs = a.gates + row * 3 * H;
+        p_dout = a.dout[row * H + ej];
+        p_r = gs[ej]; p_z = gs[H + ej]; p_c = gs[2 * H + ej];
+        p_hn = a.hn[row * H + ej];
+        p_hp = a.hall[((long)en * (T + 1) + t) * H + ej];
+    };
+    if (emine) request(T - 1);
     bool dead = false;
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
@@ -384,11 +403,11 @@ template <int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(Gru
             float dpr = 0.f, dpz = 0.f, dhn = 0.f;
             if (emine) {
                 const long row = (long)en * T + t;
-                const float dh = a.dout[row * H + ej] + carry;
-                const float *gs = a.gates + row * 3 * H;
-                const float r = gs[ej], z = gs[H + ej], c = gs[2 * H + ej];
-                const float hnv = a.hn[row * H + ej];
-                const float hp_ = a.hall[((long)en * (T + 1) + t) * H + ej];
+                const float dh = p_dout + carry;
+                const float r = p_r, z = p_z, c = p_c;
+                const float hnv = p_hn;
+                const float hp_ = p_hp;
+                if (t > 0) request(t - 1);
                 const float dc = dh * (1.f - z);
                 const float dz = dh * (hp_ - c);
                 const float dpn = dc * (1.f - c * c);
@@ -432,21 +451,27 @@ template <int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(Gru
             }
             if (ew) {
                 float sum = keep + part[0][es][ej] + part[1][es][ej];
+                // the three partners' pieces are polled together: one L2 round trip per attempt, not three in a row
+                COOP_GLOBAL gu64_t *slot[COOP_G - 1];
 #pragma unroll
                 for (int d = 1; d < COOP_G; ++d) {
                     const int src = (member + d) & (COOP_G - 1);
-                    COOP_GLOBAL gu64_t *slot =
-                        (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * COOP_G + src) * NB + es) * H + ej);
-                    gu64_t x = 0;
-                    unsigned spins = dead ? (1u << 22) : 0u;
-                    for (;;) {
-                        x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(x >> 32) == epoch) break;
-                        if (++spins > (1u << 22)) { dead = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    sum += __uint_as_float((unsigned)x);
+                    slot[d - 1] = (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * COOP_G + src) * NB + es) * H + ej);
                 }
+                gu64_t x[COOP_G - 1];
+                unsigned spins = dead ? (1u << 22) : 0u;
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int d = 0; d < COOP_G - 1; ++d) x[d] = __hip_atomic_load(slot[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int d = 0; d < COOP_G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
+                    if (ready) break;
+                    if (++spins > (1u << 22)) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int d = 0; d < COOP_G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
                 carry = sum;
             }
             dead = __syncthreads_or(dead);
