@@ -88,6 +88,9 @@ struct RowMap {
     int rows_out;     // output rows per group
     int col_rows;     // > 0: output column n belongs to row l + n / col_rows (the s phases of a backward-data
                       // product side by side: N = s * col_rows, ldc = col_rows); multiple of 32.  0: off
+    // independent of `enabled`: M is made of segments of seg_rows virtual rows of which only the first seg_valid
+    // need computing (a sample's trailing junk rows); the split kernels then tile each segment separately
+    int seg_rows, seg_valid;
 };
 
 // ---- internal launchers (defined in gemm_f32.hip / rowops.hip) ----

@@ -569,9 +569,10 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
     }
     for (int i = 1; i < 5; ++i) {
         const int k = kConv[i].k, s = kConv[i].s;
-        RowMap none{};
+        RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk
+        vrows.seg_rows = e.Rv[i]; vrows.seg_valid = e.L[i + 1];
         CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wf[i], (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
-                        k * H, none, st));
+                        k * H, vrows, st));
         NormArgs na{};
         na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
         na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;

@@ -40,32 +40,33 @@ struct GemmNTArgs {
     RowMap map;
     int aligned;   // K%4==0, lda%4==0, ldb%4==0, bases 16-B aligned
     int kchunk;    // K range per blockIdx.y (multiple of BK); gridDim.y > 1: partial products are atomically added
+    // segmented rows (x6 kernels): M = segments of seg_rows rows of which the first seg_valid are computed, tiles
+    // never straddle a segment (the junk virtual rows of a sample are then never multiplied).  seg_rows = 0: off
+    int seg_rows, seg_valid;
 };
 
 // acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
 // (the C/D layout of every 32x32 MFMA on gfx950, f32- and bf16-input alike)
-template <int MI>
-__device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[MI][2], long m0, int n0, int wm, int wn, int r32, int h)
+template <int MI, int NJ>
+__device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[MI][NJ], long m0, long m_end, int n0, int wm, int wn, int r32, int h)
 {
-    float bias_v[2];
-    int ncol[2];
+    float bias_v[NJ];
+    int ncol[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        ncol[j] = n0 + wn * 64 + j * 32 + r32;
+    for (int j = 0; j < NJ; ++j) {
+        ncol[j] = n0 + wn * 32 * NJ + j * 32 + r32;
         bias_v[j] = (p.bias != nullptr && ncol[j] < p.N && blockIdx.y == 0) ? p.bias[ncol[j]] : 0.f;
     }
     // column block of each 32-wide MFMA tile (backward-data phases side by side): 32 | col_rows
-    int jrow[2] = {0, 0};
-    if (p.map.enabled && p.map.col_rows > 0) {
+    int jrow[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) jrow[j] = (n0 + wn * 64 + j * 32) / p.map.col_rows;
-    }
+    for (int j = 0; j < NJ; ++j) jrow[j] = (p.map.enabled && p.map.col_rows > 0) ? (n0 + wn * 32 * NJ + j * 32) / p.map.col_rows : 0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long m = m0 + wm * 32 * MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= p.M) continue;
+            if (m >= m_end) continue;
             long crow = m;
             long l = 0;
             if (p.map.enabled) {
@@ -76,7 +77,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[M
             }
             float *crowp = p.C + crow * p.ldc;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (p.map.enabled && (l + jrow[j] < 0 || l + jrow[j] >= p.map.l_max)) continue;
                 if (ncol[j] < p.N) {
                     if (gridDim.y > 1) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
@@ -206,7 +207,7 @@ template <bool ALIGNED, int MI> __global__ __launch_bounds__(256, 3) void gemm_n
         __syncthreads();
     }
 
-    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
+    nt_epilogue<MI, 2>(p, acc, m0, p.M, n0, wm, wn, r32, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,13 +257,16 @@ __device__ __forceinline__ void split8_store(const float4 &u, const float4 &v, c
 
 __device__ __forceinline__ int x6_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(GemmNTArgs p)
+// MI x NJ 32x32 MFMA tiles per wave, waves 2 x 2: block tile (64 MI) x (64 NJ).  (2, 2): 128 x 128, three workgroups
+// per CU; (2, 4): 128 x 256 -- for N = 256 the A panel is then read, split and staged once -- two per CU; (1, 2)
+// for small problems.
+template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_x6_kernel(GemmNTArgs p)
 {
-    constexpr int BM = 64 * MI;
-    constexpr int PA = BM * 64, PB = BN * 64;              // bytes per plane
+    constexpr int BM = 64 * MI, BNX = 64 * NJ;
+    constexpr int PA = BM * 64, PB = BNX * 64;             // bytes per plane
     __shared__ __attribute__((aligned(16))) char lds[3 * (PA + PB)];
     char *As = lds;                   // [3][BM][64 B]
-    char *Bs = lds + 3 * PA;          // [3][BN][64 B]
+    char *Bs = lds + 3 * PA;          // [3][BNX][64 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -270,15 +274,22 @@ template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(Ge
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const long m0 = (long)(blockIdx.x / tiles_n) * BM;
-    const int n0 = (int)(blockIdx.x % tiles_n) * BN;
+    const int tiles_n = (p.N + BNX - 1) / BNX;
+    const long mt = blockIdx.x / tiles_n;
+    const int n0 = (int)(blockIdx.x % tiles_n) * BNX;
+    long m0 = mt * BM, m_end = p.M;
+    if (p.seg_rows > 0) {
+        const int tps = (p.seg_valid + BM - 1) / BM;       // tiles per segment
+        const long g = mt / tps;
+        m0 = g * p.seg_rows + (mt - g * tps) * BM;
+        m_end = g * p.seg_rows + p.seg_valid;
+    }
 
-    // loader: thread = (row tid/4 [+64 q], 8 consecutive k at (tid%4)*8): two float4 per row, MI rows of A, 2 of B
+    // loader: thread = (row tid/4 [+64 q], 8 consecutive k at (tid%4)*8): two float4 per row, MI rows of A, NJ of B
     const int lrow = tid >> 2;
     const int lchunk = tid & 3;
     const int lk = lchunk * 8;
-    float4 ra[MI][2], rb[2][2];
+    float4 ra[MI][2], rb[NJ][2];
 
     const int kbeg = blockIdx.y * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
@@ -291,7 +302,7 @@ template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(Ge
 #pragma unroll
                 for (int c = 0; c < 2; ++c) ra[q][c] = ld4<true, false>(p.A, m0 + lrow + 64 * q, p.M, p.lda, k0 + 4 * c, kend);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < NJ; ++q)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) rb[q][c] = ld4<true, false>(p.B, n0 + lrow + 64 * q, p.N, p.ldb, k0 + 4 * c, kend);
         } else {
@@ -300,17 +311,17 @@ template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(Ge
 #pragma unroll
                 for (int c = 0; c < 2; ++c) ra[q][c] = ld4<true, true>(p.A, m0 + lrow + 64 * q, p.M, p.lda, k0 + 4 * c, kend);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < NJ; ++q)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) rb[q][c] = ld4<true, true>(p.B, n0 + lrow + 64 * q, p.N, p.ldb, k0 + 4 * c, kend);
         }
     };
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -320,40 +331,45 @@ template <int MI> __global__ __launch_bounds__(256, 3) void gemm_nt_x6_kernel(Ge
 #pragma unroll
         for (int q = 0; q < MI; ++q) split8_store(ra[q][0], ra[q][1], As, PA, x6_off(lrow + 64 * q, lchunk));
 #pragma unroll
-        for (int q = 0; q < 2; ++q) split8_store(rb[q][0], rb[q][1], Bs, PB, x6_off(lrow + 64 * q, lchunk));
+        for (int q = 0; q < NJ; ++q) split8_store(rb[q][0], rb[q][1], Bs, PB, x6_off(lrow + 64 * q, lchunk));
         __syncthreads();
         if (kt + 1 < nk) load_tiles(kt + 1);
 
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             // lane (r32, h) holds k = kk*16 + 8h .. +7 of its row: chunk 2 kk + h
-            bf16x8_t fa[MI][3], fb[2][3];
+            bf16x8_t fa[MI][3];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PA + x6_off(wm * 32 * MI + i * 32 + r32, 2 * kk + h));
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int jp = 0; jp < NJ; jp += 2) {           // two column tiles at a time: bounds the fragment registers
+                bf16x8_t fb[2][3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PB + x6_off(wn * 64 + j * 32 + r32, 2 * kk + h));
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                    for (int t = 0; t < 3; ++t)
+                        fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PB + x6_off(wn * 32 * NJ + (jp + j) * 32 + r32, 2 * kk + h));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x16 &c = acc[i][jp + j];
+                        // smallest terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();
     }
-    nt_epilogue<MI>(p, acc, m0, n0, wm, wn, r32, h);
+    nt_epilogue<MI, NJ>(p, acc, m0, m_end, n0, wm, wn, r32, h);
 }
 
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
@@ -365,10 +381,19 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     a.M = M; a.N = N; a.K = K; a.map = map;
     a.aligned = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
-    // 128-row tiles unless that grid cannot give every CU at least two workgroups (256 CUs)
-    const long blocks128 = cdiv(M, 128) * cdiv(N, BN);
-    const int mi = (a.aligned && blocks128 < 2 * 256) ? 1 : 2;
-    const long blocks = cdiv(M, 64 * mi) * cdiv(N, BN);
+    const bool native = g_gemm_mode == 1;
+    const bool split_kernels = a.aligned && !native;
+    // segmented row tiling (split kernels): never multiply the junk rows at the end of a sample
+    a.seg_rows = 0; a.seg_valid = 0;
+    if (split_kernels && map.seg_rows > 0 && map.seg_valid > 0 && M % map.seg_rows == 0) { a.seg_rows = map.seg_rows; a.seg_valid = map.seg_valid; }
+    auto m_tiles = [&](int bm) { return a.seg_rows > 0 ? (M / a.seg_rows) * cdiv(a.seg_valid, bm) : cdiv(M, bm); };
+    // tile choice: 128 x 256 (A read, split and staged once per 256 columns; two workgroups per CU) when N is made of
+    // 256-column panels and the grid still fills the chip twice over; else 128 x 128 (three per CU); 64 x 128 when
+    // even that leaves CUs with fewer than two workgroups
+    int mi = 2, nj = 2;
+    if (split_kernels && N % 256 == 0 && m_tiles(128) * (N / 256) >= 2 * 256) nj = 4;
+    else if (a.aligned && m_tiles(128) * cdiv(N, BN) < 2 * 256) mi = 1;
+    const long blocks = m_tiles(64 * mi) * cdiv(N, 64 * nj);
     CPC_REQUIRE(blocks <= 2147483647L, "gemm_nt: grid too large (%ld blocks)", blocks);
     // few tiles but a long K (e.g. dC = dP . W, K = 12 H): split K over blockIdx.y, partial products are
     // atomically added into a zeroed C (dense, unmapped outputs only)
@@ -380,12 +405,12 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     if (splits > 1) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
     dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);
-    const bool native = g_gemm_mode == 1;
     if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
     else if (native && mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
     else if (native) hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
-    else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_x6_kernel<2>), grid, dim3(256), 0, st, a);
+    else if (nj == 4) hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 2>), grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
     return CPC_OK;
 }
