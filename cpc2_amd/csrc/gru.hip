@@ -194,18 +194,21 @@ __global__ void gru_bwd_kernel(GruArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// On-chip recurrence for H = 256: W_hh never leaves the register file.  A GROUP of 4 workgroups (512 threads
-// each, one per CU) shares COOP_NB windows; member m owns hidden units [64m, 64m+64) = 192 gate rows of W_hh,
-// 96 weights per thread (thread (u, q): unit u, K slice q of 32).  Per step every member multiplies its slice
-// by the full h (LDS), finishes the K reduction with 3 wave shuffles, applies the gates for its 64 units and
-// publishes them; the four members exchange the new h through 8-byte {epoch, value} granules in L2
-// (one sc1 store each, polled with relaxed agent-scope loads: MI355X guide, Guideline 16 R2).  A member can be
-// at most one step ahead of another, so two granule sets (epoch parity) suffice.  Every spin is bounded: on
-// time-out the workgroup poisons its outputs with NaN and leaves.
-constexpr int COOP_G = 4;            // workgroups per group
-constexpr int COOP_H = 256;
-constexpr int COOP_U = COOP_H / COOP_G;     // units per member
-constexpr int COOP_LDH = 8 * 36;            // padded h row: chunk q of 32 floats at q*36
+// On-chip recurrence for H = 256 and 512: W_hh never leaves the register file.  A GROUP of G workgroups (512
+// threads each, one per CU) shares NB windows; every thread holds 96 weights: thread (u, q) = unit u of the member's
+// U units, K slice q of 32 columns, 3 gates.  H = 256: 8 slices, U = 64, G = 4;  H = 512: 16 slices, U = 32, G = 16.
+// Per step every member multiplies its slice by the full h (LDS), finishes the K reduction with wave shuffles,
+// applies the gates for its U units and publishes them; the members exchange the new h through 8-byte
+// {epoch, value} granules in L2 (one sc1 store each, polled with relaxed agent-scope loads: MI355X guide,
+// Guideline 16 R2).  A member can be at most one step ahead of another, so two granule sets (epoch parity)
+// suffice.  Every spin is bounded: on time-out the workgroup poisons its outputs with NaN and leaves.
+template <int H> struct CoopCfg {
+    static constexpr int QS = H / 32;            // K slices of 32 columns
+    static constexpr int U = 512 / QS;           // units per member
+    static constexpr int G = H / U;              // workgroups per group
+    static constexpr int LDH = QS * 36;          // padded h row: chunk q of 32 floats at q*36
+    static constexpr int HALVES = 512 / H;       // backward: threads per W_hh column
+};
 
 typedef unsigned long long gu64_t;
 #define COOP_GLOBAL __attribute__((address_space(1)))
@@ -214,28 +217,36 @@ __device__ __forceinline__ int coop_pad(int k) { return (k >> 5) * 36 + (k & 31)
 
 struct GruCoopArgs {
     GruArgs g;
-    gu64_t *comm;          // [groups][2][NB][H] granules, zeroed before the launch
+    gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
     int groups, xcd_map;
 };
 
-template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(GruCoopArgs ca)
+template <int G> __device__ __forceinline__ void coop_who(const GruCoopArgs &ca, int &group, int &member)
 {
-    __shared__ __attribute__((aligned(16))) float hs[2][NB][COOP_LDH];
-    const GruArgs &a = ca.g;
-    constexpr int H = COOP_H;
-    const int T = a.T;
-    int group, member;
     if (ca.xcd_map) {                       // members of a group on one XCD (speed only: blocks b, b+8 share one)
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        group = xcd * (ca.groups / 8) + (i >> 2);
-        member = i & 3;
+        group = xcd * (ca.groups / 8) + i / G;
+        member = i % G;
     } else {
-        group = blockIdx.x >> 2;
-        member = blockIdx.x & 3;
+        group = blockIdx.x / G;
+        member = blockIdx.x % G;
     }
+}
+
+template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(GruCoopArgs ca)
+{
+    using C = CoopCfg<H>;
+    constexpr int QS = C::QS, U = C::U, G = C::G;
+    constexpr int KP = NB * H / 512 > 0 ? NB * H / 512 : 1;          // granules gathered per thread and step
+    static_assert(NB <= QS, "one finishing lane per window");
+    __shared__ __attribute__((aligned(16))) float hs[2][NB][C::LDH];
+    const GruArgs &a = ca.g;
+    const int T = a.T;
+    int group, member;
+    coop_who<G>(ca, group, member);
     const int tid = threadIdx.x;
-    const int q = tid & 7, u = tid >> 3;
-    const int j = member * COOP_U + u;
+    const int q = tid & (QS - 1), u = tid / QS;
+    const int j = member * U + u;
     const int n0 = group * NB;
 
     float w[3][32];
@@ -253,7 +264,7 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
         const int n = n0 + s;
         const float v = (n < a.N && a.h0 != nullptr) ? a.h0[(long)n * H + k] : 0.f;
         hs[0][s][coop_pad(k)] = v;
-        if (n < a.N && (k / COOP_U) == member) a.hall[((long)n * (T + 1)) * H + k] = v;
+        if (n < a.N && (k / U) == member) a.hall[((long)n * (T + 1)) * H + k] = v;
     }
     __syncthreads();
 
@@ -289,9 +300,8 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
             }
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                acc[s][g] += __shfl_xor(acc[s][g], 1, 64);
-                acc[s][g] += __shfl_xor(acc[s][g], 2, 64);
-                acc[s][g] += __shfl_xor(acc[s][g], 4, 64);
+#pragma unroll
+                for (int m = 1; m < QS; m <<= 1) acc[s][g] += __shfl_xor(acc[s][g], m, 64);
             }
         }
         if (q < NB) {
@@ -320,20 +330,33 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
                 a.hall[((long)ns * (T + 1) + t + 1) * H + j] = hv;
             }
         }
-        // gather the whole new h (all four members) into the other LDS buffer
+        // gather the whole new h (all members) into the other LDS buffer; a thread's KP granules are polled together
+        // (one L2 round trip per attempt, not KP in a row)
         if (t + 1 < T) {
-            for (int idx = tid; idx < NB * H; idx += 512) {
-                const int s = idx / H, k = idx - s * H;
-                COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + s) * H + k);
-                gu64_t x = 0;
-                unsigned spins = dead ? (1u << 22) : 0u;       // once timed out, never wait again
+            COOP_GLOBAL gu64_t *slot[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const int idx = tid + 512 * i;
+                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + idx / H) * H + (idx % H));
+            }
+            gu64_t x[KP];
+            unsigned spins = dead ? (1u << 22) : 0u;            // once timed out, never wait again
+            if (tid < NB * H) {
                 for (;;) {
-                    x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(x >> 32) == (unsigned)(t + 1)) break;
+                    bool ready = true;
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
+                    if (ready) break;
                     if (++spins > (1u << 22)) { dead = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                hs[nxt][s][coop_pad(k)] = __uint_as_float((unsigned)x);
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    const int idx = tid + 512 * i;
+                    hs[nxt][idx / H][coop_pad(idx % H)] = __uint_as_float((unsigned)x[i]);
+                }
             }
             dead = __syncthreads_or(dead);
         }
@@ -342,34 +365,30 @@ template <int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(Gru
         a.hlast[(long)(n0 + q) * H + j] = a.hall[((long)(n0 + q) * (T + 1) + T) * H + j];
 }
 
-// Backward twin of gru_fwd_coop_kernel: member m keeps the SAME 192 rows of W_hh (its 64 units x 3 gates) in
-// registers, now one COLUMN j' per thread (thread (j', half): 96 rows), forms its partial W_hh^T dGH for all 256
-// columns and the four members exchange the 64-column pieces the others own.
-//   comm: [groups][2][COOP_G (sender)][NB][H] granules, zeroed before the launch.
-template <int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(GruCoopArgs ca)
+// Backward twin of gru_fwd_coop_kernel: member m keeps the SAME 3 U rows of W_hh (its U units x 3 gates) in
+// registers, now one COLUMN j' per thread (thread (j', half): 96 rows), forms its partial W_hh^T dGH for all H
+// columns and the members exchange the U-column pieces the others own.
+//   comm: [groups][2][G (sender)][NB][H] granules, zeroed before the launch.
+template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(GruCoopArgs ca)
 {
-    __shared__ __attribute__((aligned(16))) float dgs[NB][3 * COOP_U];     // this member's dGH rows (gate, unit)
-    __shared__ float part[2][NB][COOP_H];
+    using C = CoopCfg<H>;
+    constexpr int U = C::U, G = C::G, HALVES = C::HALVES;
+    static_assert(3 * U / HALVES == 96, "96 weights per thread");
+    static_assert(NB * U <= 512, "one elementwise thread per (window, unit)");
+    __shared__ __attribute__((aligned(16))) float dgs[NB][3 * U];          // this member's dGH rows (gate, unit)
+    __shared__ float part[HALVES][NB][H];
     const GruArgs &a = ca.g;
-    constexpr int H = COOP_H, U = COOP_U;
     const int T = a.T;
     int group, member;
-    if (ca.xcd_map) {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        group = xcd * (ca.groups / 8) + (i >> 2);
-        member = i & 3;
-    } else {
-        group = blockIdx.x >> 2;
-        member = blockIdx.x & 3;
-    }
+    coop_who<G>(ca, group, member);
     const int tid = threadIdx.x;
-    const int jc = tid & (H - 1), half = tid >> 8;            // column jc, rows half*96 .. +96 of the member's 192
+    const int jc = tid & (H - 1), half = tid / H;             // column jc, rows half*96 .. +96 of the member's 3 U
     const int n0 = group * NB;
 
     float w[96];
 #pragma unroll
     for (int i = 0; i < 96; ++i) {
-        const int lr = half * 96 + i;                          // local row = gate*64 + unit
+        const int lr = half * 96 + i;                          // local row = gate*U + unit
         w[i] = a.whh[(long)((lr / U) * H + member * U + (lr % U)) * H + jc];
     }
     // elementwise role: thread (es, eu) for tid < NB*U
@@ -438,45 +457,77 @@ template <int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_kernel(Gru
 #pragma unroll
         for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s];
         __syncthreads();
+        auto column = [&](int s, int k) {
+            float v = part[0][s][k];
+#pragma unroll
+            for (int hh = 1; hh < HALVES; ++hh) v += part[hh][s][k];
+            return v;
+        };
         // publish the columns other members own (this member's own columns stay in LDS)
         if (t > 0) {
             for (int idx = tid; idx < NB * H; idx += 512) {
                 const int s = idx / H, k = idx - s * H;
                 if (k / U == member) continue;
-                const float v = part[0][s][k] + part[1][s][k];
+                const float v = column(s, k);
                 COOP_GLOBAL gu64_t *slot =
-                    (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * COOP_G + member) * NB + s) * H + k);
+                    (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * G + member) * NB + s) * H + k);
                 __hip_atomic_store(slot, ((gu64_t)epoch << 32) | (gu64_t)__float_as_uint(dead ? NAN : v), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
             if (ew) {
-                float sum = keep + part[0][es][ej] + part[1][es][ej];
-                // the three partners' pieces are polled together: one L2 round trip per attempt, not three in a row
-                COOP_GLOBAL gu64_t *slot[COOP_G - 1];
+                float sum = keep + column(es, ej);
+                // the partners' pieces are polled together: one L2 round trip per attempt, not G - 1 in a row
+                COOP_GLOBAL gu64_t *slot[G - 1];
 #pragma unroll
-                for (int d = 1; d < COOP_G; ++d) {
-                    const int src = (member + d) & (COOP_G - 1);
-                    slot[d - 1] = (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * COOP_G + src) * NB + es) * H + ej);
+                for (int d = 1; d < G; ++d) {
+                    const int src = (member + d) & (G - 1);
+                    slot[d - 1] = (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * G + src) * NB + es) * H + ej);
                 }
-                gu64_t x[COOP_G - 1];
+                gu64_t x[G - 1];
                 unsigned spins = dead ? (1u << 22) : 0u;
                 for (;;) {
                     bool ready = true;
 #pragma unroll
-                    for (int d = 0; d < COOP_G - 1; ++d) x[d] = __hip_atomic_load(slot[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int d = 0; d < G - 1; ++d) x[d] = __hip_atomic_load(slot[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int d = 0; d < COOP_G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
+                    for (int d = 0; d < G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
                     if (ready) break;
                     if (++spins > (1u << 22)) { dead = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
-                for (int d = 0; d < COOP_G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
+                for (int d = 0; d < G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
                 carry = sum;
             }
             dead = __syncthreads_or(dead);
         }
     }
+}
+
+// cooperative path: window count -> windows per group (0: not covered), for the hidden sizes that have one
+static int coop_windows_per_group(int H, int N, int n_cus, int *groups_per)
+{
+    const int G = H == 256 ? CoopCfg<256>::G : (H == 512 ? CoopCfg<512>::G : 0);
+    if (G == 0 || n_cus < G) return 0;
+    const int max_groups = n_cus / G;
+    for (int nb = 1; nb <= 8; nb *= 2)
+        if ((int)cdiv(N, nb) <= max_groups) { *groups_per = G; return nb; }
+    return 0;
+}
+
+template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
+{
+    if (nb == 1) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
+    else if (nb == 2) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
+    else if (nb == 4) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
+    else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
+}
+template <int H> static void launch_coop_bwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
+{
+    if (nb == 1) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
+    else if (nb == 2) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
+    else if (nb == 4) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
+    else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,7 +568,8 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     g.wt = sc.take<float>((size_t)3 * H * dmax);
     g.wpack = sc.take<float4>((size_t)3 * H * H / 4);
     g.cs = sc.take<float>(colsum_rows_scratch_bytes(3 * H) / sizeof(float));
-    g.comm_bytes = sizeof(unsigned long long) * 256 * 2 * COOP_G * (size_t)COOP_H;   // groups*NB <= 256 windows, 2 parities
+    // granules of the cooperative kernels: backward [groups][2][G][NB][H], groups*NB < N + 8 windows, G <= 16
+    g.comm_bytes = (H == 256 || H == 512) ? sizeof(unsigned long long) * 2 * 16 * (size_t)(N + 8) * H : 256;
     g.comm = sc.take<unsigned long long>(g.comm_bytes / sizeof(unsigned long long));
     g.tn_bytes = std::max(gemm_tn_scratch_bytes(3 * H, H, (long)N * (T + 1)), gemm_tn_scratch_bytes(3 * H, dmax, (long)N * T));
     g.tn_bytes = std::max(g.tn_bytes, gemm_tn_scratch_bytes(3 * H, Din, (long)N * T));
@@ -549,7 +601,6 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         a.hlast = h_last ? h_last + (size_t)l * N * H : nullptr;
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
-        const int nb = N <= 64 ? 1 : (N <= 128 ? 2 : (N <= 256 ? 4 : 0));
         static const int n_cus = [] {
             int dev = 0, v = 0;
             if (hipGetDevice(&dev) != hipSuccess) return 0;
@@ -557,16 +608,17 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
             return v;
         }();
         // the cooperative kernel needs every workgroup resident at once (1 per CU)
-        if (H == COOP_H && nb != 0 && !coop_off && (int)cdiv(N, nb) * COOP_G <= n_cus) {
+        int G = 0;
+        const int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        if (nb != 0) {
             GruCoopArgs ca{};
             ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
-            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * nb * COOP_H, st));
+            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * nb * H, st));
             ProfScope prof(PROF_GRU_FWD, st);
-            const dim3 grid((unsigned)(ca.groups * COOP_G));
-            if (nb == 1) hipLaunchKernelGGL(gru_fwd_coop_kernel<1>, grid, dim3(512), 0, st, ca);
-            else if (nb == 2) hipLaunchKernelGGL(gru_fwd_coop_kernel<2>, grid, dim3(512), 0, st, ca);
-            else hipLaunchKernelGGL(gru_fwd_coop_kernel<4>, grid, dim3(512), 0, st, ca);
+            const dim3 grid((unsigned)(ca.groups * G));
+            if (H == 256) launch_coop_fwd<256>(nb, grid, st, ca);
+            else launch_coop_fwd<512>(nb, grid, st, ca);
         } else {
             ProfScope prof(PROF_GRU_FWD, st);
             const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * 3 * hp);
@@ -602,17 +654,17 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
             return v;
         }();
-        const int nb = N <= 64 ? 1 : (N <= 128 ? 2 : (N <= 256 ? 4 : 0));
-        if (H == COOP_H && nb != 0 && !coop_off && (int)cdiv(N, nb) * COOP_G <= n_cus) {
+        int G = 0;
+        const int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        if (nb != 0) {
             GruCoopArgs ca{};
             ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
-            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * COOP_G * nb * COOP_H, st));
+            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * G * nb * H, st));
             ProfScope prof(PROF_GRU_BWD, st);
-            const dim3 grid((unsigned)(ca.groups * COOP_G));
-            if (nb == 1) hipLaunchKernelGGL(gru_bwd_coop_kernel<1>, grid, dim3(512), 0, st, ca);
-            else if (nb == 2) hipLaunchKernelGGL(gru_bwd_coop_kernel<2>, grid, dim3(512), 0, st, ca);
-            else hipLaunchKernelGGL(gru_bwd_coop_kernel<4>, grid, dim3(512), 0, st, ca);
+            const dim3 grid((unsigned)(ca.groups * G));
+            if (H == 256) launch_coop_bwd<256>(nb, grid, st, ca);
+            else launch_coop_bwd<512>(nb, grid, st, ca);
         } else {
             hipLaunchKernelGGL(gru_pack_bwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);
             CPC_CHECK_LAUNCH("gru_pack_bwd_kernel");
