@@ -254,15 +254,15 @@ def main():
             flops, launches = gemm_nt_algorithmic_flops(args.batch, cfg, args.dedup)
             k = kernels["gemm_nt"]
             achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_x6_kernel (conv1-4 fwd + bwd-data, GRU/predictor projections)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_x6_kernel (conv1-4 forward and backward-data, GRU / predictor projections)",
                                "achieved": round(achieved, 2), "peak": GEMM_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / GEMM_PEAK_TFLOPS, 4),
                                "peak_note": "algorithmic f32 flops; peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per "
                                             "f32 product (f32-accurate bf16x6 split); the f32 MFMA's own peak is "
                                             f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s",
-                               # HBM bytes per launch from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE KiB,
-                               # profiles/r01_v2_pmc_summary.md), valid for the default workload only
-                               "traffic": 4.46e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
+                               # HBM bytes per launch from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE KiB, mean over
+                               # the step's 12 launches: profiles/r01_v3_pmc_summary.md), valid for the default workload only
+                               "traffic": 4.35e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
                                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
                                "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
         out["kernels"] = kernels
