@@ -295,6 +295,29 @@ class PredictionNetwork(nn.Module):
         return torch.stack([p.weight for p in self.predictors], dim=0)
 
 
+class MultiHeadPredictionNetwork(nn.Module):
+    """criterion.py:44-94 with rnnMode='transformer' (--multihead_rnn): ONE transformer whose feed-forward net emits
+    nPredicts residual branches (`predictor.0.*`, a MultiClassifierTransformerHead); prediction k is
+    predictor(c)[:, :, k]."""
+
+    def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode='transformer_multi', dropout=False,
+                 sizeInputSeq=116, transformer_pruning=0):
+        super(MultiHeadPredictionNetwork, self).__init__()
+        if rnnMode != 'transformer':
+            if rnnMode == 'transformer_adaptive_span':
+                raise NotImplementedError("rnnMode='transformer_adaptive_span' is not on the MI355X hot path")
+            raise ValueError(f"unknown mode {rnnMode}")
+        if dropout:
+            raise NotImplementedError("predictor dropout is not supported by the MI355X hot path")
+        from .transformers import buildMultHeadTransformerAR
+        self.dimOutputAR = dimOutputAR
+        self.dropout = None
+        self.nPredicts = nPredicts
+        self.rnnMode = 'transformer_multi'
+        self.predictor = buildMultHeadTransformerAR(dimOutputEncoder, dimOutputAR, nLayers=1, sizeSeq=sizeInputSeq,
+                                                    abspos=False, nHeads=nPredicts)
+
+
 class BaseCriterion(nn.Module):
 
     def warmUp(self):
@@ -331,10 +354,13 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                  growth_rate=None,
                  inflection_point_x=None):
         super(CPCUnsupersivedCriterion, self).__init__()
-        if multihead_rnn:
-            raise NotImplementedError("multihead_rnn predictors are not on the MI355X hot path")
-        self.wPrediction = PredictionNetwork(nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=rnnMode,
-                                             dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts)
+        if multihead_rnn:                                # criterion.py:213-218
+            self.wPrediction = MultiHeadPredictionNetwork(nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=rnnMode,
+                                                          dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts,
+                                                          transformer_pruning=transformer_pruning)
+        else:
+            self.wPrediction = PredictionNetwork(nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=rnnMode,
+                                                 dropout=dropout, sizeInputSeq=sizeInputSeq - nPredicts)
         self.nSkipped = n_skipped
         self.nPredicts = nPredicts
         self.negativeSamplingExt = negativeSamplingExt
@@ -372,7 +398,11 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         else:
             quality_weighting = None                    # ones (criterion.py:340)
         extIdx = self.sampleIndices(batchSize, seqSize, windowSize, cFeature.device)
-        if self.wPrediction.rnnMode == 'transformer':
+        if self.wPrediction.rnnMode == 'transformer_multi':
+            cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
+            preds = torch.unbind(self.wPrediction.predictor(cW), dim=2)    # criterion.py:85 prediction[:, :, k]
+            losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
+        elif self.wPrediction.rnnMode == 'transformer':
             cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
             preds = [predictor(cW) for predictor in self.wPrediction.predictors]
             losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)

@@ -186,6 +186,33 @@ __global__ void add2_kernel(float *out, const float *a, const float *b, long n4)
     }
 }
 
+// multi-classifier head (transformers.py:137-158): t[(r, k)][:] = y[r][:] + f[r][k*D + :]  and its adjoint
+__global__ void add_bcast_kernel(float *t, const float *y, const float *f, long rows, int nc, int d4)
+{
+    const long n4 = rows * nc * d4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ((long)nc * d4);
+        const int c = (int)(i % d4);
+        const float4 a = reinterpret_cast<const float4 *>(y)[r * d4 + c], b = reinterpret_cast<const float4 *>(f)[i];
+        reinterpret_cast<float4 *>(t)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+__global__ void sum_classifiers_kernel(float *dy, const float *dt, long rows, int nc, int d4)
+{
+    const long n4 = rows * d4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d4;
+        const int c = (int)(i % d4);
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nc; ++k) {
+            const float4 v = reinterpret_cast<const float4 *>(dt)[(r * nc + k) * d4 + c];
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        }
+        reinterpret_cast<float4 *>(dy)[i] = s4;
+    }
+}
+
 static int launch_add2(float *out, const float *a, const float *b, long n, hipStream_t st)
 {
     const long n4 = n / 4;
@@ -435,7 +462,7 @@ enum { P_WQ = 0, P_WK, P_WV, P_WO, P_KREL, P_LN1W, P_LN1B, P_W1, P_B1, P_W2, P_B
 constexpr int TR_DFF = 2048;        // transformers.py:119 (dff=2048)
 
 struct TrLayout {
-    int N, S, D, Dout, SS, layers, dk, chunks;
+    int N, S, D, Dout, SS, layers, dk, chunks, nc;
     long rows;
     // saved per layer
     float *qkv[4], *probs[4], *ctx[4], *xh1[4], *rstd1[4], *y[4], *hdrop[4], *t[4], *xh2[4], *rstd2[4], *xout[4];
@@ -445,14 +472,16 @@ struct TrLayout {
     size_t tn_bytes, scratch_bytes, lds_fwd, lds_bwd;
 };
 
-static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int layers, void *saved, void *scratch)
+static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int layers, int nc, void *saved, void *scratch)
 {
+    CPC_REQUIRE(nc >= 1 && nc <= 64, "transformer: 1..64 classifiers in the last layer's head (got %d)", nc);
+    CPC_REQUIRE(nc == 1 || layers == 1 || D == Dout, "transformer: stacked layers need dmodel == dout");
     CPC_REQUIRE(supported_row_width(D) && supported_row_width(Dout), "transformer: model dims %d/%d not supported", D, Dout);
     CPC_REQUIRE(layers >= 1 && layers <= 4, "transformer: 1..4 layers supported (got %d)", layers);
     CPC_REQUIRE(layers == 1 || D == Dout, "transformer: stacked layers need dmodel == dout");
     CPC_REQUIRE(N > 0 && S > 0 && SS > 0 && SS <= 128, "transformer: need 0 < sizeSeq <= 128 (got %d)", SS);
     CPC_REQUIRE(S % SS == 0, "transformer: sequence length %d must be a multiple of sizeSeq %d", S, SS);
-    L.N = N; L.S = S; L.D = D; L.Dout = Dout; L.SS = SS; L.layers = layers; L.dk = D / TR_HEADS; L.chunks = S / SS;
+    L.N = N; L.S = S; L.D = D; L.Dout = Dout; L.SS = SS; L.layers = layers; L.dk = D / TR_HEADS; L.chunks = S / SS; L.nc = nc;
     L.rows = (long)N * S;
     const size_t R = (size_t)L.rows;
     const size_t nchunk = (size_t)N * TR_HEADS * L.chunks;
@@ -465,28 +494,29 @@ static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int lay
         L.rstd1[l] = sv.take<float>(R);
         L.y[l] = sv.take<float>(R * D);
         L.hdrop[l] = sv.take<float>(R * TR_DFF);
-        L.t[l] = sv.take<float>(R * D);
-        L.xh2[l] = sv.take<float>(R * Dout);
-        L.rstd2[l] = sv.take<float>(R);
+        const size_t k = (l + 1 == layers) ? (size_t)nc : 1;       // the multi-classifier head is the last layer only
+        L.t[l] = sv.take<float>(R * k * D);
+        L.xh2[l] = sv.take<float>(R * k * Dout);
+        L.rstd2[l] = sv.take<float>(R * k);
         L.xout[l] = (l + 1 < layers) ? sv.take<float>(R * Dout) : nullptr;
     }
     L.saved_bytes = sv.used();
     Carver sc(scratch);
     const int dmax = std::max(D, Dout);
     L.wqkv = sc.take<float>((size_t)3 * D * D);
-    L.wt = sc.take<float>((size_t)TR_DFF * dmax > (size_t)3 * D * D ? (size_t)TR_DFF * dmax : (size_t)3 * D * D);
+    L.wt = sc.take<float>(std::max((size_t)TR_DFF * dmax * nc, (size_t)3 * D * D));
     L.o = sc.take<float>(R * dmax);
-    L.u = sc.take<float>(R * dmax);
-    L.da = sc.take<float>(R * dmax);
-    L.db = sc.take<float>(R * dmax);
+    L.u = sc.take<float>(R * dmax * nc);
+    L.da = sc.take<float>(R * dmax * nc);
+    L.db = sc.take<float>(R * dmax * nc);
     L.dc = sc.take<float>(R * dmax);
     L.dh = sc.take<float>(R * TR_DFF);
     L.dqkv = sc.take<float>(R * 3 * D);
     L.part = sc.take<float>((size_t)LN_BWD_BLOCKS * 4 * rows_per_wave(std::min(D, Dout)) * 2 * dmax);
     L.krel_part = sc.take<float>(nchunk * L.dk * SS);
-    L.cs = sc.take<float>(colsum_rows_scratch_bytes(TR_DFF) / sizeof(float));
-    L.tn_bytes = std::max(gemm_tn_scratch_bytes(TR_DFF, dmax, L.rows), gemm_tn_scratch_bytes(dmax, TR_DFF, L.rows));
-    L.tn_bytes = std::max(L.tn_bytes, gemm_tn_scratch_bytes(dmax, dmax, L.rows));
+    L.cs = sc.take<float>(colsum_rows_scratch_bytes(std::max(TR_DFF, nc * D)) / sizeof(float));
+    L.tn_bytes = std::max(gemm_tn_scratch_bytes(TR_DFF, dmax, L.rows), gemm_tn_scratch_bytes(dmax * nc, TR_DFF, L.rows));
+    L.tn_bytes = std::max(L.tn_bytes, gemm_tn_scratch_bytes(dmax, dmax, L.rows * nc));
     L.tn = sc.take<float>(L.tn_bytes / sizeof(float));
     L.scratch_bytes = sc.used();
     const size_t ldk = L.dk + 1, ldp = SS + 1;
@@ -532,10 +562,10 @@ static int launch_ln_bwd(const float *dy, const float *xhat, const float *rstd, 
 static uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0); }
 
 static int transformer_forward(const float *x, const float *const *prm, float *out, void *saved, void *scratch, int N, int S,
-                               int D, int Dout, int SS, int layers, float p_drop, uint64_t seed, hipStream_t st)
+                               int D, int Dout, int SS, int layers, int nc, float p_drop, uint64_t seed, hipStream_t st)
 {
     TrLayout L;
-    CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, saved, scratch));
+    CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, nc, saved, scratch));
     const long R = L.rows;
     const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thresh = drop_thresh(p_drop);
@@ -560,22 +590,28 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
         CPC_TRY(gemm_nt(L.y[l], D, p[P_W1], D, L.hdrop[l], TR_DFF, p[P_B1], R, TR_DFF, D, none, st));           // lin1 (:116)
         hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(4096), dim3(256), 0, st, L.hdrop[l], R * TR_DFF, lseed ^ 0xFFull, thresh, scale);
         CPC_CHECK_LAUNCH("relu_dropout_fwd_kernel");
-        CPC_TRY(gemm_nt(L.hdrop[l], TR_DFF, p[P_W2], TR_DFF, L.u, D, p[P_B2], R, D, TR_DFF, none, st));        // lin2
-        CPC_TRY(launch_add2(L.t[l], L.y[l], L.u, R * D, st));                                                   // y + FFN(y) (:134)
-        CPC_TRY(gemm_nt(L.t[l], D, p[P_WL], D, L.u, Dout, p[P_BL], R, Dout, D, none, st));                       // last_linear
+        const int k = (l + 1 == layers) ? nc : 1;          // classifiers of this layer's head: lin2 is [k*D][dff]
+        CPC_TRY(gemm_nt(L.hdrop[l], TR_DFF, p[P_W2], TR_DFF, L.u, (long)k * D, p[P_B2], R, k * D, TR_DFF, none, st));   // lin2
+        if (k == 1) {
+            CPC_TRY(launch_add2(L.t[l], L.y[l], L.u, R * D, st));                                               // y + FFN(y) (:134)
+        } else {                                                                                                 // (:156-158)
+            hipLaunchKernelGGL(add_bcast_kernel, dim3(4096), dim3(256), 0, st, L.t[l], L.y[l], L.u, R, k, D / 4);
+            CPC_CHECK_LAUNCH("add_bcast_kernel");
+        }
+        CPC_TRY(gemm_nt(L.t[l], D, p[P_WL], D, L.u, Dout, p[P_BL], R * k, Dout, D, none, st));                   // last_linear
         float *yo = (l + 1 < layers) ? L.xout[l] : out;
-        CPC_TRY(launch_ln_fwd(L.u, nullptr, p[P_LN2W], p[P_LN2B], yo, L.xh2[l], L.rstd2[l], R, Dout, 1e-5f, st));
+        CPC_TRY(launch_ln_fwd(L.u, nullptr, p[P_LN2W], p[P_LN2B], yo, L.xh2[l], L.rstd2[l], R * k, Dout, 1e-5f, st));
         xin = yo;
     }
     return CPC_OK;
 }
 
 static int transformer_backward(const float *x, const float *const *prm, const float *dout, void *saved, void *scratch, float *dx,
-                                float *const *grads, int N, int S, int D, int Dout, int SS, int layers, float p_drop,
+                                float *const *grads, int N, int S, int D, int Dout, int SS, int layers, int nc, float p_drop,
                                 uint64_t seed, hipStream_t st)
 {
     TrLayout L;
-    CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, saved, scratch));
+    CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, nc, saved, scratch));
     const long R = L.rows;
     const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thresh = drop_thresh(p_drop);
@@ -586,18 +622,19 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         float *const *g = grads + (size_t)l * P_COUNT;
         const float *xin = (l == 0) ? x : L.xout[l - 1];
         const uint64_t lseed = seed + 0x1000ull * (uint64_t)l;
+        const int k = (l + 1 == layers) ? nc : 1;          // classifiers of this layer's head
         // LN2
-        CPC_TRY(launch_ln_bwd(dcur, L.xh2[l], L.rstd2[l], p[P_LN2W], L.da, g[P_LN2W], g[P_LN2B], L.part, R, Dout, st));   // da = du
+        CPC_TRY(launch_ln_bwd(dcur, L.xh2[l], L.rstd2[l], p[P_LN2W], L.da, g[P_LN2W], g[P_LN2B], L.part, R * k, Dout, st));   // da = du
         // last_linear: u = t Wl^T + bl
-        CPC_TRY(gemm_tn(L.da, Dout, L.t[l], D, g[P_WL], D, Dout, D, R, L.tn, L.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(L.da, Dout, R, Dout, g[P_BL], L.cs, st));
+        CPC_TRY(gemm_tn(L.da, Dout, L.t[l], D, g[P_WL], D, Dout, D, R * k, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(colsum_rows(L.da, Dout, R * k, Dout, g[P_BL], L.cs, st));
         CPC_TRY(transpose2d(p[P_WL], L.wt, Dout, D, st));                                            // [D][Dout]
-        CPC_TRY(gemm_nt(L.da, Dout, L.wt, Dout, L.db, D, nullptr, R, D, Dout, none, st));            // db = dt (= dy_a = df)
+        CPC_TRY(gemm_nt(L.da, Dout, L.wt, Dout, L.db, D, nullptr, R * k, D, Dout, none, st));        // db = dt [R*k][D] = df [R][k*D]
         // lin2: f = h W2^T + b2
-        CPC_TRY(gemm_tn(L.db, D, L.hdrop[l], TR_DFF, g[P_W2], TR_DFF, D, TR_DFF, R, L.tn, L.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(L.db, D, R, D, g[P_B2], L.cs, st));
-        CPC_TRY(transpose2d(p[P_W2], L.wt, D, TR_DFF, st));                                          // [dff][D]
-        CPC_TRY(gemm_nt(L.db, D, L.wt, D, L.dh, TR_DFF, nullptr, R, TR_DFF, D, none, st));
+        CPC_TRY(gemm_tn(L.db, (long)k * D, L.hdrop[l], TR_DFF, g[P_W2], TR_DFF, k * D, TR_DFF, R, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(colsum_rows(L.db, (long)k * D, R, k * D, g[P_B2], L.cs, st));
+        CPC_TRY(transpose2d(p[P_W2], L.wt, k * D, TR_DFF, st));                                      // [dff][k*D]
+        CPC_TRY(gemm_nt(L.db, (long)k * D, L.wt, (long)k * D, L.dh, TR_DFF, nullptr, R, TR_DFF, k * D, none, st));
         hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(4096), dim3(256), 0, st, L.dh, L.hdrop[l], R * TR_DFF, scale);
         CPC_CHECK_LAUNCH("relu_dropout_bwd_kernel");
         // lin1: h = y W1^T + b1
@@ -605,7 +642,13 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         CPC_TRY(colsum_rows(L.dh, TR_DFF, R, TR_DFF, g[P_B1], L.cs, st));
         CPC_TRY(transpose2d(p[P_W1], L.wt, TR_DFF, D, st));                                          // [D][dff]
         CPC_TRY(gemm_nt(L.dh, TR_DFF, L.wt, TR_DFF, L.dc, D, nullptr, R, D, TR_DFF, none, st));      // dc = dy_b
-        CPC_TRY(launch_add2(L.dc, L.dc, L.db, R * D, st));                                            // dy = dy_a + dy_b
+        if (k > 1) {                                                                                  // dy_a = sum over classifiers of dt
+            hipLaunchKernelGGL(sum_classifiers_kernel, dim3(2048), dim3(256), 0, st, L.da, L.db, R, k, D / 4);
+            CPC_CHECK_LAUNCH("sum_classifiers_kernel");
+            CPC_TRY(launch_add2(L.dc, L.dc, L.da, R * D, st));
+        } else {
+            CPC_TRY(launch_add2(L.dc, L.dc, L.db, R * D, st));                                        // dy = dy_a + dy_b
+        }
         // LN1: y = LN(x + o)
         CPC_TRY(launch_ln_bwd(L.dc, L.xh1[l], L.rstd1[l], p[P_LN1W], L.da, g[P_LN1W], g[P_LN1B], L.part, R, D, st));      // da = d(x+o)
         // Wo: o = ctx Wo^T
@@ -650,32 +693,32 @@ static int transformer_backward(const float *x, const float *const *prm, const f
 
 extern "C" int cpc_transformer_param_count(void) { return cpc::P_COUNT; }
 
-extern "C" size_t cpc_transformer_saved_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers)
+extern "C" size_t cpc_transformer_saved_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers, int n_classifiers)
 {
     cpc::TrLayout L;
-    if (cpc::tr_layout(L, n, s, d_model, d_out, size_seq, layers, nullptr, nullptr) != CPC_OK) return 0;
+    if (cpc::tr_layout(L, n, s, d_model, d_out, size_seq, layers, n_classifiers, nullptr, nullptr) != CPC_OK) return 0;
     return L.saved_bytes;
 }
 
-extern "C" size_t cpc_transformer_scratch_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers)
+extern "C" size_t cpc_transformer_scratch_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers, int n_classifiers)
 {
     cpc::TrLayout L;
-    if (cpc::tr_layout(L, n, s, d_model, d_out, size_seq, layers, nullptr, nullptr) != CPC_OK) return 0;
+    if (cpc::tr_layout(L, n, s, d_model, d_out, size_seq, layers, n_classifiers, nullptr, nullptr) != CPC_OK) return 0;
     return L.scratch_bytes;
 }
 
 extern "C" int cpc_transformer_forward(const float *x, const float *const *params, float *out, void *saved, void *scratch, int n,
-                                       int s, int d_model, int d_out, int size_seq, int layers, float dropout_p,
+                                       int s, int d_model, int d_out, int size_seq, int layers, int n_classifiers, float dropout_p,
                                        unsigned long long seed, cpc_stream_t stream)
 {
-    return cpc::transformer_forward(x, params, out, saved, scratch, n, s, d_model, d_out, size_seq, layers, dropout_p, seed,
+    return cpc::transformer_forward(x, params, out, saved, scratch, n, s, d_model, d_out, size_seq, layers, n_classifiers, dropout_p, seed,
                                     static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cpc_transformer_backward(const float *x, const float *const *params, const float *dout, void *saved, void *scratch,
                                         float *dx, float *const *grads, int n, int s, int d_model, int d_out, int size_seq,
-                                        int layers, float dropout_p, unsigned long long seed, cpc_stream_t stream)
+                                        int layers, int n_classifiers, float dropout_p, unsigned long long seed, cpc_stream_t stream)
 {
-    return cpc::transformer_backward(x, params, dout, saved, scratch, dx, grads, n, s, d_model, d_out, size_seq, layers, dropout_p,
+    return cpc::transformer_backward(x, params, dout, saved, scratch, dx, grads, n, s, d_model, d_out, size_seq, layers, n_classifiers, dropout_p,
                                      seed, static_cast<hipStream_t>(stream));
 }

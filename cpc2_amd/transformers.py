@@ -63,10 +63,11 @@ class FFNetwork(nn.Module):
 
 
 class _TransformerFn(torch.autograd.Function):
-    """`layers` stacked TransformerLayers in one call; params = 15 tensors per layer in the C-ABI order."""
+    """`layers` stacked TransformerLayers in one call; params = 15 tensors per layer in the C-ABI order.
+    n_classifiers > 1: the last layer is a MultiClassifierTransformerHead and the output is [n, s, k, d_out]."""
 
     @staticmethod
-    def forward(ctx, x, size_seq, n_layers, dropout_p, seed, *params):
+    def forward(ctx, x, size_seq, n_layers, n_classifiers, dropout_p, seed, *params):
         require_gpu(x, *[p for p in params if p is not None])
         lib = _lib.load()
         x = f32c(x)
@@ -75,32 +76,35 @@ class _TransformerFn(torch.autograd.Function):
         n, s, d_model = x.shape
         per = lib.cpc_transformer_param_count()
         d_out = params[(n_layers - 1) * per + 11].shape[0]            # last layer's last_linear.weight [d_out, d]
-        nsaved = lib.cpc_transformer_saved_bytes(n, s, d_model, d_out, size_seq, n_layers)
-        nscratch = lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers)
+        nsaved = lib.cpc_transformer_saved_bytes(n, s, d_model, d_out, size_seq, n_layers, n_classifiers)
+        nscratch = lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers, n_classifiers)
         if nsaved == 0:
             check(-1, "transformer shape query")
-        out = torch.empty(n, s, d_out, dtype=torch.float32, device=x.device)
+        shape = (n, s, d_out) if n_classifiers == 1 else (n, s, n_classifiers, d_out)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
         saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
         sc = scratch(nscratch, x.device)
         check(lib.cpc_transformer_forward(ptr(x), ptr_array(params), ptr(out), ptr(saved), ptr(sc), n, s, d_model, d_out,
-                                          size_seq, n_layers, dropout_p, seed, stream_ptr(x.device)), "transformer_forward")
+                                          size_seq, n_layers, n_classifiers, dropout_p, seed, stream_ptr(x.device)),
+              "transformer_forward")
         ctx.save_for_backward(x, saved, *params)
-        ctx.cfg = (n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed)
+        ctx.cfg = (n, s, d_model, d_out, size_seq, n_layers, n_classifiers, dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         x, saved, *params = ctx.saved_tensors
-        n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed = ctx.cfg
+        n, s, d_model, d_out, size_seq, n_layers, n_classifiers, dropout_p, seed = ctx.cfg
         dout = f32c(dout)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         grads = grad_buffers(ctx.param_refs)
-        sc = scratch(lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers), x.device)
+        sc = scratch(lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers, n_classifiers), x.device)
         check(lib.cpc_transformer_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
-                                           n, s, d_model, d_out, size_seq, n_layers, dropout_p, seed, stream_ptr(x.device)),
+                                           n, s, d_model, d_out, size_seq, n_layers, n_classifiers, dropout_p, seed,
+                                           stream_ptr(x.device)),
               "transformer_backward")
-        return (dx, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
 class TransformerLayer(nn.Module):
@@ -132,7 +136,35 @@ class TransformerLayer(nn.Module):
         p = self.dropout_p if self.training else 0.0
         # a fresh dropout stream per call, derived from torch's CPU generator (so torch.manual_seed governs it)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
-        return _TransformerFn.apply(x, self.sizeSeq, 1, p, seed, *self._param_list())
+        return _TransformerFn.apply(x, self.sizeSeq, 1, 1, p, seed, *self._param_list())
+
+
+class MultiClassifierTransformerHead(nn.Module):
+    """transformers.py:137-158: one attention block whose feed-forward net emits `nclassifiers` residual branches;
+    forward(x [B, S, dmodel]) -> [B, S, nclassifiers, dout].  One fused library call, like TransformerLayer."""
+
+    def __init__(self, nclassifiers, sizeSeq=32, dmodel=512, dout=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
+        super(MultiClassifierTransformerHead, self).__init__()
+        if abspos:
+            raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
+        if nheads != 8 or dff != 2048:
+            raise NotImplementedError("the MI355X transformer kernels are built for nheads=8, dff=2048 (the reference's values)")
+        self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
+        self.ln_multihead = nn.LayerNorm(dmodel)
+        self.ffnetwork = FFNetwork(dmodel, dmodel * nclassifiers, dff, dropout)
+        self.last_linear = nn.Linear(dmodel, dout)
+        self.ln_ffnetwork = nn.LayerNorm(dout)
+        self.nclassifiers = nclassifiers
+        self.dout = dmodel
+        self.sizeSeq = sizeSeq
+        self.dropout_p = float(dropout)
+
+    _param_list = TransformerLayer._param_list
+
+    def forward(self, x):
+        p = self.dropout_p if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+        return _TransformerFn.apply(x, self.sizeSeq, 1, self.nclassifiers, p, seed, *self._param_list())
 
 
 def buildTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos):
@@ -141,4 +173,14 @@ def buildTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos):
         raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
     layerSequence = [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
                      for _ in range(nLayers)]
+    return nn.Sequential(*layerSequence)
+
+
+def buildMultHeadTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos, nHeads):
+    """transformers.py:190-212: nLayers - 1 TransformerLayers, then the multi-classifier head."""
+    if abspos:
+        raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
+    layerSequence = [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
+                     for _ in range(nLayers - 1)]
+    layerSequence += [MultiClassifierTransformerHead(nHeads, dmodel=dimAR, dout=dimEncoded, sizeSeq=sizeSeq, abspos=abspos)]
     return nn.Sequential(*layerSequence)

@@ -132,18 +132,22 @@ int cpc_gru_backward(const float *x, const float *const *params, const float *do
  *           ln_ffnetwork.weight, .bias [d_out]
  *   dropout_p  0 in eval mode; in training the masks come from a counter-based hash of (seed, index):
  *           pass the same (dropout_p, seed) to backward.
+ *   n_classifiers  1: plain TransformerLayers.  k > 1: the LAST layer is the multi-classifier head of
+ *           the multi-head predictor (MultiClassifierTransformerHead, transformers.py:137-158):
+ *           lin2.weight is [k*d, 2048], lin2.bias [k*d], and
+ *           out[n, s, c, :] = LN2(Wl (y + FFN(y)[c*d : (c+1)*d]) + bl), out is [n, s, k, d_out].
  *   backward: dout -> dx (may be NULL), grads (same order/shapes as params, overwritten).
  * ------------------------------------------------------------------------------------------ */
 int cpc_transformer_param_count(void);
-size_t cpc_transformer_saved_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers);
-size_t cpc_transformer_scratch_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers);
+size_t cpc_transformer_saved_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers, int n_classifiers);
+size_t cpc_transformer_scratch_bytes(int n, int s, int d_model, int d_out, int size_seq, int layers, int n_classifiers);
 int cpc_transformer_forward(const float *x, const float *const *params, float *out, void *saved,
                             void *scratch, int n, int s, int d_model, int d_out, int size_seq, int layers,
-                            float dropout_p, unsigned long long seed, cpc_stream_t stream);
+                            int n_classifiers, float dropout_p, unsigned long long seed, cpc_stream_t stream);
 int cpc_transformer_backward(const float *x, const float *const *params, const float *dout, void *saved,
                              void *scratch, float *dx, float *const *grads, int n, int s, int d_model,
-                             int d_out, int size_seq, int layers, float dropout_p, unsigned long long seed,
-                             cpc_stream_t stream);
+                             int d_out, int size_seq, int layers, int n_classifiers, float dropout_p,
+                             unsigned long long seed, cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Negative-index sampler of CPCUnsupersivedCriterion.sampleClean (criterion.py:247-266), HOST

@@ -105,9 +105,11 @@ def relpos_bias(q, krelpos):
     return qp.reshape(b, s + 1, s)[:, 1:, :]
 
 
-def transformer_layer_forward(x, p, prefix, n_heads=8, size_seq=None):
+def transformer_layer_forward(x, p, prefix, n_heads=8, size_seq=None, n_classifiers=1):
     """One TransformerLayer (transformers.py:119-134) in eval mode (dropout off).
-    x [N, S, D] with S == sizeSeq (the training window)."""
+    x [N, S, D] with S == sizeSeq (the training window).
+    n_classifiers > 1: MultiClassifierTransformerHead (transformers.py:137-158): lin2 emits n_classifiers
+    residual branches, output [N, S, n_classifiers, Dout]."""
     n, s, d = x.shape
     dk = d // n_heads
     assert size_seq is None or size_seq == s
@@ -129,6 +131,9 @@ def transformer_layer_forward(x, p, prefix, n_heads=8, size_seq=None):
     y = layer_norm(x + y, p[f"{prefix}ln_multihead.weight"], p[f"{prefix}ln_multihead.bias"])
     ff = torch.relu(y @ p[f"{prefix}ffnetwork.lin1.weight"].t() + p[f"{prefix}ffnetwork.lin1.bias"])
     ff = ff @ p[f"{prefix}ffnetwork.lin2.weight"].t() + p[f"{prefix}ffnetwork.lin2.bias"]
+    if n_classifiers > 1:            # transformers.py:153-158
+        ff = ff.view(n, s, n_classifiers, d)
+        y = y.view(n, s, 1, d)
     out = (y + ff) @ p[f"{prefix}last_linear.weight"].t() + p[f"{prefix}last_linear.bias"]
     return layer_norm(out, p[f"{prefix}ln_ffnetwork.weight"], p[f"{prefix}ln_ffnetwork.bias"])
 
@@ -163,6 +168,13 @@ def quality_weights(signal_quality, growth_rate, inflection_point_x, window):
 def transformer_predictors(p, k_steps, prefix="wPrediction.predictors."):
     """rnnMode='transformer' (criterion.py:136-143): K one-layer transformers applied to c[:, :W]."""
     return [(lambda c, i=i: transformer_layer_forward(c, p, f"{prefix}{i}.0.")) for i in range(k_steps)]
+
+
+def multihead_predictors(p, k_steps, prefix="wPrediction.predictor."):
+    """--multihead_rnn (criterion.py:44-94): one MultiClassifierTransformerHead, prediction k = head(c)[:, :, k].
+    (Evaluated once per k here: the oracle favours brevity.)"""
+    return [(lambda c, i=i: transformer_layer_forward(c, p, f"{prefix}0.", n_classifiers=k_steps)[:, :, i])
+            for i in range(k_steps)]
 
 
 def criterion_forward(c, z, predictors, ext_idx, n_neg, mode=None, n_skipped=0, weights=None):

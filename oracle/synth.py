@@ -49,7 +49,7 @@ def predictor_params(k_steps, dim_ar, dim_enc, seed, prefix="wPrediction.predict
     return {f"{prefix}{k}.weight": _uniform(rs, (dim_enc, dim_ar), bound) for k in range(k_steps)}
 
 
-def transformer_params(d_model, d_out, size_seq, seed, prefix="gAR.0.", n_heads=8, dff=2048):
+def transformer_params(d_model, d_out, size_seq, seed, prefix="gAR.0.", n_heads=8, dff=2048, n_classifiers=1):
     rs = np.random.RandomState(seed)
     dk = d_model // n_heads
     b = 1.0 / np.sqrt(d_model)
@@ -61,8 +61,8 @@ def transformer_params(d_model, d_out, size_seq, seed, prefix="gAR.0.", n_heads=
     p[f"{prefix}ln_multihead.bias"] = torch.from_numpy((0.1 * rs.standard_normal(d_model)).astype(np.float32))
     p[f"{prefix}ffnetwork.lin1.weight"] = _uniform(rs, (dff, d_model), b)
     p[f"{prefix}ffnetwork.lin1.bias"] = _uniform(rs, (dff,), b)
-    p[f"{prefix}ffnetwork.lin2.weight"] = _uniform(rs, (d_model, dff), 1.0 / np.sqrt(dff))
-    p[f"{prefix}ffnetwork.lin2.bias"] = _uniform(rs, (d_model,), 1.0 / np.sqrt(dff))
+    p[f"{prefix}ffnetwork.lin2.weight"] = _uniform(rs, (d_model * n_classifiers, dff), 1.0 / np.sqrt(dff))
+    p[f"{prefix}ffnetwork.lin2.bias"] = _uniform(rs, (d_model * n_classifiers,), 1.0 / np.sqrt(dff))
     p[f"{prefix}last_linear.weight"] = _uniform(rs, (d_out, d_model), b)
     p[f"{prefix}last_linear.bias"] = _uniform(rs, (d_out,), b)
     p[f"{prefix}ln_ffnetwork.weight"] = torch.from_numpy((1 + 0.1 * rs.standard_normal(d_out)).astype(np.float32))

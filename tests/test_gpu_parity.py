@@ -351,6 +351,54 @@ def test_criterion_transformer_predictors_vs_reference_golden(golden):
             assert_close(prm.grad, t(g["grad." + name]), 5e-4, f"grad {name}")
 
 
+def test_criterion_multihead_predictor_vs_reference_golden(golden):
+    """--multihead_rnn with rnnMode='transformer' (criterion.py:44-94, transformers.py:137-158,190-212), eval mode."""
+    g = golden("g9_criterion_multihead_pred.npz")
+    b, t_len, h, k, nn, seed = (int(v) for v in g["cfg"])
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, h, h, nn, rnnMode="transformer", sizeInputSeq=t_len, multihead_rnn=True)
+    assert sorted(n for n, _ in crit.named_parameters()) == [str(x) for x in g["param_names"]]
+    assert [str(tuple(v.shape)) for _, v in sorted(crit.state_dict().items())] == [str(x) for x in g["param_shapes"]]
+    sd = crit.state_dict()
+    sd.update(synth.transformer_params(h, h, t_len - k, seed=95, prefix="wPrediction.predictor.0.", n_classifiers=k))
+    crit.load_state_dict(sd)
+    crit = crit.to(DEV).eval()
+    c = synth.features((b, t_len, h), 96).to(DEV).requires_grad_(True)
+    z = synth.features((b, t_len, h), 97, relu=True).to(DEV).requires_grad_(True)
+    torch.manual_seed(seed)
+    losses, acc = crit(c, z, None)
+    assert_close(losses, t(g["losses"]), 1e-5, "losses")
+    assert torch.allclose(acc.cpu(), t(g["acc"]), atol=1.5 / (b * (t_len - k)))
+    losses.sum().backward()
+    assert_close(c.grad, t(g["dc"]), 2e-4, "dc")
+    assert_close(z.grad, t(g["dz"]), 1e-4, "dz")
+    for name, prm in crit.named_parameters():
+        assert_close(prm.grad, t(g["grad." + name]), 5e-4, f"grad {name}")
+
+
+def test_multiclassifier_head_vs_oracle_fp64():
+    """MultiClassifierTransformerHead at the training shape family (12 classifiers, sizeSeq 116, H = 64)."""
+    from cpc2_amd.transformers import buildMultHeadTransformerAR
+    n, s, d, k = 2, 116, 64, 12
+    net = buildMultHeadTransformerAR(d, d, 1, s, False, k)
+    p = synth.transformer_params(d, d, s, seed=33, prefix="0.", n_classifiers=k)
+    net.load_state_dict({**net.state_dict(), **p})
+    net = net.to(DEV).eval()
+    x = synth.features((n, s, d), 34)
+    p64 = {kk: v.double().requires_grad_(True) for kk, v in p.items()}
+    x64 = x.double().requires_grad_(True)
+    ref = O.transformer_layer_forward(x64, p64, "0.", n_classifiers=k)
+    gout = synth.features((n, s, k, d), 35)
+    (ref * gout.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = net(xd)
+    assert out.shape == (n, s, k, d)
+    assert_close(out, ref, 2e-5, "head out")
+    (out * gout.to(DEV)).sum().backward()
+    assert_close(xd.grad, x64.grad, 2e-4, "head dx")
+    for name, prm in net.named_parameters():
+        assert_close(prm.grad, p64[name].grad, 3e-4, f"head grad {name}")
+
+
 def test_criterion_indices_on_device_are_bit_exact(golden):
     g = golden("g1_negidx.npz")
     seed, b, t_len, k, nn = (int(v) for v in g["mid_cfg"])

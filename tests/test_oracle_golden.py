@@ -236,3 +236,23 @@ def test_criterion_with_transformer_predictors(golden):
     assert torch.allclose(losses, t(g["losses"]), atol=0, rtol=1e-6)
     assert torch.allclose(c.grad, t(g["dc"]), atol=1e-8, rtol=1e-4)
     assert torch.allclose(z.grad, t(g["dz"]), atol=1e-8, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- G9
+def test_criterion_with_multihead_predictor(golden):
+    """--multihead_rnn (criterion.py:44-94): one transformer head with nPredicts residual branches."""
+    g = golden("g9_criterion_multihead_pred.npz")
+    b, t_len, h, k, nn, seed = (int(v) for v in g["cfg"])
+    p = synth.transformer_params(h, h, t_len - k, seed=95, prefix="wPrediction.predictor.0.", n_classifiers=k)
+    p = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+    c = synth.features((b, t_len, h), 96).requires_grad_(True)
+    z = synth.features((b, t_len, h), 97, relu=True).requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(seed), b, t_len, t_len - k, nn)
+    losses, acc = O.criterion_forward(c, z, O.multihead_predictors(p, k), ext, nn)
+    losses.sum().backward()
+    assert torch.allclose(losses, t(g["losses"]), atol=0, rtol=1e-6)
+    assert torch.allclose(c.grad, t(g["dc"]), atol=1e-8, rtol=1e-4)
+    assert torch.allclose(z.grad, t(g["dz"]), atol=1e-8, rtol=1e-4)
+    for name, v in p.items():
+        ref = t(g["grad." + name])
+        assert torch.allclose(v.grad, ref, atol=2e-5 * float(ref.abs().max()) + 1e-9, rtol=1e-4), name

@@ -314,7 +314,29 @@ def g8():
     save("g8_criterion_transformer_pred.npz", **d)
 
 
+# ------------------------------------------------------------------ G9 criterion with the multi-head predictor
+def g9():
+    """--multihead_rnn with rnnMode='transformer' (criterion.py:44-94, transformers.py:137-158,190-212), eval mode."""
+    b, t_len, h, k, nn, seed = 3, 32, 32, 4, 8, 6
+    crit = ref_crit.CPCUnsupersivedCriterion(k, h, h, nn, rnnMode="transformer", sizeInputSeq=t_len, multihead_rnn=True)
+    sd = crit.state_dict()
+    sd.update(synth.transformer_params(h, h, t_len - k, seed=95, prefix="wPrediction.predictor.0.", n_classifiers=k))
+    crit.load_state_dict(sd)
+    crit.eval()
+    c = synth.features((b, t_len, h), seed=96).requires_grad_(True)
+    z = synth.features((b, t_len, h), seed=97, relu=True).requires_grad_(True)
+    torch.manual_seed(seed)
+    losses, acc = crit(c, z, None)
+    losses.sum().backward()
+    d = {"cfg": np.array([b, t_len, h, k, nn, seed]), "losses": losses, "acc": acc, "dc": c.grad, "dz": z.grad}
+    for name, prm in crit.named_parameters():
+        d["grad." + name] = prm.grad
+    d["param_names"] = np.array(sorted(n for n, _ in crit.named_parameters()))
+    d["param_shapes"] = np.array([str(tuple(v.shape)) for _, v in sorted(crit.state_dict().items())])
+    save("g9_criterion_multihead_pred.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for name in which:
         globals()[name]()
