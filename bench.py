@@ -45,7 +45,8 @@ CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
 def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
     """Algorithmic FLOPs (2 per MAC) of everything that runs on gemm_nt_kernel in ONE step, and the
-    number of launches: conv1..4 forward + backward-data (the s phases side by side in one launch), GRU input projection
+    number of launches (a lower bound: the backward-data products add a one-row-per-window boundary launch where
+    that saves a round of tiles): conv1..4 forward + backward-data (the s phases side by side), GRU input projection
     + its dX, predictor GEMM + its dC.  Padding / junk virtual rows are NOT counted."""
     h, n = cfg["hidden"], (b if dedup else 2 * b)
     lens = [WINDOW]
@@ -263,7 +264,7 @@ def main():
                                # HBM bytes per launch from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE KiB, mean over
                                # the step's 12 launches: profiles/r01_v3_pmc_summary.md), valid for the default workload only
                                "traffic": 4.35e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
-                               "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                               "algorithmic_gflop_per_launch": round(flops / max(k["launches_per_step"], 1.0) / 1e9, 3),
                                "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
         out["kernels"] = kernels
         if args.cpu_seconds > 0 and world == 1:
