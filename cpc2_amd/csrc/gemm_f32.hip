@@ -402,6 +402,7 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
         splits = (int)std::min<long>(cdiv(3 * 256, blocks), K / (4 * BK));
     a.kchunk = (int)(cdiv(cdiv(K, splits), BK) * BK);
     splits = (int)cdiv(K, a.kchunk);
+
     if (splits > 1) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
     dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);

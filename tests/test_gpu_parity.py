@@ -47,7 +47,10 @@ def to64(p):
 
 
 # ----------------------------------------------------------------------------- GEMMs
-@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 200, 72), (1, 5, 3), (1026, 256, 2048), (257, 770, 24)])
+# (65536, 128, 1024) and (32768 + 77, 256, 1056): the software-pipelined 256 x 128 kernel (whole rounds of 256 workgroups),
+# the second with a ragged last row tile and an odd number of K steps
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 200, 72), (1, 5, 3), (1026, 256, 2048), (257, 770, 24),
+                                   (65536, 128, 1024), (32768 + 77, 256, 1056)])
 def test_gemm_nt(m, n, k):
     lib = _lib.load()
     g = torch.Generator().manual_seed(m * 7 + n)
