@@ -201,20 +201,27 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
     const float wgt = (a.weights != nullptr ? a.weights[bt] : 1.f) * a.inv_count;
 
     for (int g = lane; g < a.lw; g += 64) rowidx[g] = g < ncand ? (int)nce_row(a, bb, t, g) : -1;
-    for (int i = lane; i < NCE_ROWS * a.lw; i += 64) {
-        const int k = i / a.lw, g = i - k * a.lw;
-        float v = 0.f;
+    // dS[k][g]: one prediction step k at a time (wave-uniform), lanes over the candidates: the logits row of (b,t,k)
+    // is read coalesced and nothing is divided
+    for (int k = 0; k < NCE_ROWS; ++k) {
+        float coef = 0.f, l = 0.f;
+        const float *lg = a.logits;
         if (k < a.K) {
-            const float coef = a.dloss[k] * wgt * inv_h;
-            const float *lg = a.logits + (bt * a.K + k) * (a.Nneg + 1);
-            const float l = a.lse[bt * a.K + k];
-            if (g < NCE_POS) {
-                if (g == k) v = coef * (expf(lg[0] - l) - 1.f);
-            } else if (g - NCE_POS < a.Nneg) {
-                v = coef * expf(lg[1 + g - NCE_POS] - l);
-            }
+            coef = a.dloss[k] * wgt * inv_h;
+            lg = a.logits + (bt * a.K + k) * (a.Nneg + 1);
+            l = a.lse[bt * a.K + k];
         }
-        dS[i] = v;
+        for (int g = lane; g < a.lw; g += 64) {
+            float v = 0.f;
+            if (k < a.K) {
+                if (g < NCE_POS) {
+                    if (g == k) v = coef * (expf(lg[0] - l) - 1.f);
+                } else if (g - NCE_POS < a.Nneg) {
+                    v = coef * expf(lg[1 + g - NCE_POS] - l);
+                }
+            }
+            dS[k * a.lw + g] = v;
+        }
     }
     __syncthreads();                           // one wave: orders the LDS writes before the reads below
 
