@@ -124,3 +124,54 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+# ----------------------------------------------------------------------------- factories (reference: cpc/unit_tests.py:279-348)
+def _default_args(**kw):
+    """The reference's architecture defaults (cpc_default_config.py:18-78) for the flags the factories read."""
+    import types
+    args = types.SimpleNamespace(hiddenEncoder=256, hiddenGar=256, nPredicts=12, negativeSamplingExt=128, sizeWindow=20480,
+                                 samplingType="samespeaker", cpc_mode=None, encoder_type="cpc", normMode="layerNorm",
+                                 arMode="GRU", nLevelsGRU=1, rnnMode="linear", dropout=False, abspos=False)
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return args
+
+
+def test_build_cpc_encoder_like_reference_TestEncoderBuilder():
+    from cpc2_amd.train import getEncoder
+    enc = getEncoder(_default_args())
+    assert isinstance(enc, cpc2_amd.CPCEncoder) and enc.dimEncoded == 256 and enc.DOWNSAMPLING == 160
+    for other in ("mfcc", "lfb"):                      # not on the hot path: refused, never silently replaced
+        with pytest.raises(NotImplementedError):
+            getEncoder(_default_args(encoder_type=other))
+
+
+def test_build_ar_like_reference_TestARBuilder():
+    import torch
+    from cpc2_amd.train import getAR
+    ar = getAR(_default_args(arMode="GRU"))
+    assert isinstance(ar, cpc2_amd.CPCAR) and isinstance(ar.baseNet, torch.nn.GRU) and ar.getDimOutput() == 256
+    assert getAR(_default_args(arMode="GRU", samplingType="sequential")).keepHidden
+    assert getAR(_default_args(arMode="GRU", cpc_mode="reverse")).reverse
+    args = _default_args(arMode="transformer", hiddenGar=256)
+    tr = getAR(args)
+    assert isinstance(tr, torch.nn.Sequential) and len(tr) == 1 and tr[0].sizeSeq == 128 and args.hiddenGar == 256
+    for other in ("LSTM", "RNN"):
+        with pytest.raises(NotImplementedError):
+            getAR(_default_args(arMode=other))
+
+
+def test_build_criterion_variants():
+    from cpc2_amd.train import getCriterion
+    from cpc2_amd.criterion import MultiHeadPredictionNetwork, NoneCriterion, PredictionNetwork
+    crit = getCriterion(_default_args(), 160)
+    assert isinstance(crit.wPrediction, PredictionNetwork) and len(crit.wPrediction.predictors) == 12
+    assert crit.wPrediction.predictors[0].weight.shape == (256, 256)
+    tr = getCriterion(_default_args(rnnMode="transformer"), 160)
+    assert tr.wPrediction.predictors[0][0].sizeSeq == 116
+    mh = getCriterion(_default_args(rnnMode="transformer", multihead_rnn=True), 160)
+    assert isinstance(mh.wPrediction, MultiHeadPredictionNetwork) and mh.wPrediction.predictor[0].nclassifiers == 12
+    assert isinstance(getCriterion(_default_args(cpc_mode="none"), 160), NoneCriterion)
+    with pytest.raises(ValueError):
+        getCriterion(_default_args(cpc_mode="bert"), 160)
