@@ -323,6 +323,159 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA form of the attention for head size 32 (d_model = 256) and sizeSeq <= 128: one workgroup per (sequence chunk,
+// head), wave w owns query rows 32w .. 32w+31.  f32 MFMA 32x32x2 throughout (exact f32 products).  K, Krelpos^T and V^T
+// sit in LDS with the reduction index contiguous, so every operand fragment is a 16-byte read (lane (r, h) takes
+// k = 8q + 4h + 0..3 of its row for q = 0..3; A and B use the same k order, which is all the product needs).
+//   S  = Q K^T                       causal: only column tiles jt <= w
+//   R  = Q Krelpos                   [32 x SS]; S[i][j] += R[i][SS-1-(i-j)]  (transformers.py:61-66), gathered through LDS
+//   P  = softmax(S / sqrt(dk) + mask);  probs <- P;  Pd = dropout(P)
+//   ctx = Pd V                       Pd staged through LDS to become the A operand
+constexpr int AT_LD = 36;            // floats per Ks / RsT row (32 + pad)
+constexpr int AT_LP = 132;           // floats per VsT / Ps row (128 + pad)
+constexpr size_t AT_FWD_LDS = sizeof(float) * (2 * 128 * AT_LD + 32 * AT_LP + 4 * 32 * AT_LP);
+
+typedef float at_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void at_mfma4(at_f32x16 &acc, const float4 &a4, const float4 &b4)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ int at_row(int e, int h2) { return (e & 3) + 8 * (e >> 2) + 4 * h2; }   // C/D row of register e
+__device__ __forceinline__ void at_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ks = smem;                        // [128][AT_LD]   K rows
+    float *RsT = Ks + 128 * AT_LD;           // [128][AT_LD]   RsT[m][d] = Krelpos[d][m]
+    float *VsT = RsT + 128 * AT_LD;          // [32][AT_LP]    VsT[d][j] = V[j][d]
+    float *Ps = VsT + 32 * AT_LP;            // [4][32][AT_LP] per-wave staging (R tiles, then Pd)
+    const int SS = a.SS;
+    const int cid = blockIdx.x;              // (n*heads + head)*chunks + c
+    const int c = cid % a.chunks, nh = cid / a.chunks;
+    const int head = nh % TR_HEADS, n = nh / TR_HEADS;
+    const long row0 = (long)n * a.S + (long)c * SS;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < 128 * 8; i += 256) {
+        const int j = i >> 3, d4 = (i & 7) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (j < SS) {
+            const float *src = a.qkv + (row0 + j) * 3 * a.D + head * 32 + d4;
+            kv = *reinterpret_cast<const float4 *>(src + a.D);
+            vv = *reinterpret_cast<const float4 *>(src + 2 * a.D);
+        }
+        *reinterpret_cast<float4 *>(&Ks[j * AT_LD + d4]) = kv;
+        VsT[(d4 + 0) * AT_LP + j] = vv.x; VsT[(d4 + 1) * AT_LP + j] = vv.y;
+        VsT[(d4 + 2) * AT_LP + j] = vv.z; VsT[(d4 + 3) * AT_LP + j] = vv.w;
+    }
+    if (a.krel != nullptr)
+        for (int i = tid; i < 32 * 128; i += 256) {
+            const int d = i >> 7, m = i & 127;
+            RsT[m * AT_LD + d] = m < SS ? a.krel[d * SS + m] : 0.f;
+        }
+    __syncthreads();
+
+    const int lane = tid & 63, w = tid >> 6, r32 = lane & 31, h2 = lane >> 5;
+    float *Pw = Ps + w * 32 * AT_LP;
+    const int iq = 32 * w + r32;                                 // this lane's A-operand row
+    float4 qf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        qf[q] = iq < SS ? *reinterpret_cast<const float4 *>(a.qkv + (row0 + iq) * 3 * a.D + head * 32 + 8 * q + 4 * h2)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    at_f32x16 sc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[jt][e] = 0.f;
+        if (jt <= w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                at_mfma4(sc[jt], qf[q], *reinterpret_cast<const float4 *>(&Ks[(32 * jt + r32) * AT_LD + 8 * q + 4 * h2]));
+        }
+    }
+    if (a.krel != nullptr) {
+        const int m_min = SS - 32 * w - 32 > 0 ? SS - 32 * w - 32 : 0;
+        for (int mt = m_min >> 5; mt <= (SS - 1) >> 5; ++mt) {
+            at_f32x16 racc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) racc[e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                at_mfma4(racc, qf[q], *reinterpret_cast<const float4 *>(&RsT[(32 * mt + r32) * AT_LD + 8 * q + 4 * h2]));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Pw[at_row(e, h2) * AT_LP + 32 * mt + r32] = racc[e];
+        }
+        at_wave_sync();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt <= w) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int il = at_row(e, h2), i = 32 * w + il, j = 32 * jt + r32;
+                    if (j <= i && i < SS) sc[jt][e] += Pw[il * AT_LP + SS - 1 - i + j];
+                }
+            }
+        at_wave_sync();                                          // Pw is reused for Pd below
+    }
+    // softmax over j <= i, row by row (a row lives in one 32-lane half, over the tiles jt <= w)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int il = at_row(e, h2), i = 32 * w + il;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = 32 * jt + r32;
+            const bool ok = jt <= w && j <= i && i < SS;
+            sc[jt][e] = ok ? sc[jt][e] * a.inv_sqrt_dk : -INFINITY;
+            mx = fmaxf(mx, sc[jt][e]);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            sc[jt][e] = sc[jt][e] == -INFINITY ? 0.f : expf(sc[jt][e] - mx);
+            sum += sc[jt][e];
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt > w) continue;
+            const int j = 32 * jt + r32;
+            const float p = sc[jt][e] * inv;
+            float pd = 0.f;
+            if (i < SS && j < SS) {
+                const long idx = ((long)cid * SS + i) * SS + j;
+                a.probs[idx] = p;
+                pd = p * drop_mul(a.seed, (uint64_t)idx, a.thresh, a.scale);
+            }
+            Pw[il * AT_LP + j] = pd;
+        }
+    }
+    at_wave_sync();
+    // ctx = Pd V over j < 32 (w + 1)
+    at_f32x16 cx;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cx[e] = 0.f;
+    for (int kq = 0; kq < 4 * (w + 1); ++kq)
+        at_mfma4(cx, *reinterpret_cast<const float4 *>(&Pw[r32 * AT_LP + 8 * kq + 4 * h2]),
+                 *reinterpret_cast<const float4 *>(&VsT[r32 * AT_LP + 8 * kq + 4 * h2]));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = 32 * w + at_row(e, h2);
+        if (i < SS) a.ctx[(row0 + i) * a.D + head * 32 + r32] = cx[e];
+    }
+}
+
 // one workgroup per sequence chunk of one head; loops over its query tiles.  dK, dV and dKrelpos accumulate
 // in registers: thread (j = tid/2, half) owns K/V row j, thread (m = tid%128, half) owns Krelpos column m.
 template <int DKH>   // dk / 2
@@ -581,10 +734,17 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
         aa.qkv = L.qkv[l]; aa.krel = p[P_KREL]; aa.probs = L.probs[l]; aa.ctx = L.ctx[l];
         aa.N = N; aa.S = S; aa.D = D; aa.dk = L.dk; aa.SS = SS; aa.chunks = L.chunks;
         aa.seed = lseed; aa.thresh = thresh; aa.scale = scale; aa.inv_sqrt_dk = 1.f / std::sqrt((float)L.dk);
-        CPC_TRY(allow_lds_tr(attn_fwd_kernel, L.lds_fwd));
-        const int tiles = (SS + TR_QT - 1) / TR_QT;
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(N * TR_HEADS * L.chunks * tiles)), dim3(256), L.lds_fwd, st, aa);
-        CPC_CHECK_LAUNCH("attn_fwd_kernel");
+        static const bool attn_valu = getenv("CPC_ATTN_VALU") != nullptr;       // the VALU kernels, for A/B tests
+        if (L.dk == 32 && !attn_valu) {
+            CPC_TRY(allow_lds_tr(attn_fwd_mfma_kernel, AT_FWD_LDS));
+            hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(N * TR_HEADS * L.chunks)), dim3(256), AT_FWD_LDS, st, aa);
+            CPC_CHECK_LAUNCH("attn_fwd_mfma_kernel");
+        } else {
+            CPC_TRY(allow_lds_tr(attn_fwd_kernel, L.lds_fwd));
+            const int tiles = (SS + TR_QT - 1) / TR_QT;
+            hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(N * TR_HEADS * L.chunks * tiles)), dim3(256), L.lds_fwd, st, aa);
+            CPC_CHECK_LAUNCH("attn_fwd_kernel");
+        }
         CPC_TRY(gemm_nt(L.ctx[l], D, p[P_WO], D, L.o, D, nullptr, R, D, D, none, st));                       // Wo (:104)
         CPC_TRY(launch_ln_fwd(xin, L.o, p[P_LN1W], p[P_LN1B], L.y[l], L.xh1[l], L.rstd1[l], R, D, 1e-5f, st));  // :133
         CPC_TRY(gemm_nt(L.y[l], D, p[P_W1], D, L.hdrop[l], TR_DFF, p[P_B1], R, TR_DFF, D, none, st));           // lin1 (:116)

@@ -476,7 +476,10 @@ def test_transformer_vs_reference_golden(golden):
         assert_close(p.grad, t(g["grad." + name]), 2e-4, f"transformer grad {name}")
 
 
-@pytest.mark.parametrize("d_model,size_seq,s,n", [(256, 128, 128, 3), (64, 32, 96, 2), (512, 128, 128, 1)])
+# d_model 256 (head size 32) takes the MFMA attention kernels: full 128-frame window, the predictors' 116 frames (ragged
+# last tile), 32-frame blocks of a longer input, 40 frames (two waves idle)
+@pytest.mark.parametrize("d_model,size_seq,s,n", [(256, 128, 128, 3), (64, 32, 96, 2), (512, 128, 128, 1), (256, 116, 116, 2),
+                                                    (256, 32, 96, 2), (256, 40, 40, 3)])
 def test_transformer_vs_oracle_fp64(d_model, size_seq, s, n):
     params = synth.transformer_params(d_model, d_model, size_seq, 81)
     net = load_transformer(d_model, d_model, size_seq, params).eval()
@@ -514,6 +517,27 @@ def test_transformer_dropout_training_mode():
     a.sum().backward()
     assert torch.isfinite(x.grad).all()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_transformer_dropout_gradient_is_consistent_at_head_size_32():
+    """d_model 256 (MFMA attention), p = 0.1: forward and backward must draw the same masks -- checked with a
+    directional finite difference of sum(out * g) along a random direction in x (fp32: loose tolerance)."""
+    params = synth.transformer_params(256, 256, 116, 93)
+    net = load_transformer(256, 256, 116, params).train()
+    x = synth.features((2, 116, 256), 94, relu=True).to(DEV)
+    g = synth.features((2, 116, 256), 95).to(DEV)
+    v = synth.features((2, 116, 256), 96).to(DEV)
+
+    def f(inp):
+        torch.manual_seed(11)                  # same dropout seed every call
+        return (net(inp) * g).sum()
+    xr = x.clone().requires_grad_(True)
+    f(xr).backward()
+    analytic = float((xr.grad * v).sum())
+    eps = 1e-2
+    with torch.no_grad():
+        numeric = float((f(x + eps * v).double() - f(x - eps * v).double()) / (2 * eps))
+    assert abs(analytic - numeric) <= 2e-2 * max(1.0, abs(numeric)), (analytic, numeric)
 
 
 def test_model_with_transformer_ar_train_step_vs_oracle():
