@@ -476,6 +476,196 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
     }
 }
 
+// Backward twin (head size 32, sizeSeq <= 128), same workgroup / wave decomposition.  Wave w owns query rows 32w.. for
+// the row-wise quantities (dPd, dS, dQ) and key rows / relative positions 32w.. for the column-wise ones (dV, dK,
+// dKrelpos).  With M the dropout multiplier, Pd = P.M (P is read back from the forward pass):
+//   dPd = dO V^T;  dP = dPd.M;  dS = P.(dP - rowsum(dP.P)) / sqrt(dk)
+//   dV  = Pd^T dO;   dK = dS^T Q;   dQ = dS K + T Krelpos^T;   dKrelpos^T = T^T Q,   T[i][m] = dS[i][m - (SS-1-i)]
+// Operands whose reduction index is the LDS row (Pd^T, dS^T, T^T, T) are read 4 bytes at a time (consecutive lanes hit
+// consecutive addresses); everything else is a 16-byte fragment read.
+constexpr size_t AT_BWD_LDS = sizeof(float) * (4 * 32 * AT_LP + 128 * AT_LD + 128 * AT_LP);
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *QT = smem;                        // [32][AT_LP]   QT[d][i]
+    float *KT = QT + 32 * AT_LP;             // [32][AT_LP]   KT[d][j]
+    float *OT = KT + 32 * AT_LP;             // [32][AT_LP]   dO^T[d][i]
+    float *Rk = OT + 32 * AT_LP;             // [32][AT_LP]   Krelpos[d][m]
+    float *Vs = Rk + 32 * AT_LP;             // [128][AT_LD]  V rows
+    float *PS = Vs + 128 * AT_LD;            // [128][AT_LP]  Pd, then dS
+    const int SS = a.SS;
+    const int cid = blockIdx.x;
+    const int c = cid % a.chunks, nh = cid / a.chunks;
+    const int head = nh % TR_HEADS, n = nh / TR_HEADS;
+    const long row0 = (long)n * a.S + (long)c * SS;
+    const int tid = threadIdx.x;
+    const bool rel = a.krel != nullptr;
+
+    for (int i = tid; i < 128 * 8; i += 256) {
+        const int j = i >> 3, d4 = (i & 7) * 4;
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, o4 = q4;
+        if (j < SS) {
+            const float *src = a.qkv + (row0 + j) * 3 * a.D + head * 32 + d4;
+            q4 = *reinterpret_cast<const float4 *>(src);
+            k4 = *reinterpret_cast<const float4 *>(src + a.D);
+            v4 = *reinterpret_cast<const float4 *>(src + 2 * a.D);
+            o4 = *reinterpret_cast<const float4 *>(a.dctx + (row0 + j) * a.D + head * 32 + d4);
+        }
+        *reinterpret_cast<float4 *>(&Vs[j * AT_LD + d4]) = v4;
+        QT[(d4 + 0) * AT_LP + j] = q4.x; QT[(d4 + 1) * AT_LP + j] = q4.y; QT[(d4 + 2) * AT_LP + j] = q4.z; QT[(d4 + 3) * AT_LP + j] = q4.w;
+        KT[(d4 + 0) * AT_LP + j] = k4.x; KT[(d4 + 1) * AT_LP + j] = k4.y; KT[(d4 + 2) * AT_LP + j] = k4.z; KT[(d4 + 3) * AT_LP + j] = k4.w;
+        OT[(d4 + 0) * AT_LP + j] = o4.x; OT[(d4 + 1) * AT_LP + j] = o4.y; OT[(d4 + 2) * AT_LP + j] = o4.z; OT[(d4 + 3) * AT_LP + j] = o4.w;
+    }
+    for (int i = tid; i < 32 * 128; i += 256) {
+        const int d = i >> 7, m = i & 127;
+        Rk[d * AT_LP + m] = (rel && m < SS) ? a.krel[d * SS + m] : 0.f;
+    }
+
+    const int lane = tid & 63, w = tid >> 6, r32 = lane & 31, h2 = lane >> 5;
+    // ---- phase 1: dPd = dO V^T for this wave's query rows; Pd -> PS; dS kept in registers
+    const int iq = 32 * w + r32;
+    float4 of[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        of[q] = iq < SS ? *reinterpret_cast<const float4 *>(a.dctx + (row0 + iq) * a.D + head * 32 + 8 * q + 4 * h2)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    at_f32x16 ds[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ds[jt][e] = 0.f;
+        if (jt <= w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                at_mfma4(ds[jt], of[q], *reinterpret_cast<const float4 *>(&Vs[(32 * jt + r32) * AT_LD + 8 * q + 4 * h2]));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int il = at_row(e, h2), i = 32 * w + il;
+        float pv[4], rs = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = 32 * jt + r32;
+            pv[jt] = 0.f;
+            float da = 0.f;
+            if (jt <= w) {
+                float pd = 0.f;
+                if (j <= i && i < SS) {
+                    const long idx = ((long)cid * SS + i) * SS + j;
+                    const float mul = drop_mul(a.seed, (uint64_t)idx, a.thresh, a.scale);
+                    pv[jt] = a.probs[idx];
+                    pd = pv[jt] * mul;
+                    da = ds[jt][e] * mul;                   // d loss / d P (through the dropout)
+                }
+                PS[i * AT_LP + j] = pd;
+            }
+            ds[jt][e] = da;
+            rs = fmaf(da, pv[jt], rs);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ds[jt][e] = pv[jt] * (ds[jt][e] - rs) * a.inv_sqrt_dk;      // 0 where masked
+    }
+    __syncthreads();
+    // ---- phase 2: dV[j][d] = sum_{i >= j} Pd[i][j] dO[i][d] for key rows j = 32w + r32
+    const int jk = 32 * w + r32;
+    {
+        at_f32x16 dv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[e] = 0.f;
+        for (int kq = 4 * w; kq < 16; ++kq) {
+            const int i0 = 8 * kq + 4 * h2;
+            const float4 a4 = make_float4(PS[(i0 + 0) * AT_LP + jk], PS[(i0 + 1) * AT_LP + jk], PS[(i0 + 2) * AT_LP + jk], PS[(i0 + 3) * AT_LP + jk]);
+            at_mfma4(dv, a4, *reinterpret_cast<const float4 *>(&OT[r32 * AT_LP + i0]));
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * w + at_row(e, h2);
+            if (j < SS) a.dqkv[(row0 + j) * 3 * a.D + 2 * a.D + head * 32 + r32] = dv[e];
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: dS -> PS
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+        if (jt <= w) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) PS[(32 * w + at_row(e, h2)) * AT_LP + 32 * jt + r32] = ds[jt][e];
+        }
+    __syncthreads();
+    // ---- phase 4a: dK[j][d] = sum_{i >= j} dS[i][j] Q[i][d]
+    {
+        at_f32x16 dkk;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkk[e] = 0.f;
+        for (int kq = 4 * w; kq < 16; ++kq) {
+            const int i0 = 8 * kq + 4 * h2;
+            const float4 a4 = make_float4(PS[(i0 + 0) * AT_LP + jk], PS[(i0 + 1) * AT_LP + jk], PS[(i0 + 2) * AT_LP + jk], PS[(i0 + 3) * AT_LP + jk]);
+            at_mfma4(dkk, a4, *reinterpret_cast<const float4 *>(&QT[r32 * AT_LP + i0]));
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * w + at_row(e, h2);
+            if (j < SS) a.dqkv[(row0 + j) * 3 * a.D + a.D + head * 32 + r32] = dkk[e];
+        }
+    }
+    // ---- phase 4b: dQ[i][d] = sum_{j <= i} dS[i][j] K[j][d]  (+ sum_m T[i][m] Krelpos[d][m])
+    {
+        at_f32x16 dq;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+        for (int kq = 0; kq < 4 * (w + 1); ++kq)
+            at_mfma4(dq, *reinterpret_cast<const float4 *>(&PS[iq * AT_LP + 8 * kq + 4 * h2]),
+                     *reinterpret_cast<const float4 *>(&KT[r32 * AT_LP + 8 * kq + 4 * h2]));
+        if (rel) {
+            // T[i][m] = dS[i][m - (SS-1-i)] for 0 <= m - (SS-1-i) <= i, else 0; m ranges over [SS-1-i, SS-1]
+            const int m_min = SS - 32 * w - 32 > 0 ? SS - 32 * w - 32 : 0;
+            const int sh = SS - 1 - iq;                           // this lane's row shift
+            for (int kq = m_min >> 3; kq <= (SS - 1) >> 3; ++kq) {
+                const int mb = 8 * kq + 4 * h2;
+                float tv[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int j = mb + x - sh;
+                    tv[x] = (j >= 0 && j <= iq && iq < SS) ? PS[iq * AT_LP + j] : 0.f;
+                }
+                at_mfma4(dq, make_float4(tv[0], tv[1], tv[2], tv[3]), *reinterpret_cast<const float4 *>(&Rk[r32 * AT_LP + mb]));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = 32 * w + at_row(e, h2);
+            if (i < SS) a.dqkv[(row0 + i) * 3 * a.D + head * 32 + r32] = dq[e];
+        }
+    }
+    // ---- phase 4c: dKrelpos^T[m][d] = sum_i T[i][m] Q[i][d] for m = 32w + r32
+    if (rel) {
+        at_f32x16 dr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dr[e] = 0.f;
+        const int mk = 32 * w + r32;
+        for (int kq = 0; kq < 16; ++kq) {
+            const int i0 = 8 * kq + 4 * h2;
+            float tv[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int i = i0 + x, j = mk - (SS - 1 - i);
+                tv[x] = (i < SS && mk < SS && j >= 0 && j <= i) ? PS[i * AT_LP + j] : 0.f;
+            }
+            at_mfma4(dr, make_float4(tv[0], tv[1], tv[2], tv[3]), *reinterpret_cast<const float4 *>(&QT[r32 * AT_LP + i0]));
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = 32 * w + at_row(e, h2);
+            if (m < SS) a.dkrel_part[((long)cid * 32 + r32) * SS + m] = dr[e];
+        }
+    }
+}
+
 // one workgroup per sequence chunk of one head; loops over its query tiles.  dK, dV and dKrelpos accumulate
 // in registers: thread (j = tid/2, half) owns K/V row j, thread (m = tid%128, half) owns Krelpos column m.
 template <int DKH>   // dk / 2
@@ -823,6 +1013,11 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         aa.dctx = L.db; aa.dqkv = L.dqkv; aa.dkrel_part = L.krel_part;
         const int nchunk = N * TR_HEADS * L.chunks;
         int status = CPC_OK;
+        static const bool attn_valu = getenv("CPC_ATTN_VALU") != nullptr;
+        if (L.dk == 32 && !attn_valu) {
+            status = allow_lds_tr(attn_bwd_mfma_kernel, AT_BWD_LDS);
+            if (status == CPC_OK) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)nchunk), dim3(256), AT_BWD_LDS, st, aa);
+        } else
         switch (L.dk / 2) {
 #define TR_CASE(X) case X: status = allow_lds_tr(attn_bwd_kernel<X>, L.lds_bwd); \
         if (status == CPC_OK) hipLaunchKernelGGL(attn_bwd_kernel<X>, dim3((unsigned)nchunk), dim3(256), L.lds_bwd, st, aa); break;
