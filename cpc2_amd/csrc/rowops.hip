@@ -115,13 +115,20 @@ __global__ void colsum_stage1_kernel(const float *part, long rows, long ld, int 
 
 __global__ void colsum_stage2_kernel(const float *scratch, int split, int width, float *out0, float *out1, float *out2, int seg)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+    // thread (x, y): column blockIdx.x*64 + x, partial rows y, y + 4, ...; the 4 row groups meet in LDS
+    __shared__ float red[4][65];
+    const int c = blockIdx.x * 64 + threadIdx.x;
     float t = 0.f;
-    for (int i = 0; i < split; ++i) t += scratch[(long)i * width + c];
-    const int which = c / seg, off = c - which * seg;
-    float *out = which == 0 ? out0 : (which == 1 ? out1 : out2);
-    out[off] = t;
+    if (c < width)
+        for (int i = threadIdx.y; i < split; i += 4) t += scratch[(long)i * width + c];
+    red[threadIdx.y][threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < width) {
+        t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int which = c / seg, off = c - which * seg;
+        float *out = which == 0 ? out0 : (which == 1 ? out1 : out2);
+        out[off] = t;
+    }
 }
 
 size_t colsum_split_scratch_bytes(int width) { return align_up((size_t)COLSUM_SPLIT * width * sizeof(float), 256); }
@@ -133,7 +140,7 @@ int colsum_split(const float *part, long rows, long ld, int width, float *out0, 
     float *sc = static_cast<float *>(scratch);
     hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)cdiv(width, 64), COLSUM_SPLIT), dim3(64, 16), 0, st, part, rows, ld, width, sc);
     CPC_CHECK_LAUNCH("colsum_stage1_kernel");
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)cdiv(width, 256)), dim3(256), 0, st, sc, COLSUM_SPLIT, width, out0, out1, out2, seg);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)cdiv(width, 64)), dim3(64, 4), 0, st, sc, COLSUM_SPLIT, width, out0, out1, out2, seg);
     CPC_CHECK_LAUNCH("colsum_stage2_kernel");
     return CPC_OK;
 }
