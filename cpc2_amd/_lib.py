@@ -118,7 +118,7 @@ def ptr(t):
 
 
 def ptr_array(tensors):
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
 
 
 # grow-only scratch arena per device; every kernel is enqueued on the current stream in program
@@ -144,6 +144,9 @@ def grad_buffers(params):
     otherwise (accumulation across backward passes) a private buffer is returned and autograd adds it."""
     out = []
     for p in params:
+        if p is None:                      # an absent optional parameter (e.g. Krelpos with abspos=True)
+            out.append(None)
+            continue
         home = getattr(p, "_cpc_flat", None)
         if home is not None and p.grad is None:
             flat, off = home

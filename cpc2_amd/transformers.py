@@ -8,8 +8,9 @@ class names, constructor signatures, parameter/buffer names (so state dicts are 
 default initialisation under a given torch seed).  The sub-modules are parameter containers: the whole
 layer runs as ONE fused call into libcpc2_hip.so (cpc_transformer_forward / _backward).
 
-Not supported on the MI355X path: abspos=True (StaticPositionEmbedding), sequence lengths that are not a
-multiple of sizeSeq (the reference zero-pads them, transformers.py:41-48).
+abspos=True (StaticPositionEmbedding :161-173 in front, no relative-position bias) is supported; sequence lengths
+that are not a multiple of sizeSeq are zero-padded to the next multiple like the reference does (transformers.py:41-48
+pads Q, K and V, which have no bias: the same as padding the layer's input) and the outputs of the padding dropped.
 """
 import math
 
@@ -72,7 +73,7 @@ class _TransformerFn(torch.autograd.Function):
         lib = _lib.load()
         x = f32c(x)
         ctx.param_refs = params
-        params = tuple(f32c(p) for p in params)
+        params = tuple(f32c(p) if p is not None else None for p in params)
         n, s, d_model = x.shape
         per = lib.cpc_transformer_param_count()
         d_out = params[(n_layers - 1) * per + 11].shape[0]            # last layer's last_linear.weight [d_out, d]
@@ -110,8 +111,6 @@ class _TransformerFn(torch.autograd.Function):
 class TransformerLayer(nn.Module):
     def __init__(self, sizeSeq=32, dmodel=512, dout=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
         super(TransformerLayer, self).__init__()
-        if abspos:
-            raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
         if nheads != 8 or dff != 2048:
             raise NotImplementedError("the MI355X transformer kernels are built for nheads=8, dff=2048 (the reference's values)")
         self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
@@ -125,7 +124,7 @@ class TransformerLayer(nn.Module):
 
     def _param_list(self):
         m = self.multihead
-        return [m.Wq.weight, m.Wk.weight, m.Wv.weight, m.Wo.weight, m.Att.Krelpos,
+        return [m.Wq.weight, m.Wk.weight, m.Wv.weight, m.Wo.weight, getattr(m.Att, "Krelpos", None),
                 self.ln_multihead.weight, self.ln_multihead.bias,
                 self.ffnetwork.lin1.weight, self.ffnetwork.lin1.bias,
                 self.ffnetwork.lin2.weight, self.ffnetwork.lin2.bias,
@@ -136,7 +135,35 @@ class TransformerLayer(nn.Module):
         p = self.dropout_p if self.training else 0.0
         # a fresh dropout stream per call, derived from torch's CPU generator (so torch.manual_seed governs it)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
-        return _TransformerFn.apply(x, self.sizeSeq, 1, 1, p, seed, *self._param_list())
+        x, s = _pad_to_blocks(x, self.sizeSeq)
+        return _TransformerFn.apply(x, self.sizeSeq, 1, 1, p, seed, *self._param_list())[:, :s]
+
+
+def _pad_to_blocks(x, size_seq):
+    """transformers.py:38-50: inputs are attended in blocks of sizeSeq frames; a ragged tail is zero-padded."""
+    s = x.size(1)
+    r = s % size_seq
+    if r > 0:
+        x = torch.nn.functional.pad(x, (0, 0, 0, size_seq - r))
+    return x, s
+
+
+class StaticPositionEmbedding(nn.Module):
+    """transformers.py:161-173 (abspos=True): fixed sinusoidal position table added to the input (a torch add:
+    this variant is not on the measured path)."""
+
+    def __init__(self, seqlen, dmodel):
+        super(StaticPositionEmbedding, self).__init__()
+        pos = torch.arange(0., seqlen).unsqueeze(1).repeat(1, dmodel)
+        dim = torch.arange(0., dmodel).unsqueeze(0).repeat(seqlen, 1)
+        div = torch.exp(- math.log(10000) * (2 * (dim // 2) / dmodel))
+        pos *= div
+        pos[:, 0::2] = torch.sin(pos[:, 0::2])
+        pos[:, 1::2] = torch.cos(pos[:, 1::2])
+        self.register_buffer('pe', pos.unsqueeze(0))
+
+    def forward(self, x):
+        return x + self.pe[:, :x.size(1), :]
 
 
 class MultiClassifierTransformerHead(nn.Module):
@@ -145,8 +172,6 @@ class MultiClassifierTransformerHead(nn.Module):
 
     def __init__(self, nclassifiers, sizeSeq=32, dmodel=512, dout=512, dff=2048, dropout=0.1, nheads=8, abspos=False):
         super(MultiClassifierTransformerHead, self).__init__()
-        if abspos:
-            raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
         if nheads != 8 or dff != 2048:
             raise NotImplementedError("the MI355X transformer kernels are built for nheads=8, dff=2048 (the reference's values)")
         self.multihead = MultiHeadAttention(sizeSeq, dropout, dmodel, nheads, abspos)
@@ -164,23 +189,22 @@ class MultiClassifierTransformerHead(nn.Module):
     def forward(self, x):
         p = self.dropout_p if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
-        return _TransformerFn.apply(x, self.sizeSeq, 1, self.nclassifiers, p, seed, *self._param_list())
+        x, s = _pad_to_blocks(x, self.sizeSeq)
+        return _TransformerFn.apply(x, self.sizeSeq, 1, self.nclassifiers, p, seed, *self._param_list())[:, :s]
 
 
 def buildTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos):
     """transformers.py:176-187."""
-    if abspos:
-        raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
-    layerSequence = [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
-                     for _ in range(nLayers)]
+    layerSequence = [StaticPositionEmbedding(sizeSeq, dimAR)] if abspos else []
+    layerSequence += [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
+                      for _ in range(nLayers)]
     return nn.Sequential(*layerSequence)
 
 
 def buildMultHeadTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos, nHeads):
     """transformers.py:190-212: nLayers - 1 TransformerLayers, then the multi-classifier head."""
-    if abspos:
-        raise NotImplementedError("abspos=True (StaticPositionEmbedding) is not on the MI355X path")
-    layerSequence = [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
+    layerSequence = [StaticPositionEmbedding(sizeSeq, dimAR)] if abspos else []
+    layerSequence += [TransformerLayer(sizeSeq=sizeSeq, dmodel=dimAR, dout=dimEncoded, abspos=abspos)
                      for _ in range(nLayers - 1)]
     layerSequence += [MultiClassifierTransformerHead(nHeads, dmodel=dimAR, dout=dimEncoded, sizeSeq=sizeSeq, abspos=abspos)]
     return nn.Sequential(*layerSequence)

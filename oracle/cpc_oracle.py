@@ -112,7 +112,14 @@ def transformer_layer_forward(x, p, prefix, n_heads=8, size_seq=None, n_classifi
     residual branches, output [N, S, n_classifiers, Dout]."""
     n, s, d = x.shape
     dk = d // n_heads
-    assert size_seq is None or size_seq == s
+    if size_seq is not None and size_seq != s:
+        # transformers.py:38-50: blocks of size_seq frames, a ragged tail zero-padded (Q, K, V have no bias, so padding
+        # the layer input is the same thing); the rows of the padding are dropped (:69)
+        pad = (-s) % size_seq
+        xp = torch.cat([x, torch.zeros(n, pad, d, dtype=x.dtype)], dim=1) if pad else x
+        blocks = xp.reshape(n * ((s + pad) // size_seq), size_seq, d)
+        out = transformer_layer_forward(blocks, p, prefix, n_heads=n_heads, size_seq=size_seq, n_classifiers=n_classifiers)
+        return out.reshape((n, s + pad) + tuple(out.shape[2:]))[:, :s]
 
     def split(v):   # trans_ (transformers.py:89-91)
         return v.view(n, s, n_heads, dk).transpose(1, 2).reshape(n * n_heads, s, dk)
@@ -168,6 +175,16 @@ def quality_weights(signal_quality, growth_rate, inflection_point_x, window):
 def transformer_predictors(p, k_steps, prefix="wPrediction.predictors."):
     """rnnMode='transformer' (criterion.py:136-143): K one-layer transformers applied to c[:, :W]."""
     return [(lambda c, i=i: transformer_layer_forward(c, p, f"{prefix}{i}.0.")) for i in range(k_steps)]
+
+
+def static_position_embedding(seqlen, dmodel, dtype=torch.float32):
+    """transformers.py:161-173."""
+    pos = torch.arange(0., seqlen, dtype=torch.float64).unsqueeze(1).repeat(1, dmodel)
+    dim = torch.arange(0., dmodel, dtype=torch.float64).unsqueeze(0).repeat(seqlen, 1)
+    pos = pos * torch.exp(-math.log(10000) * (2 * torch.div(dim, 2, rounding_mode="floor") / dmodel))
+    pos[:, 0::2] = torch.sin(pos[:, 0::2])
+    pos[:, 1::2] = torch.cos(pos[:, 1::2])
+    return pos.unsqueeze(0).to(dtype)
 
 
 def multihead_predictors(p, k_steps, prefix="wPrediction.predictor."):

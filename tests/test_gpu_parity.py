@@ -478,6 +478,31 @@ def test_transformer_vs_reference_golden(golden):
 
 # d_model 256 (head size 32) takes the MFMA attention kernels: full 128-frame window, the predictors' 116 frames (ragged
 # last tile), 32-frame blocks of a longer input, 40 frames (two waves idle)
+@pytest.mark.parametrize("tag", ["abspos", "ragged", "abspos_ragged"])
+def test_transformer_variants_vs_reference_golden(golden, tag):
+    """abspos=True (StaticPositionEmbedding in front, no Krelpos) and lengths that are not a multiple of sizeSeq
+    (zero-padded blocks, transformers.py:38-50)."""
+    from cpc2_amd.transformers import buildTransformerAR
+    g = golden("g10_transformer_variants.npz")
+    d_model, size_seq, n = (int(v) for v in g["cfg"])
+    s_len = int(g[tag + "_len"])
+    abspos = tag.startswith("abspos")
+    net = buildTransformerAR(d_model, d_model, 1, size_seq, abspos)
+    assert sorted(net.state_dict().keys()) == [str(x) for x in g[tag + "_keys"]]
+    layer = "1." if abspos else "0."
+    p = synth.transformer_params(d_model, d_model, size_seq, 171)
+    sd = {layer + k[len("gAR.0."):]: v for k, v in p.items() if not (abspos and k.endswith("Krelpos"))}
+    net.load_state_dict({**net.state_dict(), **sd})
+    net = net.to(DEV).eval()
+    x = synth.features((n, s_len, d_model), 172, relu=True).to(DEV).requires_grad_(True)
+    out = net(x)
+    assert_close(out, t(g[tag + "_out"]), 2e-5, "out")
+    (out * synth.features((n, s_len, d_model), 173).to(DEV)).sum().backward()
+    assert_close(x.grad, t(g[tag + "_dx"]), 1e-4, "dx")
+    for name, prm in net.named_parameters():
+        assert_close(prm.grad, t(g[tag + "_grad." + name]), 2e-4, f"grad {name}")
+
+
 @pytest.mark.parametrize("d_model,size_seq,s,n", [(256, 128, 128, 3), (64, 32, 96, 2), (512, 128, 128, 1), (256, 116, 116, 2),
                                                     (256, 32, 96, 2), (256, 40, 40, 3)])
 def test_transformer_vs_oracle_fp64(d_model, size_seq, s, n):

@@ -256,3 +256,27 @@ def test_criterion_with_multihead_predictor(golden):
     for name, v in p.items():
         ref = t(g["grad." + name])
         assert torch.allclose(v.grad, ref, atol=2e-5 * float(ref.abs().max()) + 1e-9, rtol=1e-4), name
+
+
+# ----------------------------------------------------------------------------- G10
+@pytest.mark.parametrize("tag", ["abspos", "ragged", "abspos_ragged"])
+def test_transformer_variants(golden, tag):
+    """abspos=True (StaticPositionEmbedding, no relative positions) and lengths that are not a multiple of sizeSeq."""
+    g = golden("g10_transformer_variants.npz")
+    d_model, size_seq, n = (int(v) for v in g["cfg"])
+    s_len = int(g[tag + "_len"])
+    abspos = tag.startswith("abspos")
+    p = synth.transformer_params(d_model, d_model, size_seq, 171)
+    if abspos:
+        p = {k: v for k, v in p.items() if not k.endswith("Krelpos")}
+    p = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x = synth.features((n, s_len, d_model), 172, relu=True).requires_grad_(True)
+    xin = x + O.static_position_embedding(size_seq, d_model)[:, :s_len] if abspos else x
+    out = O.transformer_layer_forward(xin, p, "gAR.0.", size_seq=size_seq)
+    assert torch.allclose(out, t(g[tag + "_out"]), atol=2e-6, rtol=1e-5)
+    (out * synth.features((n, s_len, d_model), 173)).sum().backward()
+    assert torch.allclose(x.grad, t(g[tag + "_dx"]), atol=1e-5, rtol=1e-4)
+    layer = "1." if abspos else "0."
+    for k, v in p.items():
+        ref = t(g[tag + "_grad." + layer + k[len("gAR.0."):]])
+        assert torch.allclose(v.grad, ref, atol=2e-5 * float(ref.abs().max()) + 1e-7, rtol=1e-4), k

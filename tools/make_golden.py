@@ -336,7 +336,33 @@ def g9():
     save("g9_criterion_multihead_pred.npz", **d)
 
 
+# ------------------------------------------------------------------ G10 transformer variants
+def g10():
+    """abspos=True (StaticPositionEmbedding, no Krelpos) and an input whose length is not a multiple of sizeSeq."""
+    d_model, size_seq, n = 32, 16, 2
+    d = {"cfg": np.array([d_model, size_seq, n])}
+    for tag, abspos, s_len in (("abspos", True, 16), ("ragged", False, 41), ("abspos_ragged", True, 11)):
+        p = synth.transformer_params(d_model, d_model, size_seq, seed=171, dff=2048)
+        net = ref_tr.buildTransformerAR(d_model, d_model, 1, size_seq, abspos)
+        layer = "1." if abspos else "0."
+        sd = {layer + k[len("gAR.0."):]: v for k, v in p.items() if not (abspos and k.endswith("Krelpos"))}
+        sd.update({k: v for k, v in net.state_dict().items() if k.endswith(".z") or k.endswith(".mask") or k.endswith(".pe")})
+        net.load_state_dict(sd)
+        net.eval()
+        x = synth.features((n, s_len, d_model), seed=172, relu=True).requires_grad_(True)
+        g = synth.features((n, s_len, d_model), seed=173)
+        out = net(x)
+        (out * g).sum().backward()
+        d[tag + "_len"] = np.array(s_len)
+        d[tag + "_out"] = out
+        d[tag + "_dx"] = x.grad
+        d[tag + "_keys"] = np.array(sorted(net.state_dict().keys()))
+        for k, v in net.named_parameters():
+            d[tag + "_grad." + k] = v.grad
+    save("g10_transformer_variants.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for name in which:
         globals()[name]()
