@@ -239,9 +239,37 @@ class CPCAR(nn.Module):
 
 
 # --------------------------------------------------------------------------- CPCModel
+def span_mask(batch, frames, mask_prob, mask_length, min_masks=0):
+    """Boolean [batch, frames] mask of model.py:300-365 (the simplified wav2vec 2.0 span sampler): the same draws from
+    numpy's global generator in the same order, so a given np.random.seed masks the same frames as the reference.
+    Every sequence gets the same number of spans (int(mask_prob * 100 * frames / mask_length + U[0,1))), span starts
+    are drawn without replacement, overlapping spans merge, and the rows are then thinned to the shortest one."""
+    import numpy as np
+    n_spans = max(min_masks, int(mask_prob * 100 * frames / float(mask_length) + np.random.rand()))
+    rows = []
+    for _ in range(batch):
+        lengths = np.full(n_spans, mask_length)
+        if lengths.sum() == 0:
+            lengths[0] = min(mask_length, frames - 1)
+        shortest = min(lengths)
+        if frames - shortest <= n_spans:
+            shortest = frames - n_spans - 1
+        starts = np.random.choice(frames - shortest, n_spans, replace=False)
+        covered = np.asarray([st + off for st, ln in zip(starts, lengths) for off in range(ln)])
+        rows.append(np.unique(covered[covered < frames]))
+    keep = min(len(r) for r in rows)
+    mask = np.zeros((batch, frames), dtype=bool)
+    for i, r in enumerate(rows):
+        if len(r) > keep:
+            r = np.random.choice(r, keep, replace=False)
+        mask[i, r] = True
+    return mask
+
+
 class CPCModel(nn.Module):
-    """model.py:279-390 with mask_prob == 0 (the default; the wav2vec-style masking of
-    :300-379 is not on the hot path)."""
+    """model.py:279-390.  mask_prob > 0: spans of encoder frames are overwritten by a learned embedding before the
+    context network (host-side span sampling + one torch index_put; like the reference, the returned encodedData is the
+    masked tensor too, :373-385)."""
 
     def __init__(self, encoder, AR, mask_prob=0.0, mask_length=10):
         super(CPCModel, self).__init__()
@@ -250,12 +278,26 @@ class CPCModel(nn.Module):
         self.mask_prob = mask_prob
         self.mask_length = mask_length
         if mask_prob > 0.0:
-            raise NotImplementedError("mask_prob > 0 is not supported by the MI355X hot path")
+            self.mask_emb = nn.Parameter(torch.FloatTensor(encoder.dimEncoded).uniform_())
+
+    def compute_mask_indices(self, shape, mask_prob, mask_length, min_masks=0):
+        return span_mask(shape[0], shape[1], mask_prob, mask_length, min_masks)
+
+    def getMask(self, features):
+        batchSize, seqSize, _ = features.shape
+        mask = self.compute_mask_indices((batchSize, seqSize), self.mask_prob, self.mask_length, min_masks=2)
+        if mask.mean() > 0.6:
+            import warnings
+            warnings.warn("We detected that %.2f of all encoded frames have been masked. This might be too much." % mask.mean())
+        features[torch.from_numpy(mask).to(features.device)] = self.mask_emb
+        return features
 
     def forward(self, batchData, label):
         if hasattr(self.gEncoder, "forward_channel_last"):
             encodedData = self.gEncoder.forward_channel_last(batchData)      # [N, T, H], contiguous
         else:
             encodedData = self.gEncoder(batchData).permute(0, 2, 1)
+        if self.mask_prob > 0.0:
+            encodedData = self.getMask(encodedData)
         cFeature = self.gAR(encodedData)
         return cFeature, encodedData, label

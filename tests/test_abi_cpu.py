@@ -175,3 +175,16 @@ def test_build_criterion_variants():
     assert isinstance(getCriterion(_default_args(cpc_mode="none"), 160), NoneCriterion)
     with pytest.raises(ValueError):
         getCriterion(_default_args(cpc_mode="bert"), 160)
+
+
+def test_span_mask_draws_like_the_reference(golden):
+    """model.py:300-365: same spans for the same numpy seed, and the generator is left in the same state."""
+    import numpy as np
+    from cpc2_amd.model import span_mask
+    g = golden("g11_model_span_mask.npz")
+    np.random.seed(123)
+    for i in range(4):
+        bsz, frames, prob, length, mn = g[f"mask{i}_cfg"]
+        m = span_mask(int(bsz), int(frames), float(prob), int(length), min_masks=int(mn))
+        assert m.dtype == bool and np.array_equal(m, g[f"mask{i}"]), i
+    assert np.random.rand() == float(g["rand_after"])

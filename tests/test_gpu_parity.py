@@ -453,6 +453,29 @@ def test_criterion_properties_at_full_size():
     assert torch.equal(l2, l3)
 
 
+def test_model_span_masking_vs_reference_golden(golden):
+    """CPCModel(mask_prob > 0) (model.py:300-390), forward (the reference's own backward fails: it writes in place into
+    the ReLU output autograd needs); here the masked frames simply get no encoder gradient and mask_emb gets theirs."""
+    g = golden("g11_model_span_mask.npz")
+    hidden, n = (int(v) for v in g["cfg"])
+    mp = synth.encoder_params(hidden, 11)
+    mp.update(synth.gru_params(hidden, hidden, 1, 41))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1), mask_prob=0.02, mask_length=4)
+    mp["mask_emb"] = t(g["mask_emb"])
+    model.load_state_dict(mp)
+    model = model.to(DEV)
+    x = synth.audio_windows(n, 20480, 12).to(DEV)
+    np.random.seed(5)
+    c, z, _ = model(x, None)
+    assert_close(z, t(g["z"]), 2e-5, "masked encodedData")
+    assert_close(c, t(g["c"]), 2e-5, "context")
+    masked = (z == model.mask_emb).all(dim=2)
+    assert 0 < int(masked.sum()) < n * 128
+    (c.sum() + z.sum()).backward()
+    assert torch.isfinite(model.mask_emb.grad).all() and float(model.mask_emb.grad.abs().sum()) > 0
+    assert torch.isfinite(model.gEncoder.conv0.weight.grad).all()
+
+
 # ----------------------------------------------------------------------------- transformer AR (config 4)
 def load_transformer(d_model, d_out, size_seq, params, n_layers=1):
     from cpc2_amd.transformers import buildTransformerAR

@@ -362,7 +362,35 @@ def g10():
     save("g10_transformer_variants.npz", **d)
 
 
+# ------------------------------------------------------------------ G11 CPCModel with span masking
+def g11():
+    """mask_prob > 0 (model.py:300-390): spans from numpy's global generator, frames overwritten by mask_emb."""
+    hidden, n = 32, 3
+    p = synth.encoder_params(hidden, seed=11)
+    p.update(synth.gru_params(hidden, hidden, 1, seed=41))
+    d = {"cfg": np.array([hidden, n])}
+    # the span sampler alone, several shapes, one generator stream
+    np.random.seed(123)
+    probe = ref_model.CPCModel(ref_model.CPCEncoder(hidden, "layerNorm"), ref_model.CPCAR(hidden, hidden, False, 1, mode="GRU"))
+    for i, (bsz, frames, prob, length, mn) in enumerate([(4, 128, 0.01, 10, 2), (3, 50, 0.05, 3, 0), (2, 20, 0.02, 8, 2), (5, 128, 0.065, 10, 2)]):
+        d[f"mask{i}_cfg"] = np.array([bsz, frames, prob, length, mn])
+        d[f"mask{i}"] = probe.compute_mask_indices((bsz, frames), prob, length, min_masks=mn)
+    d["rand_after"] = np.random.rand()
+    # the model
+    model = ref_model.CPCModel(ref_model.CPCEncoder(hidden, "layerNorm"), ref_model.CPCAR(hidden, hidden, False, 1, mode="GRU"),
+                               mask_prob=0.02, mask_length=4)
+    sd = dict(p)
+    sd["mask_emb"] = torch.from_numpy(np.random.RandomState(77).uniform(size=hidden).astype(np.float32))
+    model.load_state_dict(sd)
+    x = synth.audio_windows(n, 20480, seed=12)
+    np.random.seed(5)
+    with torch.no_grad():      # the reference's own backward fails here (in-place write into the ReLU output it needs)
+        c, z, _ = model(x, None)
+    d.update({"c": c, "z": z, "mask_emb": sd["mask_emb"]})
+    save("g11_model_span_mask.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name in which:
         globals()[name]()
