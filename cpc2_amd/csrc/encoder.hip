@@ -1,5 +1,6 @@
-// CPCEncoder on gfx950: conv0 + ChannelNorm + ReLU fused (HBM-bound), conv1..4 as implicit GEMMs on
-// the f32 MFMA over channel-last activations, ChannelNorm(+ReLU) row kernels, and the matching backward.
+// CPCEncoder on gfx950: conv0 + ChannelNorm + ReLU fused (HBM-bound), conv1..4 as implicit GEMMs (gemm_f32.hip:
+// f32 products on the bf16 matrix pipe) over channel-last activations, ChannelNorm(+ReLU) row kernels, and the
+// matching backward.
 //
 // Reference: /root/reference/cpc/model.py:63-108 (CPCEncoder), :27-60 (ChannelNorm).
 //
@@ -8,11 +9,12 @@
 //                  data row of position l is row l + p_{i+1}; the other rows are zero (conv padding).
 //                  Output frame t of layer i+1 then reads the k*H CONTIGUOUS floats at row t*s, so the
 //                  conv is a GEMM whose A rows overlap: A(m) = Y_i + m*s*H, m = n*Rv + t, Rv = L[i+2]+2
-//                  (rows t >= L[i+2] of a sample are junk and ignored downstream).
+//                  (rows t >= L[i+2] of a sample are junk: never multiplied by the split kernels, which tile each
+//                  sample's valid rows separately, and ignored downstream).
 //   Xh_i (i=1..4)  normalised pre-activation xhat: [N*Rv_i][H] (conv output, normalised in place)
 //   dU_i           gradient wrt conv output, SHIFTED by one row: row n*Rv + t + 1; rows 0 and > L of every
-//                  sample are zero.  Backward-data (k == 2s) then is, per phase j in [0,s), a GEMM with
-//                  A(m) = dU + m*H (rows t_hi-1 and t_hi, 2H contiguous floats) and weight-gradient a TN
+//                  sample are zero.  Backward-data (k == 2s) then is ONE GEMM with A(m) = dU + m*H (rows t_hi-1
+//                  and t_hi, 2H contiguous floats) and the s phases side by side in N; weight-gradient a TN
 //                  GEMM over m with A(m) = dU + (m+1)*H, B(m) = Y_{i-1} + m*s*H.
 #include "common.h"
 #include "rowcfg.h"
