@@ -39,7 +39,10 @@ CONFIGS = {
     "transformer": dict(hidden=256, layers=1, npred=12, nneg=128, ar="transformer"),    # BASELINE configs[3]
     # the fork's default predictor (rnnMode='transformer', criterion.py:136-143) on the GRU model
     "transformer_pred": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", rnn="transformer"),
+    # the fork's default autoregressive network (arMode='LSTM', cpc_default_config.py; model.py:171-173)
+    "lstm": dict(hidden=256, layers=1, npred=12, nneg=128, ar="LSTM"),
 }
+GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
 
@@ -65,7 +68,7 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
             flops += 2 * (2.0 * n * t_len * (5 * h * h + 2 * h * 2048))
             launches += 12
         else:
-            flops += 2 * (2.0 * n * t_len * din * 3 * h)   # GI and dX
+            flops += 2 * (2.0 * n * t_len * din * GATES[cfg["ar"]] * h)   # GI and dX
             launches += 2
         din = h
     w = t_len - cfg["npred"]
@@ -121,7 +124,8 @@ def cpu_baseline(cfg, seconds_budget):
     log(f"cpu baseline on {torch.get_num_threads()} threads")
     b, h = 8, cfg["hidden"]
     mp = synth.encoder_params(h, 1)
-    mp.update(synth.gru_params(h, h, cfg["layers"], 2))
+    ar = cfg["ar"] if cfg["ar"] in GATES else "GRU"          # the transformer configs keep the GRU-model baseline
+    mp.update(synth.gru_params(h, h, cfg["layers"], 2, gates=GATES[ar]))
     cp = synth.predictor_params(cfg["npred"], h, h, 3)
     x = synth.audio_windows(b, WINDOW, 4)
     params = {k: v.clone().requires_grad_(True) for k, v in list(cp.items()) + list(mp.items())}
@@ -130,7 +134,7 @@ def cpu_baseline(cfg, seconds_budget):
 
     def step():
         tot, _l, _a = O.train_step_loss(x, x, {k: params[k] for k in mp}, {k: params[k] for k in cp}, mt,
-                                        cfg["npred"], cfg["nneg"], cfg["layers"])
+                                        cfg["npred"], cfg["nneg"], cfg["layers"], ar)
         grads = torch.autograd.grad(tot, list(params.values()))
         opt.step(dict(zip(params, grads)))
 

@@ -39,6 +39,14 @@ SIGNATURES = {
     "cpc_gru_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cpc_gru_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_gru_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_lstm_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cpc_lstm_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cpc_lstm_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_lstm_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_rnn_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cpc_rnn_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cpc_rnn_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_rnn_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_transformer_param_count": (c_int, []),
     "cpc_transformer_saved_bytes": (c_size_t, [c_int] * 7),
     "cpc_transformer_scratch_bytes": (c_size_t, [c_int] * 7),

@@ -159,28 +159,32 @@ class CPCEncoder(nn.Module):
         return self.forward_channel_last(x).permute(0, 2, 1)
 
 
-# --------------------------------------------------------------------------- CPCAR (GRU)
+# --------------------------------------------------------------------------- CPCAR (GRU / LSTM)
 class _GruFn(torch.autograd.Function):
+    """kind = "gru" or "rnn" (tanh): the two single-state recurrences share one calling convention."""
+
     @staticmethod
-    def forward(ctx, x, h0, n_layers, want_hidden, *params):
+    def forward(ctx, x, h0, n_layers, want_hidden, kind, *params):
         require_gpu(x, *params)
         lib = _lib.load()
         x = f32c(x)
         ctx.param_refs = params
+        ctx.kind = kind
         params = tuple(f32c(p) for p in params)
         n, t, dim_in = x.shape
         hidden = params[1].shape[1]
-        nsaved = lib.cpc_gru_saved_bytes(n, t, dim_in, hidden, n_layers)
-        nscratch = lib.cpc_gru_scratch_bytes(n, t, dim_in, hidden, n_layers)
+        nsaved = getattr(lib, f"cpc_{kind}_saved_bytes")(n, t, dim_in, hidden, n_layers)
+        nscratch = getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers)
         if nsaved == 0:
-            check(-1, "gru shape query")
+            check(-1, f"{kind} shape query")
         out = torch.empty(n, t, hidden, dtype=torch.float32, device=x.device)
         h_last = torch.empty(n_layers, n, hidden, dtype=torch.float32, device=x.device) if want_hidden else None
         h0c = f32c(h0) if h0 is not None else None
         saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
         sc = scratch(nscratch, x.device)
-        check(lib.cpc_gru_forward(ptr(x), ptr_array(params), ptr(h0c), ptr(out), ptr(h_last), ptr(saved), ptr(sc),
-                                  n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "gru_forward")
+        check(getattr(lib, f"cpc_{kind}_forward")(ptr(x), ptr_array(params), ptr(h0c), ptr(out), ptr(h_last), ptr(saved),
+                                                  ptr(sc), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
+              f"{kind}_forward")
         ctx.save_for_backward(x, saved, *params)
         ctx.dims = (n, t, dim_in, hidden, n_layers)
         if want_hidden:
@@ -197,22 +201,69 @@ class _GruFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
-        sc = scratch(lib.cpc_gru_scratch_bytes(n, t, dim_in, hidden, n_layers), x.device)
-        check(lib.cpc_gru_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
-                                   ptr_array(grads), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
-              "gru_backward")
-        return (dx, None, None, None) + tuple(grads)
+        kind = ctx.kind
+        sc = scratch(getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers), x.device)
+        check(getattr(lib, f"cpc_{kind}_backward")(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
+                                                   ptr_array(grads), n, t, dim_in, hidden, n_layers,
+                                                   stream_ptr(x.device)), f"{kind}_backward")
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+class _LstmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h0, c0, n_layers, want_hidden, *params):
+        require_gpu(x, *params)
+        lib = _lib.load()
+        x = f32c(x)
+        ctx.param_refs = params
+        params = tuple(f32c(p) for p in params)
+        n, t, dim_in = x.shape
+        hidden = params[1].shape[1]
+        nsaved = lib.cpc_lstm_saved_bytes(n, t, dim_in, hidden, n_layers)
+        nscratch = lib.cpc_lstm_scratch_bytes(n, t, dim_in, hidden, n_layers)
+        if nsaved == 0:
+            check(-1, "lstm shape query")
+        out = torch.empty(n, t, hidden, dtype=torch.float32, device=x.device)
+        h_last = torch.empty(n_layers, n, hidden, dtype=torch.float32, device=x.device) if want_hidden else None
+        c_last = torch.empty_like(h_last) if want_hidden else None
+        h0c = f32c(h0) if h0 is not None else None
+        c0c = f32c(c0) if c0 is not None else None
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
+        sc = scratch(nscratch, x.device)
+        check(lib.cpc_lstm_forward(ptr(x), ptr_array(params), ptr(h0c), ptr(c0c), ptr(out), ptr(h_last), ptr(c_last),
+                                   ptr(saved), ptr(sc), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
+              "lstm_forward")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.dims = (n, t, dim_in, hidden, n_layers)
+        if want_hidden:
+            ctx.mark_non_differentiable(h_last, c_last)
+            return out, h_last, c_last
+        return out, None, None
+
+    @staticmethod
+    def backward(ctx, dout, _dh, _dc):
+        lib = _lib.load()
+        x, saved, *params = ctx.saved_tensors
+        n, t, dim_in, hidden, n_layers = ctx.dims
+        dout = f32c(dout)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        grads = grad_buffers(ctx.param_refs)
+        sc = scratch(lib.cpc_lstm_scratch_bytes(n, t, dim_in, hidden, n_layers), x.device)
+        check(lib.cpc_lstm_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
+                                    ptr_array(grads), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
+              "lstm_backward")
+        return (dx, None, None, None, None) + tuple(grads)
 
 
 class CPCAR(nn.Module):
-    """model.py:158-207.  mode="GRU" runs on the HIP path (LSTM / RNN are not on the hot path)."""
+    """model.py:158-207.  mode="GRU", "LSTM" (this fork's default arMode) and "RNN" all run on the HIP path."""
 
     def __init__(self, dimEncoded, dimOutput, keepHidden, nLevelsGRU, mode="GRU", reverse=False):
         super(CPCAR, self).__init__()
         self.RESIDUAL_STD = 0.1
-        if mode in ("LSTM", "RNN"):
-            raise NotImplementedError(f"CPCAR mode={mode!r}: only 'GRU' has an MI355X kernel path")
-        self.baseNet = nn.GRU(dimEncoded, dimOutput, num_layers=nLevelsGRU, batch_first=True)
+        rnn = {"LSTM": nn.LSTM, "RNN": nn.RNN}.get(mode, nn.GRU)        # anything else is a GRU (model.py:177-179)
+        self.baseNet = rnn(dimEncoded, dimOutput, num_layers=nLevelsGRU, batch_first=True)
         self.hidden = None
         self.keepHidden = keepHidden
         self.reverse = reverse
@@ -229,9 +280,17 @@ class CPCAR(nn.Module):
     def forward(self, x):
         if self.reverse:
             x = torch.flip(x, [1])
-        x, h = _GruFn.apply(x, self.hidden, self.baseNet.num_layers, bool(self.keepHidden), *self._param_list())
-        if self.keepHidden:
-            self.hidden = h.detach()
+        layers, keep = self.baseNet.num_layers, bool(self.keepHidden)
+        if isinstance(self.baseNet, nn.LSTM):
+            h0, c0 = self.hidden if self.hidden is not None else (None, None)
+            x, h, c = _LstmFn.apply(x, h0, c0, layers, keep, *self._param_list())
+            if self.keepHidden:
+                self.hidden = (h.detach(), c.detach())
+        else:
+            kind = "rnn" if isinstance(self.baseNet, nn.RNN) else "gru"
+            x, h = _GruFn.apply(x, self.hidden, layers, keep, kind, *self._param_list())
+            if self.keepHidden:
+                self.hidden = h.detach()
         # a sequence's order is preserved by each module (model.py:203-206)
         if self.reverse:
             x = torch.flip(x, [1])

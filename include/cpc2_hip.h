@@ -120,6 +120,34 @@ int cpc_gru_backward(const float *x, const float *const *params, const float *do
                      int hidden, int layers, cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CPCAR with mode="LSTM" (model.py:171-173 -> torch.nn.LSTM, batch_first, gate order i,f,g,o;
+ * the default arMode of this fork, cpc/cpc_default_config.py).  Same conventions as the GRU:
+ *   params  4 pointers per layer: weight_ih_l{k} [4H, in], weight_hh_l{k} [4H, H],
+ *           bias_ih_l{k} [4H], bias_hh_l{k} [4H]
+ *   h0, c0  [layers, n, H] or NULL (zeros);  h_last, c_last [layers, n, H] or NULL
+ *           (keepHidden keeps the (h, c) tuple, model.py:197-199)
+ * ------------------------------------------------------------------------------------------ */
+size_t cpc_lstm_saved_bytes(int n, int t, int dim_in, int hidden, int layers);
+size_t cpc_lstm_scratch_bytes(int n, int t, int dim_in, int hidden, int layers);
+int cpc_lstm_forward(const float *x, const float *const *params, const float *h0, const float *c0,
+                     float *out, float *h_last, float *c_last, void *saved, void *scratch, int n,
+                     int t, int dim_in, int hidden, int layers, cpc_stream_t stream);
+int cpc_lstm_backward(const float *x, const float *const *params, const float *dout, void *saved,
+                      void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
+                      int hidden, int layers, cpc_stream_t stream);
+
+/* CPCAR with mode="RNN" (model.py:174-176 -> torch.nn.RNN, tanh): weight_ih [H, in], weight_hh [H, H],
+ * bias_ih [H], bias_hh [H]; arguments as for the GRU. */
+size_t cpc_rnn_saved_bytes(int n, int t, int dim_in, int hidden, int layers);
+size_t cpc_rnn_scratch_bytes(int n, int t, int dim_in, int hidden, int layers);
+int cpc_rnn_forward(const float *x, const float *const *params, const float *h0, float *out,
+                    float *h_last, void *saved, void *scratch, int n, int t, int dim_in, int hidden,
+                    int layers, cpc_stream_t stream);
+int cpc_rnn_backward(const float *x, const float *const *params, const float *dout, void *saved,
+                     void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
+                     int hidden, int layers, cpc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Transformer autoregressive network (arMode="transformer", cpc/transformers.py:10-134,176-187):
  * `layers` TransformerLayers, each   y = LN1(x + Wo.MHA(x)),  out = LN2(Wl (y + FFN(y)) + bl),
  * 8 heads, causal mask, relative-position bias q_i.Krelpos[:, S-1-(i-j)], dff = 2048, ReLU.

@@ -85,6 +85,69 @@ def gru_forward(x, p, n_layers, prefix="", h0=None, reverse=False):
     return out, torch.stack(h_last, dim=0)
 
 
+def lstm_forward(x, p, n_layers, prefix="", h0=None, c0=None, reverse=False):
+    """CPCAR(mode="LSTM"), model.py:171-173 -> torch.nn.LSTM (batch_first, gate order i, f, g, o).
+    x [N, T, Hin].  Returns (out [N, T, H], h_last [n_layers, N, H], c_last [n_layers, N, H]).
+
+        i = sigmoid(W_ii x + b_ii + W_hi h + b_hi)      f = sigmoid(W_if x + b_if + W_hf h + b_hf)
+        g = tanh   (W_ig x + b_ig + W_hg h + b_hg)      o = sigmoid(W_io x + b_io + W_ho h + b_ho)
+        c' = f * c + i * g                               h' = o * tanh(c')"""
+    if reverse:
+        x = torch.flip(x, [1])
+    n, t_len, _ = x.shape
+    h_last, c_last = [], []
+    inp = x
+    for layer in range(n_layers):
+        w_ih, w_hh = p[f"{prefix}weight_ih_l{layer}"], p[f"{prefix}weight_hh_l{layer}"]
+        b_ih, b_hh = p[f"{prefix}bias_ih_l{layer}"], p[f"{prefix}bias_hh_l{layer}"]
+        hid = w_hh.shape[1]
+        h = torch.zeros(n, hid, dtype=x.dtype) if h0 is None else h0[layer]
+        c = torch.zeros(n, hid, dtype=x.dtype) if c0 is None else c0[layer]
+        gi_all = inp @ w_ih.t() + b_ih
+        steps = []
+        for t in range(t_len):
+            pre = gi_all[:, t] + h @ w_hh.t() + b_hh
+            i = torch.sigmoid(pre[:, :hid])
+            f = torch.sigmoid(pre[:, hid:2 * hid])
+            g = torch.tanh(pre[:, 2 * hid:3 * hid])
+            o = torch.sigmoid(pre[:, 3 * hid:])
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            steps.append(h)
+        inp = torch.stack(steps, dim=1)
+        h_last.append(h)
+        c_last.append(c)
+    out = inp
+    if reverse:
+        out = torch.flip(out, [1])
+    return out, torch.stack(h_last, dim=0), torch.stack(c_last, dim=0)
+
+
+def rnn_forward(x, p, n_layers, prefix="", h0=None, reverse=False):
+    """CPCAR(mode="RNN"), model.py:174-176 -> torch.nn.RNN (tanh):  h' = tanh(W_ih x + b_ih + W_hh h + b_hh)."""
+    if reverse:
+        x = torch.flip(x, [1])
+    n, t_len, _ = x.shape
+    h_last = []
+    inp = x
+    for layer in range(n_layers):
+        w_ih, w_hh = p[f"{prefix}weight_ih_l{layer}"], p[f"{prefix}weight_hh_l{layer}"]
+        b_ih, b_hh = p[f"{prefix}bias_ih_l{layer}"], p[f"{prefix}bias_hh_l{layer}"]
+        hid = w_hh.shape[1]
+        h = torch.zeros(n, hid, dtype=x.dtype) if h0 is None else h0[layer]
+        gi_all = inp @ w_ih.t() + b_ih
+        steps = []
+        for t in range(t_len):
+            h = torch.tanh(gi_all[:, t] + h @ w_hh.t() + b_hh)
+            steps.append(h)
+        inp = torch.stack(steps, dim=1)
+        h_last.append(h)
+    out = inp
+    if reverse:
+        out = torch.flip(out, [1])
+    return out, torch.stack(h_last, dim=0)
+
+
 # --------------------------------------------------------------------------- #
 # Autoregressive network: light causal transformer (transformers.py:10-134)
 # --------------------------------------------------------------------------- #
@@ -153,6 +216,10 @@ def model_forward(x, p, n_layers_gru=1, ar="GRU", reverse=False):
     z = encoder_forward(x, p, "gEncoder.").permute(0, 2, 1)
     if ar == "GRU":
         c, _ = gru_forward(z, p, n_layers_gru, "gAR.baseNet.", reverse=reverse)
+    elif ar == "LSTM":
+        c = lstm_forward(z, p, n_layers_gru, "gAR.baseNet.", reverse=reverse)[0]
+    elif ar == "RNN":
+        c = rnn_forward(z, p, n_layers_gru, "gAR.baseNet.", reverse=reverse)[0]
     elif ar == "transformer":
         c = z
         for layer in range(n_layers_gru):

@@ -30,17 +30,25 @@ def encoder_params(hidden, seed, prefix="gEncoder."):
     return p
 
 
-def gru_params(dim_in, hidden, n_layers, seed, prefix="gAR.baseNet."):
+def gru_params(dim_in, hidden, n_layers, seed, prefix="gAR.baseNet.", gates=3):
     rs = np.random.RandomState(seed)
     bound = 1.0 / np.sqrt(hidden)
     p = {}
     for layer in range(n_layers):
         d = dim_in if layer == 0 else hidden
-        p[f"{prefix}weight_ih_l{layer}"] = _uniform(rs, (3 * hidden, d), bound)
-        p[f"{prefix}weight_hh_l{layer}"] = _uniform(rs, (3 * hidden, hidden), bound)
-        p[f"{prefix}bias_ih_l{layer}"] = _uniform(rs, (3 * hidden,), bound)
-        p[f"{prefix}bias_hh_l{layer}"] = _uniform(rs, (3 * hidden,), bound)
+        p[f"{prefix}weight_ih_l{layer}"] = _uniform(rs, (gates * hidden, d), bound)
+        p[f"{prefix}weight_hh_l{layer}"] = _uniform(rs, (gates * hidden, hidden), bound)
+        p[f"{prefix}bias_ih_l{layer}"] = _uniform(rs, (gates * hidden,), bound)
+        p[f"{prefix}bias_hh_l{layer}"] = _uniform(rs, (gates * hidden,), bound)
     return p
+
+
+def lstm_params(dim_in, hidden, n_layers, seed, prefix="gAR.baseNet."):
+    return gru_params(dim_in, hidden, n_layers, seed, prefix, gates=4)
+
+
+def rnn_params(dim_in, hidden, n_layers, seed, prefix="gAR.baseNet."):
+    return gru_params(dim_in, hidden, n_layers, seed, prefix, gates=1)
 
 
 def predictor_params(k_steps, dim_ar, dim_enc, seed, prefix="wPrediction.predictors.", scale=1.0):

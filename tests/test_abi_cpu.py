@@ -157,9 +157,9 @@ def test_build_ar_like_reference_TestARBuilder():
     args = _default_args(arMode="transformer", hiddenGar=256)
     tr = getAR(args)
     assert isinstance(tr, torch.nn.Sequential) and len(tr) == 1 and tr[0].sizeSeq == 128 and args.hiddenGar == 256
-    for other in ("LSTM", "RNN"):
-        with pytest.raises(NotImplementedError):
-            getAR(_default_args(arMode=other))
+    lstm = getAR(_default_args(arMode="LSTM", nLevelsGRU=2))                 # the fork's default arMode
+    assert isinstance(lstm.baseNet, torch.nn.LSTM) and lstm.baseNet.num_layers == 2 and lstm.getDimOutput() == 256
+    assert isinstance(getAR(_default_args(arMode="RNN")).baseNet, torch.nn.RNN)
 
 
 def test_build_criterion_variants():

@@ -267,6 +267,77 @@ def test_gru_vs_oracle_fp64(hid, layers, n, t_len):
         assert_close(p.grad, p64["gAR." + name].grad, 1e-4, f"gru grad {name}")
 
 
+# ----------------------------------------------------------------------------- LSTM / RNN (model.py:171-176)
+_RECURRENT = {"LSTM": (synth.lstm_params, O.lstm_forward), "RNN": (synth.rnn_params, O.rnn_forward)}
+
+
+def load_recurrent(mode, hin, hid, layers, params, reverse=False, keep=False):
+    ar = cpc2_amd.CPCAR(hin, hid, keep, layers, mode=mode, reverse=reverse)
+    ar.load_state_dict({k[len("gAR."):]: v for k, v in params.items()})
+    return ar.to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["LSTM", "RNN"])
+@pytest.mark.parametrize("tag", ["l1", "l2"])
+def test_lstm_rnn_vs_reference_golden(golden, mode, tag):
+    g = golden("g12_lstm_rnn.npz")
+    hin, hid, layers, n, t_len = (int(v) for v in g[f"{mode}_{tag}_cfg"])
+    ar = load_recurrent(mode, hin, hid, layers, _RECURRENT[mode][0](hin, hid, layers, 51))
+    x = synth.features((n, t_len, hin), 52, relu=True).to(DEV).requires_grad_(True)
+    out = ar(x)
+    assert_close(out, t(g[f"{mode}_{tag}_out"]), 1e-5, f"{mode} out")
+    (out * synth.features((n, t_len, hid), 53).to(DEV)).sum().backward()
+    assert_close(x.grad, t(g[f"{mode}_{tag}_dx"]), 1e-4, f"{mode} dx")
+    for name, p in ar.named_parameters():
+        assert_close(p.grad, t(g[f"{mode}_{tag}_grad." + name]), 1e-4, f"{mode} grad {name}")
+
+
+@pytest.mark.parametrize("mode", ["LSTM", "RNN"])
+def test_lstm_rnn_keep_hidden_vs_reference_golden(golden, mode):
+    g = golden("g12_lstm_rnn.npz")
+    ar = load_recurrent(mode, 32, 32, 2, _RECURRENT[mode][0](32, 32, 2, 51), keep=True)
+    ar(synth.features((2, 9, 32), 54, relu=True).to(DEV))
+    out2 = ar(synth.features((2, 7, 32), 55, relu=True).to(DEV))
+    assert_close(out2, t(g[f"{mode}_keep_out2"]), 1e-5, "second call")
+    if mode == "LSTM":
+        assert isinstance(ar.hidden, tuple) and len(ar.hidden) == 2
+        assert_close(ar.hidden[0], t(g["LSTM_keep_h"]), 1e-5, "h")
+        assert_close(ar.hidden[1], t(g["LSTM_keep_c"]), 1e-5, "c")
+    else:
+        assert_close(ar.hidden, t(g["RNN_keep_h"]), 1e-5, "h")
+
+
+@pytest.mark.parametrize("mode,hin,hid,layers,n,t_len", [("LSTM", 256, 256, 1, 5, 128), ("LSTM", 512, 512, 2, 3, 40),
+                                                         ("LSTM", 256, 256, 2, 70, 12), ("LSTM", 64, 100, 1, 4, 17),
+                                                         ("RNN", 256, 256, 1, 5, 128), ("RNN", 512, 512, 2, 3, 40),
+                                                         ("RNN", 48, 36, 2, 9, 11)])
+def test_lstm_rnn_vs_oracle_fp64(mode, hin, hid, layers, n, t_len):
+    make, fwd = _RECURRENT[mode]
+    params = make(hin, hid, layers, 9)
+    ar = load_recurrent(mode, hin, hid, layers, params)
+    x = synth.features((n, t_len, hin), 10, relu=True)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x.double().requires_grad_(True)
+    ref = fwd(x64, p64, layers, "gAR.baseNet.")[0]
+    gout = synth.features((n, t_len, hid), 11)
+    (ref * gout.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = ar(xd)
+    assert_close(out, ref, 1e-5, f"{mode} out")
+    (out * gout.to(DEV)).sum().backward()
+    assert_close(xd.grad, x64.grad, 1e-4, f"{mode} dx")
+    for name, p in ar.named_parameters():
+        assert_close(p.grad, p64["gAR." + name].grad, 1e-4, f"{mode} grad {name}")
+
+
+def test_lstm_reverse_matches_flipped_forward():
+    params = synth.lstm_params(32, 32, 1, 3)
+    x = synth.features((3, 20, 32), 4, relu=True).to(DEV)
+    fwd = load_recurrent("LSTM", 32, 32, 1, params)(torch.flip(x, [1]))
+    rev = load_recurrent("LSTM", 32, 32, 1, params, reverse=True)(x)
+    assert torch.equal(rev, torch.flip(fwd, [1]))
+
+
 # ----------------------------------------------------------------------------- criterion
 def make_criterion(k, har, henc, nn, pseed, scale=4.0, **kw):
     crit = cpc2_amd.CPCUnsupersivedCriterion(k, har, henc, nn, rnnMode="linear", sizeInputSeq=999, **kw)
@@ -609,6 +680,31 @@ def test_model_with_transformer_ar_train_step_vs_oracle():
     p64 = {kk: v.double().requires_grad_(True) for kk, v in list(mp.items()) + list(cp.items())}
     ref_tot, ref_losses, _ = O.train_step_loss(x.double(), x.double(), {kk: p64[kk] for kk in mp}, {kk: p64[kk] for kk in cp},
                                                MT19937(77), k, nn, 1, ar="transformer")
+    ref_tot.backward()
+    assert_close(losses, ref_losses, 1e-5, "losses")
+    for name, p in list(model.named_parameters()) + list(crit.named_parameters()):
+        assert_close(p.grad, p64[name].grad, 5e-4, f"grad {name}")
+
+
+@pytest.mark.parametrize("mode,layers", [("LSTM", 2), ("RNN", 1)])
+def test_model_with_lstm_ar_train_step_vs_oracle(mode, layers):
+    """The fork's default model (arMode='LSTM', cpc_default_config.py) through one full step: loss and every gradient."""
+    hidden, b, k, nn = 64, 2, 12, 16
+    mp = synth.encoder_params(hidden, 21)
+    mp.update(_RECURRENT[mode][0](hidden, hidden, layers, 26))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, layers, mode=mode))
+    model.load_state_dict(mp)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, hidden, hidden, nn, rnnMode="linear", sizeInputSeq=128)
+    cp = synth.predictor_params(k, hidden, hidden, 23)
+    crit.load_state_dict(cp)
+    model, crit = model.to(DEV), crit.to(DEV)
+    x = synth.audio_windows(b, 20480, 24)
+    crit.seed(78)
+    tot, losses, _ = cpcStep(x.to(DEV), x.to(DEV), torch.zeros(b, dtype=torch.long, device=DEV), model, crit)
+    tot.backward()
+    p64 = {kk: v.double().requires_grad_(True) for kk, v in list(mp.items()) + list(cp.items())}
+    ref_tot, ref_losses, _ = O.train_step_loss(x.double(), x.double(), {kk: p64[kk] for kk in mp}, {kk: p64[kk] for kk in cp},
+                                               MT19937(78), k, nn, layers, ar=mode)
     ref_tot.backward()
     assert_close(losses, ref_losses, 1e-5, "losses")
     for name, p in list(model.named_parameters()) + list(crit.named_parameters()):

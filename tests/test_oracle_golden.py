@@ -138,6 +138,43 @@ def test_gru_reverse(golden):
     assert torch.allclose(out, t(g["rev_out"]), atol=1e-6, rtol=1e-5)
 
 
+# ----------------------------------------------------------------------------- G12
+_RECURRENT = {"LSTM": (synth.lstm_params, O.lstm_forward), "RNN": (synth.rnn_params, O.rnn_forward)}
+
+
+@pytest.mark.parametrize("mode", ["LSTM", "RNN"])
+@pytest.mark.parametrize("tag", ["l1", "l2"])
+def test_lstm_rnn(golden, mode, tag):
+    g = golden("g12_lstm_rnn.npz")
+    make, fwd = _RECURRENT[mode]
+    hin, hid, layers, n, t_len = (int(v) for v in g[f"{mode}_{tag}_cfg"])
+    p = {k: v.clone().requires_grad_(True) for k, v in make(hin, hid, layers, 51).items()}
+    x = synth.features((n, t_len, hin), 52, relu=True).requires_grad_(True)
+    out = fwd(x, p, layers, "gAR.baseNet.")[0]
+    assert torch.allclose(out, t(g[f"{mode}_{tag}_out"]), atol=1e-6, rtol=1e-5)
+    (out * synth.features((n, t_len, hid), 53)).sum().backward()
+    assert torch.allclose(x.grad, t(g[f"{mode}_{tag}_dx"]), atol=1e-5, rtol=1e-4)
+    for k, v in p.items():
+        assert torch.allclose(v.grad, t(g[f"{mode}_{tag}_grad." + k[len("gAR."):]]), atol=1e-5, rtol=1e-4), k
+
+
+@pytest.mark.parametrize("mode", ["LSTM", "RNN"])
+def test_lstm_rnn_keep_hidden(golden, mode):
+    g = golden("g12_lstm_rnn.npz")
+    make, fwd = _RECURRENT[mode]
+    p = make(32, 32, 2, 51)
+    xa = synth.features((2, 9, 32), 54, relu=True)
+    xb = synth.features((2, 7, 32), 55, relu=True)
+    state = fwd(xa, p, 2, "gAR.baseNet.")[1:]
+    if mode == "LSTM":
+        out2, h, c = fwd(xb, p, 2, "gAR.baseNet.", h0=state[0], c0=state[1])
+        assert torch.allclose(c, t(g["LSTM_keep_c"]), atol=1e-6, rtol=1e-5)
+    else:
+        out2, h = fwd(xb, p, 2, "gAR.baseNet.", h0=state[0])
+    assert torch.allclose(out2, t(g[f"{mode}_keep_out2"]), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(h, t(g[f"{mode}_keep_h"]), atol=1e-6, rtol=1e-5)
+
+
 # ----------------------------------------------------------------------------- G5
 def _criterion_case(b, t_len, har, henc, k, nn, seed, pseed, mode=None, n_skipped=0, weights=None):
     p = {kk: v.clone().requires_grad_(True)

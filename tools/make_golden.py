@@ -390,7 +390,42 @@ def g11():
     save("g11_model_span_mask.npz", **d)
 
 
+# ------------------------------------------------------------------ G12 CPCAR LSTM / RNN
+def g12():
+    """CPCAR(mode="LSTM") -- this fork's default arMode -- and mode="RNN" (model.py:171-176), forward + backward,
+    plus keepHidden carry-over across two calls (model.py:197-201)."""
+    d = {}
+    for mode, make in (("LSTM", synth.lstm_params), ("RNN", synth.rnn_params)):
+        for tag, (hin, hid, layers, n, t_len) in {"l1": (32, 32, 1, 3, 20), "l2": (24, 32, 2, 2, 16)}.items():
+            p = make(hin, hid, layers, seed=51)
+            ar = ref_model.CPCAR(hin, hid, False, layers, mode=mode, reverse=False)
+            ar.load_state_dict(strip(p, "gAR."))
+            x = synth.features((n, t_len, hin), seed=52, relu=True).requires_grad_(True)
+            g = synth.features((n, t_len, hid), seed=53)
+            out = ar(x)
+            (out * g).sum().backward()
+            key = f"{mode}_{tag}"
+            d[f"{key}_cfg"] = np.array([hin, hid, layers, n, t_len])
+            d[f"{key}_out"], d[f"{key}_dx"] = out, x.grad
+            for k, v in ar.named_parameters():
+                d[f"{key}_grad." + k] = v.grad
+        # keepHidden: the second call starts from the first call's final state
+        p = make(32, 32, 2, seed=51)
+        ar = ref_model.CPCAR(32, 32, True, 2, mode=mode, reverse=False)
+        ar.load_state_dict(strip(p, "gAR."))
+        xa = synth.features((2, 9, 32), seed=54, relu=True)
+        xb = synth.features((2, 7, 32), seed=55, relu=True)
+        ar(xa)
+        d[f"{mode}_keep_out2"] = ar(xb)
+        hid_state = ar.hidden
+        if isinstance(hid_state, tuple):
+            d[f"{mode}_keep_h"], d[f"{mode}_keep_c"] = hid_state
+        else:
+            d[f"{mode}_keep_h"] = hid_state
+    save("g12_lstm_rnn.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for name in which:
         globals()[name]()
