@@ -1,0 +1,61 @@
+// Pieces shared by the cooperative (weights-in-registers) recurrent kernels of gru.hip and lstm.hip.
+#pragma once
+#include "common.h"
+
+namespace cpc {
+
+// A GROUP of G workgroups (512 threads each, one per CU) shares NB windows.  Forward: thread (u, q) = unit u of the
+// member's U units, K slice q of 32 columns, all gates.  H = 256: 8 slices, U = 64, G = 4;  H = 512: 16 slices,
+// U = 32, G = 16.
+template <int H> struct CoopCfg {
+    static constexpr int QS = H / 32;            // K slices of 32 columns
+    static constexpr int U = 512 / QS;           // units per member
+    static constexpr int G = H / U;              // workgroups per group
+    static constexpr int LDH = QS * 36;          // padded h row: chunk q of 32 floats at q*36
+    static constexpr int HALVES = 512 / H;       // backward: threads per W_hh column
+};
+
+typedef unsigned long long gu64_t;               // {epoch, value} granule
+#define COOP_GLOBAL __attribute__((address_space(1)))
+
+__device__ __forceinline__ int coop_pad(int k) { return (k >> 5) * 36 + (k & 31); }
+
+template <int G> __device__ __forceinline__ void coop_who(int groups, int xcd_map, int &group, int &member)
+{
+    if (xcd_map) {                          // members of a group on one XCD (speed only: blocks b, b+8 share one)
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        group = xcd * (groups / 8) + i / G;
+        member = i % G;
+    } else {
+        group = blockIdx.x / G;
+        member = blockIdx.x % G;
+    }
+}
+
+// window count -> windows per group (0: not covered), for the hidden sizes that have a cooperative kernel; every
+// workgroup must be resident at once (1 per CU)
+static inline int coop_windows_per_group(int H, int N, int n_cus, int *groups_per)
+{
+    const int G = H == 256 ? CoopCfg<256>::G : (H == 512 ? CoopCfg<512>::G : 0);
+    if (G == 0 || n_cus < G) return 0;
+    const int max_groups = n_cus / G;
+    for (int nb = 1; nb <= 8; nb *= 2)
+        if ((int)cdiv(N, nb) <= max_groups) { *groups_per = G; return nb; }
+    return 0;
+}
+
+static inline int coop_cu_count()
+{
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+}
+
+// granules of the backward kernels: [groups][2][G][NB][H] with groups*NB < N + 8 windows and G <= 16
+static inline size_t coop_comm_bytes(int H, int N)
+{
+    return (H == 256 || H == 512) ? sizeof(gu64_t) * 2 * 16 * (size_t)(N + 8) * H : 256;
+}
+
+}  // namespace cpc

@@ -9,6 +9,7 @@
 // unit j and K slice q, h lives in LDS and W_hh (re-laid out so that lanes read consecutive float4s)
 // is streamed from L2 every step.  Backward mirrors it (BPTT), then three GEMMs give dW_hh, dW_ih and dX.
 #include "common.h"
+#include "coop.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -202,36 +203,11 @@ __global__ void gru_bwd_kernel(GruArgs a)
 // {epoch, value} granules in L2 (one sc1 store each, polled with relaxed agent-scope loads: MI355X guide,
 // Guideline 16 R2).  A member can be at most one step ahead of another, so two granule sets (epoch parity)
 // suffice.  Every spin is bounded: on time-out the workgroup poisons its outputs with NaN and leaves.
-template <int H> struct CoopCfg {
-    static constexpr int QS = H / 32;            // K slices of 32 columns
-    static constexpr int U = 512 / QS;           // units per member
-    static constexpr int G = H / U;              // workgroups per group
-    static constexpr int LDH = QS * 36;          // padded h row: chunk q of 32 floats at q*36
-    static constexpr int HALVES = 512 / H;       // backward: threads per W_hh column
-};
-
-typedef unsigned long long gu64_t;
-#define COOP_GLOBAL __attribute__((address_space(1)))
-
-__device__ __forceinline__ int coop_pad(int k) { return (k >> 5) * 36 + (k & 31); }
-
 struct GruCoopArgs {
     GruArgs g;
     gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
     int groups, xcd_map;
 };
-
-template <int G> __device__ __forceinline__ void coop_who(const GruCoopArgs &ca, int &group, int &member)
-{
-    if (ca.xcd_map) {                       // members of a group on one XCD (speed only: blocks b, b+8 share one)
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        group = xcd * (ca.groups / 8) + i / G;
-        member = i % G;
-    } else {
-        group = blockIdx.x / G;
-        member = blockIdx.x % G;
-    }
-}
 
 template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(GruCoopArgs ca)
 {
@@ -243,7 +219,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
     const GruArgs &a = ca.g;
     const int T = a.T;
     int group, member;
-    coop_who<G>(ca, group, member);
+    coop_who<G>(ca.groups, ca.xcd_map, group, member);
     const int tid = threadIdx.x;
     const int q = tid & (QS - 1), u = tid / QS;
     const int j = member * U + u;
@@ -380,7 +356,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
     const GruArgs &a = ca.g;
     const int T = a.T;
     int group, member;
-    coop_who<G>(ca, group, member);
+    coop_who<G>(ca.groups, ca.xcd_map, group, member);
     const int tid = threadIdx.x;
     const int jc = tid & (H - 1), half = tid / H;             // column jc, rows half*96 .. +96 of the member's 3 U
     const int n0 = group * NB;
@@ -504,17 +480,6 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
     }
 }
 
-// cooperative path: window count -> windows per group (0: not covered), for the hidden sizes that have one
-static int coop_windows_per_group(int H, int N, int n_cus, int *groups_per)
-{
-    const int G = H == 256 ? CoopCfg<256>::G : (H == 512 ? CoopCfg<512>::G : 0);
-    if (G == 0 || n_cus < G) return 0;
-    const int max_groups = n_cus / G;
-    for (int nb = 1; nb <= 8; nb *= 2)
-        if ((int)cdiv(N, nb) <= max_groups) { *groups_per = G; return nb; }
-    return 0;
-}
-
 template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
     if (nb == 1) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
@@ -569,7 +534,7 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     g.wpack = sc.take<float4>((size_t)3 * H * H / 4);
     g.cs = sc.take<float>(colsum_rows_scratch_bytes(3 * H) / sizeof(float));
     // granules of the cooperative kernels: backward [groups][2][G][NB][H], groups*NB < N + 8 windows, G <= 16
-    g.comm_bytes = (H == 256 || H == 512) ? sizeof(unsigned long long) * 2 * 16 * (size_t)(N + 8) * H : 256;
+    g.comm_bytes = coop_comm_bytes(H, N);
     g.comm = sc.take<unsigned long long>(g.comm_bytes / sizeof(unsigned long long));
     g.tn_bytes = std::max(gemm_tn_scratch_bytes(3 * H, H, (long)N * (T + 1)), gemm_tn_scratch_bytes(3 * H, dmax, (long)N * T));
     g.tn_bytes = std::max(g.tn_bytes, gemm_tn_scratch_bytes(3 * H, Din, (long)N * T));
@@ -601,12 +566,7 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         a.hlast = h_last ? h_last + (size_t)l * N * H : nullptr;
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
-        static const int n_cus = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess) return 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-            return v;
-        }();
+        static const int n_cus = coop_cu_count();
         // the cooperative kernel needs every workgroup resident at once (1 per CU)
         int G = 0;
         const int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
@@ -648,12 +608,7 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
-        static const int n_cus = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess) return 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-            return v;
-        }();
+        static const int n_cus = coop_cu_count();
         int G = 0;
         const int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
         if (nb != 0) {

@@ -13,8 +13,10 @@
 // read consecutive float4s) is streamed from L2 every step.  Backward mirrors it (BPTT), then GEMMs give dW_hh,
 // dW_ih and dX.  Both bias gradients are column sums of the same pre-activation gradient.
 #include "common.h"
+#include "coop.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace cpc {
 
@@ -49,7 +51,8 @@ __global__ void lstm_pack_bwd_kernel(const float *w, float4 *wb, int H, int G)
 
 struct LstmArgs {
     const float *gi;      // [N*T][G*H]  input projections incl. b_ih
-    const float4 *wpack;  // packed W_hh
+    const float4 *wpack;  // packed W_hh (streaming kernels)
+    const float *whh;     // [G*H][H] as stored (cooperative kernels)
     const float *bhh;     // [G*H]
     const float *h0, *c0; // [N][H] or null
     float *out;           // [N][T][H]
@@ -225,6 +228,303 @@ __global__ void lstm_bwd_kernel(LstmArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-chip LSTM recurrence for H = 256 and 512 (same scheme as gru.hip's cooperative kernels, see coop.h): a group of
+// G workgroups shares NB windows and W_hh never leaves the register file -- 4 gates x 32 columns = 128 weights per
+// thread.  The cell state of (window q, unit j) stays in the register of the lane that finishes that pair.
+struct LstmCoopArgs {
+    LstmArgs g;
+    gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
+    int groups, xcd_map;
+};
+
+template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_kernel(LstmCoopArgs ca)
+{
+    using C = CoopCfg<H>;
+    constexpr int QS = C::QS, U = C::U, G = C::G;
+    constexpr int KP = NB * H / 512 > 0 ? NB * H / 512 : 1;          // granules gathered per thread and step
+    static_assert(NB <= QS, "one finishing lane per window");
+    __shared__ __attribute__((aligned(16))) float hs[2][NB][C::LDH];
+    const LstmArgs &a = ca.g;
+    const int T = a.T;
+    int group, member;
+    coop_who<G>(ca.groups, ca.xcd_map, group, member);
+    const int tid = threadIdx.x;
+    const int q = tid & (QS - 1), u = tid / QS;
+    const int j = member * U + u;
+    const int n0 = group * NB;
+
+    float w[4][32];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i4 = 0; i4 < 8; ++i4) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.whh + (long)(g * H + j) * H + q * 32 + 4 * i4);
+            w[g][4 * i4] = v.x; w[g][4 * i4 + 1] = v.y; w[g][4 * i4 + 2] = v.z; w[g][4 * i4 + 3] = v.w;
+        }
+    const float bh0 = a.bhh[j], bh1 = a.bhh[H + j], bh2 = a.bhh[2 * H + j], bh3 = a.bhh[3 * H + j];
+
+    for (int idx = tid; idx < NB * H; idx += 512) {
+        const int s = idx / H, k = idx - s * H;
+        const int n = n0 + s;
+        const float v = (n < a.N && a.h0 != nullptr) ? a.h0[(long)n * H + k] : 0.f;
+        hs[0][s][coop_pad(k)] = v;
+        if (n < a.N && (k / U) == member) a.hall[((long)n * (T + 1)) * H + k] = v;
+    }
+    __syncthreads();
+
+    const int ns = n0 + q;
+    const bool mine = q < NB && ns < a.N;
+    float cprev = 0.f;
+    float gin0 = 0.f, gin1 = 0.f, gin2 = 0.f, gin3 = 0.f;
+    if (mine) {
+        cprev = a.c0 != nullptr ? a.c0[(long)ns * H + j] : 0.f;
+        a.call[((long)ns * (T + 1)) * H + j] = cprev;
+        const float *gp = a.gi + (long)ns * T * 4 * H;
+        gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j]; gin3 = gp[3 * H + j];
+    }
+    bool dead = false;
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // the input projections of step t were requested one step ago; the next step's are requested now, so that no
+        // L2/HBM round trip sits on the serial path of a time step
+        const float gi0 = gin0, gi1 = gin1, gi2 = gin2, gi3 = gin3;
+        if (mine && t + 1 < T) {
+            const float *gp = a.gi + ((long)ns * T + t + 1) * 4 * H;
+            gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j]; gin3 = gp[3 * H + j];
+        }
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;          // the pre-activations of window q, for its finishing lane
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const float4 h4 = *reinterpret_cast<const float4 *>(&hs[cur][s][q * 36 + 4 * i4]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = fmaf(w[g][4 * i4], h4.x, fmaf(w[g][4 * i4 + 1], h4.y,
+                             fmaf(w[g][4 * i4 + 2], h4.z, fmaf(w[g][4 * i4 + 3], h4.w, acc[g]))));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int m = 1; m < QS; m <<= 1) acc[g] += __shfl_xor(acc[g], m, 64);
+            }
+            if (s == q) { g0 = acc[0]; g1 = acc[1]; g2 = acc[2]; g3 = acc[3]; }
+        }
+        if (q < NB) {
+            const float ig = sigm(gi0 + g0 + bh0);
+            const float fg = sigm(gi1 + g1 + bh1);
+            const float gg = tanhf(gi2 + g2 + bh2);
+            const float og = sigm(gi3 + g3 + bh3);
+            const float cv = fg * cprev + ig * gg;
+            float hv = og * tanhf(cv);
+            cprev = cv;
+            if (dead) hv = NAN;
+            // publish first (also for padding windows, so that every granule of the epoch gets written): the other
+            // members wait for this store, nobody waits for the saved activations below
+            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
+            __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine) {
+                const long row = (long)ns * T + t;
+                float *gs = a.gates + row * 4 * H;
+                gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
+                a.out[row * H + j] = hv;
+                a.hall[((long)ns * (T + 1) + t + 1) * H + j] = hv;
+                a.call[((long)ns * (T + 1) + t + 1) * H + j] = cv;
+            }
+        }
+        // gather the whole new h (all members) into the other LDS buffer; a thread's KP granules are polled together
+        if (t + 1 < T) {
+            COOP_GLOBAL gu64_t *slot[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const int idx = tid + 512 * i;
+                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + idx / H) * H + (idx % H));
+            }
+            gu64_t x[KP];
+            unsigned spins = dead ? (1u << 22) : 0u;            // once timed out, never wait again
+            if (tid < NB * H) {
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
+                    if (ready) break;
+                    if (++spins > (1u << 22)) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    const int idx = tid + 512 * i;
+                    hs[nxt][idx / H][coop_pad(idx % H)] = __uint_as_float((unsigned)x[i]);
+                }
+            }
+            dead = __syncthreads_or(dead);
+        }
+    }
+    if (mine) {
+        // hall row T was written by this same lane
+        if (a.hlast != nullptr) a.hlast[(long)ns * H + j] = a.hall[((long)ns * (T + 1) + T) * H + j];
+        if (a.clast != nullptr) a.clast[(long)ns * H + j] = cprev;
+    }
+}
+
+// Backward twin: member m keeps the SAME 4 U rows of W_hh (its U units x 4 gates) in registers, one COLUMN j' per
+// thread (thread (j', half): 128 rows), forms its partial W_hh^T dG for all H columns and the members exchange the
+// U-column pieces the others own.   comm: [groups][2][G (sender)][NB][H] granules, zeroed before the launch.
+template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_kernel(LstmCoopArgs ca)
+{
+    using C = CoopCfg<H>;
+    constexpr int U = C::U, G = C::G, HALVES = C::HALVES;
+    constexpr int RW = 4 * U / HALVES;                                      // rows per thread
+    static_assert(RW == 128, "128 weights per thread");
+    static_assert(NB * U <= 512, "one elementwise thread per (window, unit)");
+    __shared__ __attribute__((aligned(16))) float dgs[NB][4 * U];          // this member's dG rows (gate, unit)
+    __shared__ float part[HALVES][NB][H];
+    const LstmArgs &a = ca.g;
+    const int T = a.T;
+    int group, member;
+    coop_who<G>(ca.groups, ca.xcd_map, group, member);
+    const int tid = threadIdx.x;
+    const int jc = tid & (H - 1), half = tid / H;             // column jc, rows half*RW .. +RW of the member's 4 U
+    const int n0 = group * NB;
+
+    float w[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int lr = half * RW + i;                          // local row = gate*U + unit
+        w[i] = a.whh[(long)((lr / U) * H + member * U + (lr % U)) * H + jc];
+    }
+    // elementwise role: thread (es, eu) for tid < NB*U
+    const int es = tid / U, eu = tid - es * U;
+    const int ej = member * U + eu;
+    const int en = n0 + es;
+    const bool ew = tid < NB * U;
+    const bool emine = ew && en < a.N;
+    float carry = 0.f, carry_c = 0.f;
+    if (emine) {                                               // zero junk row T of dGH
+        float *zr = a.dgh + ((long)en * (T + 1) + T) * 4 * H;
+        zr[ej] = 0.f; zr[H + ej] = 0.f; zr[2 * H + ej] = 0.f; zr[3 * H + ej] = 0.f;
+    }
+    // the saved activations of step t-1 are requested while step t runs (same reason as in the forward kernel)
+    float p_dout = 0.f, p_i = 0.f, p_f = 0.f, p_g = 0.f, p_o = 0.f, p_c = 0.f, p_cp = 0.f;
+    auto request = [&](int t) {
+        const long row = (long)en * T + t;
+        const float *gs = a.gates + row * 4 * H;
+        p_dout = a.dout[row * H + ej];
+        p_i = gs[ej]; p_f = gs[H + ej]; p_g = gs[2 * H + ej]; p_o = gs[3 * H + ej];
+        p_cp = a.call[((long)en * (T + 1) + t) * H + ej];
+    };
+    if (emine) {
+        p_c = a.call[((long)en * (T + 1) + T) * H + ej];
+        request(T - 1);
+    }
+    bool dead = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
+        if (ew) {
+            float dpi = 0.f, dpf = 0.f, dpg = 0.f, dpo = 0.f;
+            if (emine) {
+                const long row = (long)en * T + t;
+                const float dh = p_dout + carry;
+                const float ig = p_i, fg = p_f, gg = p_g, og = p_o, cv = p_c, cp = p_cp;
+                p_c = cp;                                       // c_{t-1} is the next step's c_t
+                if (t > 0) request(t - 1);
+                const float tc = tanhf(cv);
+                const float dcv = dh * og * (1.f - tc * tc) + carry_c;
+                dpi = dcv * gg * ig * (1.f - ig);
+                dpf = dcv * cp * fg * (1.f - fg);
+                dpg = dcv * ig * (1.f - gg * gg);
+                dpo = dh * tc * og * (1.f - og);
+                carry_c = dcv * fg;
+                float *gi = a.dgi + row * 4 * H;
+                gi[ej] = dpi; gi[H + ej] = dpf; gi[2 * H + ej] = dpg; gi[3 * H + ej] = dpo;
+                float *gh = a.dgh + ((long)en * (T + 1) + t) * 4 * H;
+                gh[ej] = dpi; gh[H + ej] = dpf; gh[2 * H + ej] = dpg; gh[3 * H + ej] = dpo;
+            }
+            dgs[es][eu] = dpi; dgs[es][U + eu] = dpf; dgs[es][2 * U + eu] = dpg; dgs[es][3 * U + eu] = dpo;
+        }
+        __syncthreads();
+        if (t == 0) break;                                      // dh_{-1} is not needed
+        // partial[jc] over this thread's RW rows, all NB windows
+        float acc[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) acc[s] = 0.f;
+#pragma unroll
+        for (int i4 = 0; i4 < RW / 4; ++i4) {
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(&dgs[s][half * RW + 4 * i4]);
+                acc[s] = fmaf(w[4 * i4], d4.x, fmaf(w[4 * i4 + 1], d4.y, fmaf(w[4 * i4 + 2], d4.z, fmaf(w[4 * i4 + 3], d4.w, acc[s]))));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s];
+        __syncthreads();
+        auto column = [&](int s, int k) {
+            float v = part[0][s][k];
+#pragma unroll
+            for (int hh = 1; hh < HALVES; ++hh) v += part[hh][s][k];
+            return v;
+        };
+        // publish the columns other members own (this member's own columns stay in LDS)
+        for (int idx = tid; idx < NB * H; idx += 512) {
+            const int s = idx / H, k = idx - s * H;
+            if (k / U == member) continue;
+            const float v = column(s, k);
+            COOP_GLOBAL gu64_t *slot =
+                (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * G + member) * NB + s) * H + k);
+            __hip_atomic_store(slot, ((gu64_t)epoch << 32) | (gu64_t)__float_as_uint(dead ? NAN : v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ew) {
+            float sum = column(es, ej);
+            // the partners' pieces are polled together: one L2 round trip per attempt, not G - 1 in a row
+            COOP_GLOBAL gu64_t *slot[G - 1];
+#pragma unroll
+            for (int d = 1; d < G; ++d) {
+                const int src = (member + d) & (G - 1);
+                slot[d - 1] = (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * G + src) * NB + es) * H + ej);
+            }
+            gu64_t x[G - 1];
+            unsigned spins = dead ? (1u << 22) : 0u;
+            for (;;) {
+                bool ready = true;
+#pragma unroll
+                for (int d = 0; d < G - 1; ++d) x[d] = __hip_atomic_load(slot[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int d = 0; d < G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
+                if (ready) break;
+                if (++spins > (1u << 22)) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int d = 0; d < G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
+            carry = sum;
+        }
+        dead = __syncthreads_or(dead);
+    }
+}
+
+template <int H> static void launch_lstm_coop_fwd(int nb, dim3 grid, hipStream_t st, const LstmCoopArgs &ca)
+{
+    if (nb == 1) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
+    else if (nb == 2) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
+    else if (nb == 4) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
+    else hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
+}
+template <int H> static void launch_lstm_coop_bwd(int nb, dim3 grid, hipStream_t st, const LstmCoopArgs &ca)
+{
+    if (nb == 1) hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
+    else if (nb == 2) hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
+    else if (nb == 4) hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
+    else hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
+}
+
 struct LstmLayout {
     int N, T, Din, H, layers, G;
     // saved, per layer
@@ -233,6 +533,8 @@ struct LstmLayout {
     // scratch
     float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn;
     float4 *wpack;
+    gu64_t *comm;
+    size_t comm_bytes;
     size_t tn_bytes, scratch_bytes;
 };
 
@@ -261,11 +563,22 @@ int lstm_layout(LstmLayout &g, int G, int N, int T, int Din, int H, int layers, 
     g.wt = sc.take<float>((size_t)G * H * dmax);
     g.wpack = sc.take<float4>((size_t)G * H * H / 4);
     g.cs = sc.take<float>(colsum_rows_scratch_bytes(G * H) / sizeof(float));
+    g.comm_bytes = G == 4 ? coop_comm_bytes(H, N) : 256;
+    g.comm = sc.take<gu64_t>(g.comm_bytes / sizeof(gu64_t));
     g.tn_bytes = std::max(gemm_tn_scratch_bytes(G * H, H, (long)N * (T + 1)), gemm_tn_scratch_bytes(G * H, dmax, (long)N * T));
     g.tn_bytes = std::max(g.tn_bytes, gemm_tn_scratch_bytes(G * H, Din, (long)N * T));
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
     g.scratch_bytes = sc.used();
     return CPC_OK;
+}
+
+// cooperative kernels exist for the LSTM at H = 256 / 512 (CPC_LSTM_STREAM forces the streaming ones)
+int lstm_coop_windows(int G, int H, int N, int *members)
+{
+    static const bool coop_off = getenv("CPC_LSTM_STREAM") != nullptr;
+    static const int n_cus = coop_cu_count();
+    if (G != 4 || coop_off) return 0;
+    return coop_windows_per_group(H, N, n_cus, members);
 }
 
 void lstm_threads(int H, int G, int &hp, int &kq)
@@ -291,10 +604,8 @@ static int lstm_forward(const float *x, const float *const *prm, const float *h0
         const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1], *b_ih = prm[4 * l + 2], *b_hh = prm[4 * l + 3];
         RowMap none{};
         CPC_TRY(gemm_nt(xin, din, w_ih, din, g.gi, (long)G * H, b_ih, (long)N * T, G * H, din, none, st));
-        hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H, G);
-        CPC_CHECK_LAUNCH("lstm_pack_fwd_kernel");
         LstmArgs a{};
-        a.gi = g.gi; a.wpack = g.wpack; a.bhh = b_hh;
+        a.gi = g.gi; a.wpack = g.wpack; a.whh = w_hh; a.bhh = b_hh;
         a.h0 = h0 ? h0 + (size_t)l * N * H : nullptr;
         a.c0 = c0 ? c0 + (size_t)l * N * H : nullptr;
         a.out = (l + 1 < layers) ? g.outl[l] : out;
@@ -302,8 +613,24 @@ static int lstm_forward(const float *x, const float *const *prm, const float *h0
         a.hlast = h_last ? h_last + (size_t)l * N * H : nullptr;
         a.clast = c_last ? c_last + (size_t)l * N * H : nullptr;
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
-        const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * G * hp);
-        hipLaunchKernelGGL(lstm_fwd_kernel<G>, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
+        int members = 0;
+        const int nb = lstm_coop_windows(G, H, N, &members);
+        if (nb != 0) {
+            LstmCoopArgs ca{};
+            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(gu64_t) * (size_t)ca.groups * 2 * nb * H, st));
+            ProfScope prof(PROF_GRU_FWD, st);
+            const dim3 grid((unsigned)(ca.groups * members));
+            if (H == 256) launch_lstm_coop_fwd<256>(nb, grid, st, ca);
+            else launch_lstm_coop_fwd<512>(nb, grid, st, ca);
+        } else {
+            hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H, G);
+            CPC_CHECK_LAUNCH("lstm_pack_fwd_kernel");
+            ProfScope prof(PROF_GRU_FWD, st);
+            const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * G * hp);
+            hipLaunchKernelGGL(lstm_fwd_kernel<G>, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
+        }
         CPC_CHECK_LAUNCH("lstm_fwd_kernel");
         xin = a.out;
         din = H;
@@ -324,14 +651,28 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1];
         const float *xin = (l == 0) ? x : g.outl[l - 1];
         const int din = (l == 0) ? Din : H;
-        hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H, G);
-        CPC_CHECK_LAUNCH("lstm_pack_bwd_kernel");
         LstmArgs a{};
-        a.wpack = g.wpack; a.hall = g.hall[l]; a.call = g.call[l]; a.gates = g.gates[l];
+        a.wpack = g.wpack; a.whh = w_hh; a.hall = g.hall[l]; a.call = g.call[l]; a.gates = g.gates[l];
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
-        const size_t lds = sizeof(float) * ((size_t)G * H + (size_t)kq * hp);
-        hipLaunchKernelGGL(lstm_bwd_kernel<G>, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
+        int members = 0;
+        const int nb = lstm_coop_windows(G, H, N, &members);
+        if (nb != 0) {
+            LstmCoopArgs ca{};
+            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(gu64_t) * (size_t)ca.groups * 2 * members * nb * H, st));
+            ProfScope prof(PROF_GRU_BWD, st);
+            const dim3 grid((unsigned)(ca.groups * members));
+            if (H == 256) launch_lstm_coop_bwd<256>(nb, grid, st, ca);
+            else launch_lstm_coop_bwd<512>(nb, grid, st, ca);
+        } else {
+            hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H, G);
+            CPC_CHECK_LAUNCH("lstm_pack_bwd_kernel");
+            ProfScope prof(PROF_GRU_BWD, st);
+            const size_t lds = sizeof(float) * ((size_t)G * H + (size_t)kq * hp);
+            hipLaunchKernelGGL(lstm_bwd_kernel<G>, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
+        }
         CPC_CHECK_LAUNCH("lstm_bwd_kernel");
         const int GH = G * H;
         // dW_hh[g][k] = sum_{n,t} dG[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)

@@ -309,6 +309,9 @@ def test_lstm_rnn_keep_hidden_vs_reference_golden(golden, mode):
 
 @pytest.mark.parametrize("mode,hin,hid,layers,n,t_len", [("LSTM", 256, 256, 1, 5, 128), ("LSTM", 512, 512, 2, 3, 40),
                                                          ("LSTM", 256, 256, 2, 70, 12), ("LSTM", 64, 100, 1, 4, 17),
+                                                         ("LSTM", 512, 512, 1, 100, 12), ("LSTM", 512, 512, 1, 40, 10),
+                                                         ("LSTM", 256, 256, 1, 300, 6), ("LSTM", 128, 256, 2, 130, 7),
+                                                         ("LSTM", 256, 256, 1, 2000, 3),
                                                          ("RNN", 256, 256, 1, 5, 128), ("RNN", 512, 512, 2, 3, 40),
                                                          ("RNN", 48, 36, 2, 9, 11)])
 def test_lstm_rnn_vs_oracle_fp64(mode, hin, hid, layers, n, t_len):
@@ -328,6 +331,18 @@ def test_lstm_rnn_vs_oracle_fp64(mode, hin, hid, layers, n, t_len):
     assert_close(xd.grad, x64.grad, 1e-4, f"{mode} dx")
     for name, p in ar.named_parameters():
         assert_close(p.grad, p64["gAR." + name].grad, 1e-4, f"{mode} grad {name}")
+
+
+@pytest.mark.parametrize("hid,n", [(256, 6), (512, 21), (96, 3)])
+def test_lstm_keep_hidden_halves_equal_full_sequence(hid, n):
+    """keepHidden (model.py:197-201): two half-sequences with the carried (h, c) == one full sequence, on the
+    cooperative (256, 512) and the streaming (96) kernels."""
+    params = synth.lstm_params(hid, hid, 2, 5)
+    x = synth.features((n, 24, hid), 6, relu=True).to(DEV)
+    full = load_recurrent("LSTM", hid, hid, 2, params)(x)
+    ar = load_recurrent("LSTM", hid, hid, 2, params, keep=True)
+    halves = torch.cat([ar(x[:, :10].contiguous()), ar(x[:, 10:].contiguous())], dim=1)
+    assert_close(halves, full, 1e-6, "keepHidden")
 
 
 def test_lstm_reverse_matches_flipped_forward():
