@@ -20,6 +20,28 @@ typedef unsigned long long gu64_t;               // {epoch, value} granule
 
 __device__ __forceinline__ int coop_pad(int k) { return (k >> 5) * 36 + (k & 31); }
 
+// two f32 lanes per register pair: v_pk_fma_f32 issues at the rate of v_fma_f32 and does twice the work
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_lo(const float4 &v) { return f32x2{v.x, v.y}; }
+__device__ __forceinline__ f32x2 pk_hi(const float4 &v) { return f32x2{v.z, v.w}; }
+
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over an aligned group of QS = 8 or 16 consecutive lanes, left in every lane of the group: data-parallel
+// primitives (VALU speed) instead of ds_bpermute round trips through the LDS crossbar
+template <int QS> __device__ __forceinline__ float coop_group_sum(float v)
+{
+    static_assert(QS == 8 || QS == 16, "half a DPP row or a full one");
+    v += dpp_get<0xB1>(v);                  // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);                  // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v);                 // row_half_mirror: the other quad of the 8
+    if (QS == 16) v += dpp_get<0x140>(v);   // row_mirror: the other half of the 16
+    return v;
+}
+
 template <int G> __device__ __forceinline__ void coop_who(int groups, int xcd_map, int &group, int &member)
 {
     if (xcd_map) {                          // members of a group on one XCD (speed only: blocks b, b+8 share one)

@@ -254,13 +254,13 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
     const int j = member * U + u;
     const int n0 = group * NB;
 
-    float w[4][32];
+    f32x2 w[4][16];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i4 = 0; i4 < 8; ++i4) {
             const float4 v = *reinterpret_cast<const float4 *>(a.whh + (long)(g * H + j) * H + q * 32 + 4 * i4);
-            w[g][4 * i4] = v.x; w[g][4 * i4 + 1] = v.y; w[g][4 * i4 + 2] = v.z; w[g][4 * i4 + 3] = v.w;
+            w[g][2 * i4] = pk_lo(v); w[g][2 * i4 + 1] = pk_hi(v);
         }
     const float bh0 = a.bhh[j], bh1 = a.bhh[H + j], bh2 = a.bhh[2 * H + j], bh3 = a.bhh[3 * H + j];
 
@@ -296,20 +296,17 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;          // the pre-activations of window q, for its finishing lane
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x2 a2[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // even / odd columns
 #pragma unroll
             for (int i4 = 0; i4 < 8; ++i4) {
                 const float4 h4 = *reinterpret_cast<const float4 *>(&hs[cur][s][q * 36 + 4 * i4]);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    acc[g] = fmaf(w[g][4 * i4], h4.x, fmaf(w[g][4 * i4 + 1], h4.y,
-                             fmaf(w[g][4 * i4 + 2], h4.z, fmaf(w[g][4 * i4 + 3], h4.w, acc[g]))));
+                    a2[g] = pk_fma(w[g][2 * i4 + 1], pk_hi(h4), pk_fma(w[g][2 * i4], pk_lo(h4), a2[g]));
             }
+            float acc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int m = 1; m < QS; m <<= 1) acc[g] += __shfl_xor(acc[g], m, 64);
-            }
+            for (int g = 0; g < 4; ++g) acc[g] = coop_group_sum<QS>(a2[g].x + a2[g].y);
             if (s == q) { g0 = acc[0]; g1 = acc[1]; g2 = acc[2]; g3 = acc[3]; }
         }
         if (q < NB) {
@@ -392,11 +389,11 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
     const int jc = tid & (H - 1), half = tid / H;             // column jc, rows half*RW .. +RW of the member's 4 U
     const int n0 = group * NB;
 
-    float w[RW];
+    f32x2 w[RW / 2];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int lr = half * RW + i;                          // local row = gate*U + unit
-        w[i] = a.whh[(long)((lr / U) * H + member * U + (lr % U)) * H + jc];
+        w[i / 2][i % 2] = a.whh[(long)((lr / U) * H + member * U + (lr % U)) * H + jc];
     }
     // elementwise role: thread (es, eu) for tid < NB*U
     const int es = tid / U, eu = tid - es * U;
@@ -451,19 +448,19 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
         __syncthreads();
         if (t == 0) break;                                      // dh_{-1} is not needed
         // partial[jc] over this thread's RW rows, all NB windows
-        float acc[NB];
+        f32x2 acc[NB];                                         // even / odd rows
 #pragma unroll
-        for (int s = 0; s < NB; ++s) acc[s] = 0.f;
+        for (int s = 0; s < NB; ++s) acc[s] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int i4 = 0; i4 < RW / 4; ++i4) {
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 const float4 d4 = *reinterpret_cast<const float4 *>(&dgs[s][half * RW + 4 * i4]);
-                acc[s] = fmaf(w[4 * i4], d4.x, fmaf(w[4 * i4 + 1], d4.y, fmaf(w[4 * i4 + 2], d4.z, fmaf(w[4 * i4 + 3], d4.w, acc[s]))));
+                acc[s] = pk_fma(w[2 * i4 + 1], pk_hi(d4), pk_fma(w[2 * i4], pk_lo(d4), acc[s]));
             }
         }
 #pragma unroll
-        for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s];
+        for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s].x + acc[s].y;
         __syncthreads();
         auto column = [&](int s, int k) {
             float v = part[0][s][k];
