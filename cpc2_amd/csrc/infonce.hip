@@ -14,6 +14,9 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace cpc {
 
@@ -42,7 +45,9 @@ struct NceArgs {
     int lw;                // LDS dS row length (floats), multiple of 4
     // backward
     const float *dloss;    // [K]
-    float *dz;             // [b*T][H]  (atomics)
+    float *dz;             // [b*T][H]  (atomics; unused when vbuf is set)
+    float *vbuf;           // [b*W][K + Nneg][H] or null: every candidate's dz contribution stored once (see below)
+    float *ds_buf;         // [b*W][17][lw]: dS and the candidate rows, handed from infonce_bwd_kernel to the dz kernels
     float inv_count;       // 1 / (b*W)
 };
 
@@ -176,7 +181,11 @@ __global__ void infonce_reduce_kernel(const float *lossp, const float *hit, long
 // holds dS[16][lw] = d loss / d <P_k, cand_g> and the candidates' z-row indices.
 //   dP^T[d][k] += sum_g cand_g[d] * dS[k][g]    16x16x4, A = candidate rows streamed from L2 as float4s: lane
 //                 (i, q) reads cand_{4s+q}[64T + 4i ..+3] and feeds the 4 row-interleaved tiles d = 64T + 4i + e
-//   dz[row_g][d] += sum_k dS[k][g] * P_k[d]     32x32x2, output rows leave as 128-byte fp32 atomic segments
+//   dz[row_g][d] += sum_k dS[k][g] * P_k[d]     32x32x2.  The b*W*(K + Nneg) contribution rows are either added to dz
+//                 with fp32 atomics (128-byte segments; the atomic units' rate then IS the kernel's time) or, when
+//                 a.vbuf is set, stored once to vbuf[(b,t)][candidate][H] and summed per target row by
+//                 infonce_dz_gather_kernel from counting-sorted reference lists: plain streaming traffic, and a
+//                 summation order that does not change from run to run.
 template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArgs a)
 {
     constexpr int DG = (H + 63) / 64;          // groups of 4 interleaved 16-row d tiles (H = 32: half a group)
@@ -275,6 +284,14 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
     // ---- dz ------------------------------------------------------------------------------------
     const int r32 = lane & 31, h = lane >> 5;
     const long prow_off = ((long)bb * a.p_rows + t) * a.p_stride;
+    if (a.vbuf != nullptr) {
+        // the contribution rows are formed and stored by infonce_dz_store_kernel (its own launch: this kernel's register
+        // budget allows two waves per SIMD, too few to overlap the row gather above with 1 GB of stores)
+        float *dsg = a.ds_buf + bt * (long)(NCE_ROWS + 1) * a.lw;
+        for (int i = lane; i < NCE_ROWS * a.lw; i += 64) dsg[i] = dS[i];
+        for (int g = lane; g < a.lw; g += 64) reinterpret_cast<int *>(dsg)[NCE_ROWS * a.lw + g] = rowidx[g];
+        return;
+    }
     for (int dt = 0; dt < DT32; ++dt) {
         float bvals[NCE_ROWS / 2];
 #pragma unroll
@@ -301,6 +318,174 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
     }
 }
 
+// Second half of the backward pass when the dz contributions are stored (a.vbuf): one wave per (b,t) reloads its
+// dS[16][lw] and candidate rows (written by infonce_bwd_kernel) and forms  V[cand][d] = sum_k dS[k][cand] * P_k[d]
+// with the 32x32x2 MFMA, candidate tiles outermost so that the H/32 128-byte pieces of a row are stored back to back.
+template <int H> __global__ __launch_bounds__(64) void infonce_dz_store_kernel(NceArgs a)
+{
+    constexpr int DT32 = H / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *dS = smem;                                              // [16][lw] then lw row indices
+    const int *rowidx = reinterpret_cast<const int *>(dS + NCE_ROWS * a.lw);
+    const int bb = blockIdx.x / a.W, t = blockIdx.x - bb * a.W;
+    const long bt = blockIdx.x;
+    const int lane = threadIdx.x, r32 = lane & 31, h = lane >> 5;
+    const int npad = a.lw - 4;
+    const float4 *src = reinterpret_cast<const float4 *>(a.ds_buf + bt * (long)(NCE_ROWS + 1) * a.lw);
+    for (int i = lane; i < (NCE_ROWS + 1) * a.lw / 4; i += 64) reinterpret_cast<float4 *>(dS)[i] = src[i];
+    const long prow_off = ((long)bb * a.p_rows + t) * a.p_stride;
+    float bvals[DT32][NCE_ROWS / 2];
+#pragma unroll
+    for (int dt = 0; dt < DT32; ++dt)
+#pragma unroll
+        for (int kp = 0; kp < NCE_ROWS / 2; ++kp) {
+            const int k = 2 * kp + h;
+            bvals[dt][kp] = k < a.K ? a.Pk[k][prow_off + dt * 32 + r32] : 0.f;
+        }
+    __syncthreads();
+    float *vb = a.vbuf + bt * (long)(a.K + a.Nneg) * H + r32;
+    for (int ct = 0; ct < npad / 32; ++ct) {
+        float av[NCE_ROWS / 2];
+#pragma unroll
+        for (int kp = 0; kp < NCE_ROWS / 2; ++kp) av[kp] = dS[(2 * kp + h) * a.lw + ct * 32 + r32];
+        int voff[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            voff[e] = rowidx[ci] >= 0 ? (ci < NCE_POS ? ci : ci - NCE_POS + a.K) * H : -1;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT32; ++dt) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int kp = 0; kp < NCE_ROWS / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], bvals[dt][kp], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (voff[e] >= 0) vb[voff[e] + dt * 32] = acc[e];
+        }
+    }
+}
+
+// ---- reference lists: which (b, t, negative) triples point at z row r (counting sort of ext by value) -------------
+__global__ void nce_hist_kernel(const int32_t *ext, long n, int *counts)
+{
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x)
+        atomicAdd(counts + ext[o], 1);
+}
+
+// offsets[r] = sum of counts[0..r), offsets[rows] = total; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void nce_scan_kernel(const int *counts, int rows, int *offsets)
+{
+    __shared__ int part[1024];
+    const int per = (rows + 1023) / 1024;
+    const int lo = min(rows, (int)threadIdx.x * per), hi = min(rows, lo + per);
+    int sum = 0;
+    for (int r = lo; r < hi; ++r) sum += counts[r];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int r = lo; r < hi; ++r) { offsets[r] = run; run += counts[r]; }
+    if (threadIdx.x == 1023) offsets[rows] = part[1023];
+}
+
+__global__ void nce_fill_kernel(const int32_t *ext, long n, const int *offsets, int *cursor, int *entries)
+{
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        const int r = ext[o];
+        entries[offsets[r] + atomicAdd(cursor + r, 1)] = (int)o;
+    }
+}
+
+// the fill order depends on the atomics' arrival order: sort every row's list (one wave per row, rank sort in LDS) so
+// that the sum below always runs in the same order.  Lists longer than NCE_SORT_MAX stay as filled (correct, but the
+// order of their sum may then vary from run to run).
+constexpr int NCE_SORT_MAX = 512;
+__global__ __launch_bounds__(256) void nce_sort_kernel(const int *offsets, int *entries, int rows)
+{
+    __shared__ int buf[4][NCE_SORT_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const int beg = offsets[r], n = offsets[r + 1] - beg;
+    if (n < 2 || n > NCE_SORT_MAX) return;
+    for (int i = lane; i < n; i += 64) buf[wave][i] = entries[beg + i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (int i = lane; i < n; i += 64) {
+        const int v = buf[wave][i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += buf[wave][j] < v;          // entries are distinct
+        entries[beg + rank] = v;
+    }
+}
+
+// dz[r][:] = sum of the stored contributions that point at z row r = (bb, t'): the positives of steps k = 0..K-1
+// come from (bb, t' - 1 - k), the negatives from the row's reference list.  One wave per row, 16 bytes per lane.
+template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel(const float *vbuf, const int *offsets,
+                                                                                   const int *entries, float *dz, int b, int T,
+                                                                                   int W, int K, int Nneg)
+{
+    constexpr int C4 = H / 4;                        // float4 per row
+    constexpr int PER = (C4 + 63) / 64;              // per lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= b * T) return;
+    const int bb = r / T, tp = r - bb * T;
+    const int vrows = K + Nneg;
+    const float4 *v4 = reinterpret_cast<const float4 *>(vbuf);
+    float4 acc[PER];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_row = [&](long vrow) {
+#pragma unroll
+        for (int c = 0; c < PER; ++c) {
+            if (lane + 64 * c < C4) {
+                const float4 v = v4[vrow * C4 + lane + 64 * c];
+                acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+            }
+        }
+    };
+    for (int k = 0; k < K; ++k) {
+        const int t = tp - 1 - k;
+        if (t >= 0 && t < W) add_row(((long)bb * W + t) * vrows + k);
+    }
+    const int beg = offsets[r], end = offsets[r + 1];
+    int e = beg;
+    for (; e + 8 <= end; e += 8) {                   // eight rows in flight
+        long src[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = entries[e + i];
+            src[i] = (long)(o / Nneg) * vrows + K + o % Nneg;
+        }
+        float4 v[8][PER];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int c = 0; c < PER; ++c)
+                v[i][c] = lane + 64 * c < C4 ? v4[src[i] * C4 + lane + 64 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int c = 0; c < PER; ++c) { acc[c].x += v[i][c].x; acc[c].y += v[i][c].y; acc[c].z += v[i][c].z; acc[c].w += v[i][c].w; }
+    }
+    for (; e < end; ++e) {
+        const int o = entries[e];
+        add_row((long)(o / Nneg) * vrows + K + o % Nneg);
+    }
+#pragma unroll
+    for (int c = 0; c < PER; ++c)
+        if (lane + 64 * c < C4) reinterpret_cast<float4 *>(dz)[(long)r * C4 + lane + 64 * c] = acc[c];
+}
+
 // raw[0..n) -> batchIdx = raw % b, raw[n..2n) -> seqIdx = raw % (T-1) + 1 (draw order i = (bb*Nneg + nn)*W + t);
 // ext[(bb*W + t)*Nneg + nn] = (seqIdx + t) mod T + batchIdx*T      (criterion.py:247-266, integer-exact)
 __global__ void negidx_expand_kernel(const uint32_t *raw, int32_t *ext, int b, int T, int W, int Nneg)
@@ -324,6 +509,9 @@ struct NceLayout {
     float *P, *logits, *lse;            // saved
     size_t saved_bytes;
     float *lossp, *hit, *dP, *wt, *tn;  // scratch
+    float *vbuf;                        // scratch: [b*W][K + Nneg][Henc] contribution rows of the dz product
+    float *ds_buf;                      // scratch: [b*W][17][lw]
+    int *counts, *offsets, *entries;    // scratch: reference lists (counts doubles as the fill cursor)
     size_t tn_bytes, scratch_bytes;
     size_t lds_fwd, lds_bwd;
 };
@@ -349,6 +537,11 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.wt = sc.take<float>((size_t)K * Henc * Har);
     l.tn_bytes = gemm_tn_scratch_bytes(K * Henc, Har, (long)b * T);
     l.tn = sc.take<float>(l.tn_bytes / sizeof(float));
+    l.counts = sc.take<int>((size_t)b * T);
+    l.offsets = sc.take<int>((size_t)b * T + 1);
+    l.entries = sc.take<int>((size_t)b * l.W * Nneg);
+    l.vbuf = sc.take<float>((size_t)b * l.W * (K + Nneg) * Henc);
+    l.ds_buf = sc.take<float>((size_t)b * l.W * (NCE_ROWS + 1) * l.lw);
     l.scratch_bytes = sc.used();
     l.lds_fwd = 0;
     l.lds_bwd = sizeof(float) * (size_t)NCE_ROWS * l.lw + sizeof(int) * (size_t)l.lw;
@@ -396,18 +589,74 @@ static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *
     return CPC_OK;
 }
 
-static int nce_launch_bwd(NceArgs &a, const NceLayout &l, hipStream_t st)
+// The reference lists depend on the indices only, the kernels before the gather do not need them: they are built
+// on a stream of the library's own (one per device, created on first use), forked from and joined to the caller's
+// stream with events -- no host synchronisation, and nothing of it outlives the call on the caller's stream.
+struct NceSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+static int nce_side(NceSide **out)
 {
-    int status = CPC_OK;
-    {
-        ProfScope prof(PROF_NCE_BWD, st);
-        NCE_DISPATCH(l.Henc, {
-            status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
-            if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(l.b * a.p_rows)), dim3(64), l.lds_bwd, st, a);
-        });
+    static std::mutex mu;
+    static std::map<int, NceSide> sides;
+    int dev = 0;
+    CPC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    NceSide &sd = sides[dev];
+    if (sd.stream == nullptr) {
+        CPC_CHECK_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+        CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+        CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
     }
+    *out = &sd;
+    return CPC_OK;
+}
+
+// dz of the criterion: CPC_NCE_ATOMIC in the environment selects the fp32-atomic form, the default stores every
+// contribution once and sums per target row (see infonce_bwd_kernel)
+static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t st)
+{
+    static const bool atomic_dz = getenv("CPC_NCE_ATOMIC") != nullptr;
+    const long n = (long)l.b * l.W * l.Nneg;
+    const int rows = l.b * l.T;
+    a.dz = dz;
+    a.vbuf = atomic_dz ? nullptr : l.vbuf;
+    a.ds_buf = l.ds_buf;
+    ProfScope prof(PROF_NCE_BWD, st);
+    NceSide *side = nullptr;
+    if (atomic_dz) {
+        CPC_CHECK_HIP(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)rows * l.Henc, st));
+    } else {
+        CPC_TRY(nce_side(&side));
+        CPC_CHECK_HIP(hipEventRecord(side->fork, st));
+        CPC_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+        const unsigned blocks = (unsigned)std::min<long>(cdiv(n, 256), 4096);
+        CPC_CHECK_HIP(hipMemsetAsync(l.counts, 0, sizeof(int) * (size_t)rows, side->stream));
+        hipLaunchKernelGGL(nce_hist_kernel, dim3(blocks), dim3(256), 0, side->stream, a.ext, n, l.counts);
+        hipLaunchKernelGGL(nce_scan_kernel, dim3(1), dim3(1024), 0, side->stream, l.counts, rows, l.offsets);
+        CPC_CHECK_HIP(hipMemsetAsync(l.counts, 0, sizeof(int) * (size_t)rows, side->stream));
+        hipLaunchKernelGGL(nce_fill_kernel, dim3(blocks), dim3(256), 0, side->stream, a.ext, n, l.offsets, l.counts, l.entries);
+        hipLaunchKernelGGL(nce_sort_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, side->stream, l.offsets, l.entries, rows);
+        CPC_CHECK_LAUNCH("infonce reference lists");
+        CPC_CHECK_HIP(hipEventRecord(side->join, side->stream));
+    }
+    int status = CPC_OK;
+    NCE_DISPATCH(l.Henc, {
+        status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
+        if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(l.b * a.p_rows)), dim3(64), l.lds_bwd, st, a);
+    });
     CPC_TRY(status);
     CPC_CHECK_LAUNCH("infonce_bwd_kernel");
+    if (!atomic_dz) {
+        NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_store_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_bwd, st, a));
+        CPC_CHECK_LAUNCH("infonce_dz_store_kernel");
+        CPC_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
+        NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_gather_kernel<HH>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, l.vbuf,
+                                                 l.offsets, l.entries, dz, l.b, l.T, l.W, l.K, l.Nneg));
+        CPC_CHECK_LAUNCH("infonce_dz_gather_kernel");
+    }
     return CPC_OK;
 }
 
@@ -433,13 +682,12 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
 {
     NceLayout l;
     CPC_TRY(nce_layout(l, b, T, K, Har, Henc, Nneg, saved, scratch));
-    CPC_CHECK_HIP(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)b * T * Henc, st));
     NceArgs a{};
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) { a.Pk[k] = l.P + (size_t)k * Henc; a.dPk[k] = l.dP + (size_t)k * Henc; }
     a.p_stride = (long)K * Henc; a.p_rows = T;
-    a.dloss = dlosses; a.dz = dz;
-    CPC_TRY(nce_launch_bwd(a, l, st));
+    a.dloss = dlosses;
+    CPC_TRY(nce_launch_bwd(a, l, dz, st));
     // dc = dP . W  (rows t >= W of dP are zero)
     CPC_TRY(transpose2d(wpred, l.wt, K * Henc, Har, st));                        // [Har][K*Henc]
     RowMap none{};
@@ -468,13 +716,12 @@ static int infonce_backward_pred(const float *const *pred, const float *z, const
 {
     NceLayout l;
     CPC_TRY(nce_layout(l, b, T, K, Henc, Henc, Nneg, saved, scratch));
-    CPC_CHECK_HIP(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)b * T * Henc, st));
     NceArgs a{};
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) { a.Pk[k] = pred[k]; a.dPk[k] = dpred[k]; }
     a.p_stride = Henc; a.p_rows = l.W;
-    a.dloss = dlosses; a.dz = dz;
-    return nce_launch_bwd(a, l, st);
+    a.dloss = dlosses;
+    return nce_launch_bwd(a, l, dz, st);
 }
 
 }  // namespace cpc

@@ -13,7 +13,9 @@
  *   - plain C, no torch types; all pointers are DEVICE pointers unless named *_host.
  *   - the caller allocates every buffer (inputs, outputs, saved-for-backward workspace,
  *     scratch); sizes come from the *_bytes() queries; the library never frees or retains.
- *   - all work is enqueued on `stream` (a hipStream_t); no internal synchronisation.
+ *   - all work is enqueued on `stream` (a hipStream_t); no host synchronisation.  One exception to
+ *     "on `stream`": cpc_infonce_backward* build their reference lists on a stream owned by the
+ *     library (one per device), forked from and joined to `stream` with events inside the call.
  *   - every function returns 0 on success, a negative cpc_status otherwise;
  *     cpc_last_error() gives a thread-local message.
  *   - fp32 everywhere (the reference's arithmetic); activations are CHANNEL-LAST
@@ -226,7 +228,8 @@ int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_
  *   weights  [b*W] per-sample loss weights or NULL (ones)        (criterion.py:334-340)
  *   losses   [K]  mean_i(w_i * CE_i);  acc [K] = #(argmax == 0) / (b*W)
  * backward: dlosses [K] upstream gradient -> dc [b,T,dim_ar], dz [b,T,dim_enc],
- *           dwpred [K,dim_enc,dim_ar]  (all overwritten; dz uses fp32 atomics)
+ *           dwpred [K,dim_enc,dim_ar]  (all overwritten; dz is summed per row in a fixed order, so it
+ *           is identical from run to run; CPC_NCE_ATOMIC=1 in the environment selects fp32 atomics)
  * ------------------------------------------------------------------------------------------ */
 size_t cpc_infonce_saved_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
 size_t cpc_infonce_scratch_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
