@@ -179,7 +179,9 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # CPC_BENCH_FORCE_DIST=1: go through the process-group code path (RCCL init, broadcast, all-reduce) with one rank too
+    use_dist = world > 1 or bool(os.environ.get("CPC_BENCH_FORCE_DIST") and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
 
     from cpc2_amd import _lib
@@ -208,7 +210,7 @@ def main():
             log("first step done")
     torch.cuda.synchronize()
     log("warm-up done")
-    if world > 1:
+    if use_dist:
         dist.barrier()
     prof = not args.no_prof
     if prof:
@@ -218,12 +220,12 @@ def main():
     for _ in range(args.steps):
         losses = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     lib.cpc_prof_enable(0)
     log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -274,7 +276,7 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

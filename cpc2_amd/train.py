@@ -161,12 +161,13 @@ class DataParallelContext:
 
     def __init__(self, optimizer):
         self.opt = optimizer
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if self.world > 1:
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.active else 1
+        if self.active:
             dist.broadcast(self.opt.flat, src=0)
 
     def reduce_and_step(self):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM)
         self.opt.step(grad_scale=1.0 / self.world)
 
