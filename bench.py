@@ -41,6 +41,8 @@ CONFIGS = {
     "transformer_pred": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", rnn="transformer"),
     # the fork's default autoregressive network (arMode='LSTM', cpc_default_config.py; model.py:171-173)
     "lstm": dict(hidden=256, layers=1, npred=12, nneg=128, ar="LSTM"),
+    # the documented training recipe (docs/training_and_eval.md:6-9): the defaults + --n-levels-gru=2 --multihead-rnn
+    "recipe": dict(hidden=256, layers=2, npred=12, nneg=128, ar="LSTM", rnn="transformer", multihead=True),
 }
 GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
@@ -72,7 +74,10 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
             launches += 2
         din = h
     w = t_len - cfg["npred"]
-    if cfg.get("rnn") == "transformer":                 # K one-layer transformer predictors on [b, W, H]
+    if cfg.get("multihead"):                            # one transformer, the FFN emits K branches, K x last_linear
+        flops += 2 * (2.0 * b * w * (16 * h * h + 13 * h * 2048))
+        launches += 12
+    elif cfg.get("rnn") == "transformer":               # K one-layer transformer predictors on [b, W, H]
         flops += cfg["npred"] * 2 * (2.0 * b * w * (5 * h * h + 2 * h * 2048))
         launches += cfg["npred"] * 12
     else:
@@ -93,7 +98,8 @@ def build(cfg, device):
         ar = cpc2_amd.CPCAR(cfg["hidden"], cfg["hidden"], False, cfg["layers"], mode=cfg["ar"])
     model = cpc2_amd.CPCModel(enc, ar).to(device)
     crit = cpc2_amd.CPCUnsupersivedCriterion(cfg["npred"], cfg["hidden"], cfg["hidden"], cfg["nneg"],
-                                             rnnMode=cfg.get("rnn", "linear"), sizeInputSeq=WINDOW // 160).to(device)
+                                             rnnMode=cfg.get("rnn", "linear"), sizeInputSeq=WINDOW // 160,
+                                             multihead_rnn=cfg.get("multihead", False)).to(device)
     opt = buildOptimizer(model, crit, lr=2e-4)
     return model, crit, opt
 
@@ -249,7 +255,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
-                                   f"{cfg['npred']}, {cfg['nneg']} negatives, {cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
+                                   f"{cfg['npred']}, {cfg['nneg']} negatives, {('multi-head ' if cfg.get('multihead') else '') + cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
                                    f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
                                                              if args.dedup else
                                                              "reference trainStep semantics (encoder+AR on 2b windows), ")
