@@ -59,13 +59,15 @@ def getCriterion(args, downsampling, nSpeakers=0, nPhones=0):
 
 
 # --------------------------------------------------------------------------- flat parameters + fused Adam
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, betas, eps) of train.py:477-479 on one flat buffer.
 
     Re-homes every parameter into `self.flat` (views, same values) and every .grad into
     `self.flat_grad`, then `step()` is a single cpc_adam_step launch.  State-dict interop with
     torch.optim.Adam is kept through `state_dict()` / `load_state_dict()` (per-parameter
-    exp_avg / exp_avg_sq / step)."""
+    exp_avg / exp_avg_sq / step).  A torch.optim.Optimizer with ONE param group, so the reference's
+    learning-rate schedulers (train.py:501-520: StepLR, the LambdaLR ramp, SchedulerCombiner) attach
+    to it unchanged; the learning rate is read from param_groups[0]["lr"] at every step."""
 
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, direct_grads=True):
         self.params = [p for p in params]
@@ -74,6 +76,7 @@ class FlatAdam:
             raise ValueError("FlatAdam got an empty parameter list")
         dev = self.params[0].device
         _lib.require_gpu(*self.params)
+        super(FlatAdam, self).__init__(self.params, dict(lr=lr, betas=betas, eps=eps))
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         total = sum(p.numel() for p in self.params)
@@ -96,7 +99,6 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
             self.offsets.append(off)
             off += n
-        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "params": self.params}]
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
@@ -116,7 +118,9 @@ class FlatAdam:
             if p.grad is not None and p.grad.data_ptr() != base + 4 * off:
                 self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
 
-    def step(self, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0):
+        if closure is not None:
+            raise NotImplementedError("FlatAdam.step does not re-evaluate a closure")
         if self.direct_grads:
             self._gather_stray_grads()
         self.step_count += 1
@@ -154,6 +158,57 @@ def buildOptimizer(cpcModel, cpcCriterion, lr=2e-4, beta1=0.9, beta2=0.999, epsi
 
 
 # --------------------------------------------------------------------------- data parallel
+# --------------------------------------------------------------------------- learning-rate schedule
+def ramp_scheduling_function(n_epoch_ramp, epoch, square_ramp=False):
+    """cpc/utils/misc.py:77-83: linear (or squared) warm-up factor over the first n_epoch_ramp epochs."""
+    if epoch >= n_epoch_ramp:
+        return 1
+    frac = (epoch + 1) / n_epoch_ramp
+    return frac ** 2 if square_ramp else frac
+
+
+class SchedulerCombiner:
+    """cpc/utils/misc.py:85-122: schedulers activated one after the other.  step() advances every scheduler from the
+    one before the current activation boundary on, LAST first -- so while the ramp is active the step schedule's
+    epoch counter already runs, and the ramp (stepped last) has the final word on the learning rate."""
+
+    def __init__(self, scheduler_list, activation_step, curr_step=0):
+        if len(scheduler_list) != len(activation_step):
+            raise ValueError("The number of scheduler must be the same as the number of activation step")
+        if activation_step[0] > curr_step:
+            raise ValueError("The first activation step cannot be higher than the current step.")
+        self.scheduler_list = scheduler_list
+        self.activation_step = list(activation_step)
+        self.curr_step = curr_step
+
+    def step(self):
+        import bisect
+        self.curr_step += 1
+        first = bisect.bisect_left(self.activation_step, self.curr_step) - 1
+        for i in reversed(range(first, len(self.scheduler_list))):
+            self.scheduler_list[i].step()
+
+    def __str__(self):
+        return "SchedulerCombiner \n(\n" + "".join(f"({i}) {sc} \n" for i, sc in enumerate(self.scheduler_list)) + ")\n"
+
+
+def buildScheduler(optimizer, schedulerStep=-1, schedulerRamp=None, epochs_done=0):
+    """train.py:501-520: StepLR(gamma 0.5) every schedulerStep epochs, a linear ramp over the first schedulerRamp
+    epochs, both (combined), or None; then fast-forwarded over the epochs a resumed run has behind it."""
+    scheduler = None
+    if schedulerStep > 0:
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, schedulerStep, gamma=0.5)
+    if schedulerRamp is not None:
+        n_epoch = schedulerRamp
+        ramp = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: ramp_scheduling_function(n_epoch, epoch),
+                                                 last_epoch=-1)
+        scheduler = ramp if scheduler is None else SchedulerCombiner([ramp, scheduler], [0, schedulerRamp])
+    if scheduler is not None:
+        for _ in range(epochs_done):
+            scheduler.step()
+    return scheduler
+
+
 class DataParallelContext:
     """One process per GPU (train.py:291-295, 523-527 with --distributed).  Replaces the two DDP
     wrappers by: one broadcast of the flat parameter buffer from rank 0 at start, and one all-reduce

@@ -188,3 +188,24 @@ def test_span_mask_draws_like_the_reference(golden):
         m = span_mask(int(bsz), int(frames), float(prob), int(length), min_masks=int(mn))
         assert m.dtype == bool and np.array_equal(m, g[f"mask{i}"]), i
     assert np.random.rand() == float(g["rand_after"])
+
+
+# ----------------------------------------------------------------------------- learning-rate schedules (train.py:501-520)
+@pytest.mark.parametrize("tag,step,ramp,done", [("step3", 3, None, 0), ("ramp4", -1, 4, 0), ("ramp4_step3", 3, 4, 0),
+                                               ("ramp4_step3_resumed5", 3, 4, 5)])
+def test_lr_schedules_follow_the_reference(tag, step, ramp, done):
+    import numpy as np
+    import torch
+    from cpc2_amd.train import buildScheduler
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "g13_lr_schedules.npz"))[tag]
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=2e-4)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                 # the reference steps the scheduler before the optimiser when resuming
+        sched = buildScheduler(opt, step, ramp, done)
+        lrs = []
+        for _ in range(len(ref)):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+    assert np.allclose(lrs, ref, rtol=1e-12, atol=0)

@@ -749,6 +749,33 @@ def test_fused_adam_vs_oracle():
         assert_close(p.data, r, 1e-6, "adam params")
 
 
+def test_flat_adam_is_a_torch_optimizer_the_schedulers_drive():
+    """train.py:501-520: the reference's StepLR / ramp / SchedulerCombiner attach to the optimiser and the fused update
+    uses the scheduled rate (zero gradient history: the first Adam step moves every weight by exactly lr)."""
+    import warnings
+    from cpc2_amd.train import buildScheduler
+    w = torch.nn.Parameter(torch.zeros(1000, device=DEV))
+    opt = FlatAdam([w], lr=2e-4)
+    assert isinstance(opt, torch.optim.Optimizer)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sched = buildScheduler(opt, 3, 4, 0)
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_lr_schedules.npz"))["ramp4_step3"]
+    for epoch in range(8):
+        lr = opt.param_groups[0]["lr"]
+        assert abs(lr - ref[epoch]) <= 1e-12 * ref[epoch]
+        if epoch == 0:
+            w.grad = None
+            before = w.detach().clone()
+            (w.sum()).backward()
+            opt.step()
+            opt.zero_grad()
+            assert_close(before - w.detach(), torch.full((1000,), float(lr)), 1e-5, "first Adam step = lr")
+        else:
+            opt.step()
+        sched.step()
+
+
 def test_dedup_step_matches_reference_semantics():
     hidden, b, k, nn = 64, 3, 12, 16
     mp = synth.encoder_params(hidden, 21)

@@ -425,7 +425,36 @@ def g12():
     save("g12_lstm_rnn.npz", **d)
 
 
+# ------------------------------------------------------------------ G13 learning-rate schedules
+def g13():
+    """train.py:501-520 with the reference's own utils: learning rate after each of 14 epochs for the three scheduler
+    set-ups (step only, ramp only, ramp + step through SchedulerCombiner) and a resumed run (5 epochs done)."""
+    import cpc.utils.misc as ref_utils
+
+    def make(step, ramp, done):
+        w = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.Adam([w], lr=2e-4)
+        sched = None
+        if step > 0:
+            sched = torch.optim.lr_scheduler.StepLR(opt, step, gamma=0.5)
+        if ramp is not None:
+            r = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: ref_utils.ramp_scheduling_function(ramp, e),
+                                                  last_epoch=-1)
+            sched = r if sched is None else ref_utils.SchedulerCombiner([r, sched], [0, ramp])
+        for _ in range(done):
+            sched.step()
+        lrs = []
+        for _ in range(14):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+        return np.array(lrs)
+
+    save("g13_lr_schedules.npz", step3=make(3, None, 0), ramp4=make(-1, 4, 0), ramp4_step3=make(3, 4, 0),
+         ramp4_step3_resumed5=make(3, 4, 5))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for name in which:
         globals()[name]()
