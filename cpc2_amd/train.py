@@ -315,6 +315,42 @@ def valStep(dataLoader, cpcModel, cpcCriterion, device=None):
     return logs
 
 
+def run(trainDataset, valDataset, batchSize, samplingMode, cpcModel, cpcCriterion, nEpoch, pathCheckpoint, optimizer,
+        scheduler, logs, no_artefacts=False, batchSizePerGPU=None, dp=None, is_master=True):
+    """The epoch loop of train.py:190-255: per epoch a fresh train loader (random offsets) and a sequential
+    validation loader, trainStep, valStep, the logs dict extended key by key, and every logs["saveStep"] epochs (and
+    after the last one) a checkpoint `{pathCheckpoint}_{epoch}.pt` in the reference layout plus `_logs.json`.
+    Resumes from len(logs["epoch"]).  Like the reference, `best` holds the model state of the last epoch whose
+    validation accuracy beat bestAcc -- which is never raised from 0 (train.py:207,237-238)."""
+    import json
+    from . import feature_loader as fl
+    dp = dp or DataParallelContext(optimizer)
+    print(f"Running {nEpoch} epochs")
+    best_acc, best_state = 0, None
+    t_start = time.perf_counter()
+    for epoch in range(len(logs["epoch"]), nEpoch):
+        print(f"Starting epoch {epoch}")
+        train_loader = trainDataset.getDataLoader(batchSize, samplingMode, True, numWorkers=0, remove_artefacts=no_artefacts,
+                                                  batch_size_per_gpu=batchSizePerGPU)
+        val_loader = valDataset.getDataLoader(batchSize, "sequential", False, numWorkers=0)
+        print("Training dataset %d batches, Validation dataset %d batches, batch size %d"
+              % (len(train_loader), len(val_loader), batchSize))
+        epoch_logs = trainStep(train_loader, cpcModel, cpcCriterion, optimizer, scheduler, logs["logging_step"], dp=dp)
+        epoch_logs.update(valStep(val_loader, cpcModel, cpcCriterion))
+        print(f"Ran {epoch + 1} epochs in {time.perf_counter() - t_start:.2f} seconds")
+        if "locAcc_val" in epoch_logs and float(epoch_logs["locAcc_val"].mean()) > best_acc:
+            best_state = {k: v.detach().clone() for k, v in fl.get_module(cpcModel).state_dict().items()}
+        for key, value in epoch_logs.items():
+            logs.setdefault(key, [None] * epoch).append(value.tolist() if isinstance(value, np.ndarray) else value)
+        logs["epoch"].append(epoch)
+        if pathCheckpoint is not None and is_master and (epoch % logs["saveStep"] == 0 or epoch == nEpoch - 1):
+            fl.save_checkpoint(fl.get_module(cpcModel).state_dict(), fl.get_module(cpcCriterion).state_dict(),
+                               optimizer.state_dict(), best_state, f"{pathCheckpoint}_{epoch}.pt")
+            with open(pathCheckpoint + "_logs.json", "w") as fh:
+                json.dump(logs, fh, indent=2)
+    return logs
+
+
 def init_distributed_mode(backend="nccl"):
     """distributed_mode.py:75-142 reduced to the torch.distributed.run environment: RANK, LOCAL_RANK,
     WORLD_SIZE, MASTER_ADDR/PORT; one process per GPU; backend 'nccl' is RCCL on ROCm."""

@@ -965,3 +965,48 @@ def test_training_steps_on_reference_test_data_vs_oracle():
         adam.step(dict(zip(params, grads)))
         err = float(((curve[step] - losses.detach()).abs() / losses.detach().abs()).max())
         assert err <= 1e-3, f"step {step}: loss differs by {err:.2e}"
+
+
+def test_run_epoch_loop_checkpoints_and_resumes(tmp_path):
+    """train.py:190-255 on the reference's cpc/test_data fixture: two epochs with a ramp + step schedule, logs grow key by
+    key, checkpoints in the reference layout every saveStep epochs; a second call resumes from len(logs["epoch"])."""
+    import json
+    import random
+    from cpc2_amd.feature_loader import getCheckpointData, loadModel
+    from cpc2_amd.train import buildScheduler, run
+    hidden = 64
+    model, _ = _small_model(hidden)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128).to(DEV)
+    crit.seed(7)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    sched = buildScheduler(opt, schedulerStep=2, schedulerRamp=2)
+    random.seed(0)
+    data = _feeder(DEV)
+    ckpt = str(tmp_path / "checkpoint")
+    with open(ckpt + "_args.json", "w") as fh:
+        json.dump({"hiddenEncoder": hidden, "hiddenGar": hidden, "arMode": "GRU", "nLevelsGRU": 1, "encoder_type": "cpc",
+                   "normMode": "layerNorm", "samplingType": "uniform", "cpc_mode": None}, fh)
+    logs = {"epoch": [], "iter": [], "saveStep": 1, "logging_step": 1000}
+    before = model.gEncoder.conv0.weight.detach().clone()
+    run(data, data, 8, "uniform", model, crit, 2, ckpt, opt, sched, logs)
+    assert logs["epoch"] == [0, 1] and len(logs["locLoss_train"]) == 2 and len(logs["locAcc_val"]) == 2
+    assert len(logs["locLoss_train"][0]) == 12 and all(np.isfinite(logs["locLoss_val"][1]))
+    assert not torch.equal(before, model.gEncoder.conv0.weight.detach())
+    shadow = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-4)     # same schedule on a plain optimiser
+    shadow_sched = buildScheduler(shadow, schedulerStep=2, schedulerRamp=2)
+    for _ in range(2):
+        shadow.step()
+        shadow_sched.step()
+    assert opt.param_groups[0]["lr"] == shadow.param_groups[0]["lr"]
+    for epoch in (0, 1):
+        sd = torch.load(f"{ckpt}_{epoch}.pt", map_location="cpu")
+        assert set(sd) == {"gEncoder", "cpcCriterion", "optimizer", "best"}
+    path, saved_logs, _args = getCheckpointData(str(tmp_path))
+    assert path.endswith("checkpoint_1.pt") and saved_logs["epoch"] == [0, 1]
+    # resume: nothing to do for nEpoch = 2, one more epoch for nEpoch = 3
+    run(data, data, 8, "uniform", model, crit, 2, ckpt, opt, sched, saved_logs)
+    assert saved_logs["epoch"] == [0, 1]
+    run(data, data, 8, "uniform", model, crit, 3, ckpt, opt, sched, saved_logs)
+    assert saved_logs["epoch"] == [0, 1, 2] and os.path.exists(f"{ckpt}_2.pt")
+    reloaded = loadModel([f"{ckpt}_2.pt"])[0]
+    assert torch.equal(reloaded.gEncoder.conv0.weight.cpu(), model.gEncoder.conv0.weight.detach().cpu())
