@@ -12,10 +12,22 @@ template <int H> struct RowCfg {
     static constexpr int RPW = 64 / G;   // rows per wave pass
 };
 
+template <int CTRL> __device__ __forceinline__ float row_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over an aligned group of G lanes (8, 16, 32 or 64), left in every lane.  Inside a row of 16 lanes the partners
+// come through data-parallel primitives (VALU speed); only the 16- and 32-lane hops go through the LDS crossbar.
 template <int G> __device__ __forceinline__ float group_sum(float v)
 {
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group of 8, 16, 32 or 64 lanes");
+    v += row_dpp<0xB1>(v);                      // quad_perm [1,0,3,2]
+    v += row_dpp<0x4E>(v);                      // quad_perm [2,3,0,1]
+    v += row_dpp<0x141>(v);                     // row_half_mirror
+    if (G >= 16) v += row_dpp<0x140>(v);        // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
