@@ -135,7 +135,8 @@ _scratch = {}
 
 
 def scratch(nbytes, device):
-    key = (device.type, device.index)
+    # one buffer per (device, stream): ops enqueued on different streams may run at the same time
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
