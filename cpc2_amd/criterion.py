@@ -260,15 +260,16 @@ class _InfoNCEPredFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- modules
 class PredictionNetwork(nn.Module):
     """criterion.py:97-173: K predictors under `predictors` (same keys / init as the reference):
-    linear (the `else` branch :144-150, nn.Linear(dimOutputAR, dimOutputEncoder, bias=False)) or one-layer
-    transformers (rnnMode='transformer' :136-143, the fork's default; keys `predictors.{k}.0.*`)."""
+    linear (the `else` branch :144-150, nn.Linear(dimOutputAR, dimOutputEncoder, bias=False)), one-layer
+    transformers (rnnMode='transformer' :136-143, the fork's default; keys `predictors.{k}.0.*`), or the recurrent
+    ones (rnnMode='LSTM' / 'RNN' :115-123)."""
 
     def __init__(self, nPredicts, dimOutputAR, dimOutputEncoder, rnnMode=None, dropout=False,
                  sizeInputSeq=116, transformer_pruning=0):
         super(PredictionNetwork, self).__init__()
-        if rnnMode in ("RNN", "LSTM", "ffd", "conv4", "conv8", "conv12"):
+        if rnnMode in ("ffd", "conv4", "conv8", "conv12"):
             raise NotImplementedError(
-                f"rnnMode={rnnMode!r}: only 'linear' and 'transformer' predictors have an MI355X kernel path")
+                f"rnnMode={rnnMode!r}: only 'linear', 'transformer', 'LSTM' and 'RNN' predictors have an MI355X kernel path")
         if dropout:
             raise NotImplementedError("predictor dropout is not supported by the MI355X hot path")
         self.predictors = nn.ModuleList()
@@ -281,6 +282,12 @@ class PredictionNetwork(nn.Module):
             for _ in range(nPredicts):
                 self.predictors.append(buildTransformerAR(dimOutputEncoder, dimOutputAR, nLayers=1,
                                                           sizeSeq=sizeInputSeq, abspos=False))
+            return
+        if rnnMode in ('LSTM', 'RNN'):                   # criterion.py:115-123
+            from .model import LSTMPredictor, RNNPredictor
+            for _ in range(nPredicts):
+                self.predictors.append(LSTMPredictor(dimOutputAR, dimOutputEncoder, batch_first=True) if rnnMode == 'LSTM'
+                                       else RNNPredictor(dimOutputAR, dimOutputEncoder))
             return
         for _ in range(nPredicts):
             self.predictors.append(nn.Linear(dimOutputAR, dimOutputEncoder, bias=False))
@@ -402,9 +409,10 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
             preds = torch.unbind(self.wPrediction.predictor(cW), dim=2)    # criterion.py:85 prediction[:, :, k]
             losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
-        elif self.wPrediction.rnnMode == 'transformer':
+        elif self.wPrediction.rnnMode in ('transformer', 'LSTM', 'RNN'):
             cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
             preds = [predictor(cW) for predictor in self.wPrediction.predictors]
+            preds = [p[0] if isinstance(p, tuple) else p for p in preds]   # criterion.py:164-165
             losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
         else:
             losses, acc = _InfoNCEFn.apply(cFeature, encodedData, extIdx, quality_weighting, self.negativeSamplingExt,

@@ -297,6 +297,31 @@ class CPCAR(nn.Module):
         return x
 
 
+class LSTMPredictor(nn.LSTM):
+    """nn.LSTM(dimOutputAR, dimOutputEncoder, batch_first=True) as a predictor (criterion.py:119-123): same parameters and
+    state-dict keys, forward on the HIP kernels; returns (output, None) -- the criterion only takes element 0."""
+
+    def forward(self, x, hx=None):
+        if hx is not None or not self.batch_first or self.bidirectional or self.proj_size:
+            raise NotImplementedError("LSTMPredictor: batch_first, unidirectional, zero initial state only")
+        params = [getattr(self, f"{n}_l{layer}") for layer in range(self.num_layers)
+                  for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return _LstmFn.apply(x, None, None, self.num_layers, False, *params)[0], None
+
+
+class RNNPredictor(nn.RNN):
+    """nn.RNN(dimOutputAR, dimOutputEncoder) as a predictor (criterion.py:115-118).  Like the reference's it is NOT
+    batch_first: fed c [b, W, H], the recurrence runs along b and W is the batch."""
+
+    def forward(self, x, hx=None):
+        if hx is not None or self.batch_first or self.bidirectional or self.nonlinearity != "tanh":
+            raise NotImplementedError("RNNPredictor: time-major, unidirectional tanh RNN with zero initial state only")
+        params = [getattr(self, f"{n}_l{layer}") for layer in range(self.num_layers)
+                  for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        out = _GruFn.apply(x.transpose(0, 1).contiguous(), None, self.num_layers, False, "rnn", *params)[0]
+        return out.transpose(0, 1).contiguous(), None
+
+
 # --------------------------------------------------------------------------- CPCModel
 def span_mask(batch, frames, mask_prob, mask_length, min_masks=0):
     """Boolean [batch, frames] mask of model.py:300-365 (the simplified wav2vec 2.0 span sampler): the same draws from

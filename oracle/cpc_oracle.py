@@ -244,6 +244,14 @@ def transformer_predictors(p, k_steps, prefix="wPrediction.predictors."):
     return [(lambda c, i=i: transformer_layer_forward(c, p, f"{prefix}{i}.0.")) for i in range(k_steps)]
 
 
+def recurrent_predictors(p, k_steps, mode, prefix="wPrediction.predictors."):
+    """rnnMode='LSTM' (criterion.py:119-123: nn.LSTM, batch_first) or 'RNN' (:115-118: nn.RNN WITHOUT batch_first, so
+    the recurrence runs along the batch axis of c [b, W, H] and W plays the batch)."""
+    if mode == "LSTM":
+        return [(lambda c, i=i: lstm_forward(c, p, 1, f"{prefix}{i}.")[0]) for i in range(k_steps)]
+    return [(lambda c, i=i: rnn_forward(c.transpose(0, 1), p, 1, f"{prefix}{i}.")[0].transpose(0, 1)) for i in range(k_steps)]
+
+
 def static_position_embedding(seqlen, dmodel, dtype=torch.float32):
     """transformers.py:161-173."""
     pos = torch.arange(0., seqlen, dtype=torch.float64).unsqueeze(1).repeat(1, dmodel)

@@ -440,6 +440,31 @@ def test_criterion_transformer_predictors_vs_reference_golden(golden):
             assert_close(prm.grad, t(g["grad." + name]), 5e-4, f"grad {name}")
 
 
+@pytest.mark.parametrize("mode,gates", [("LSTM", 4), ("RNN", 1)])
+def test_criterion_recurrent_predictors_vs_reference_golden(golden, mode, gates):
+    """rnnMode='LSTM' / 'RNN' (criterion.py:115-123): same state-dict keys, losses and gradients as the reference."""
+    g = golden("g14_criterion_recurrent_pred.npz")
+    b, t_len, har, henc, k, nn, seed = (int(v) for v in g["cfg"])
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, har, henc, nn, rnnMode=mode, sizeInputSeq=t_len)
+    sd = {}
+    for i in range(k):
+        sd.update(synth.gru_params(har, henc, 1, seed=110 + i, prefix=f"wPrediction.predictors.{i}.", gates=gates))
+    assert sorted(sd) == sorted(crit.state_dict())
+    crit.load_state_dict(sd)
+    crit = crit.to(DEV)
+    c = synth.features((b, t_len, har), 120).to(DEV).requires_grad_(True)
+    z = synth.features((b, t_len, henc), 121, relu=True).to(DEV).requires_grad_(True)
+    torch.manual_seed(seed)
+    losses, acc = crit(c, z, None)
+    assert_close(losses, t(g[f"{mode}_losses"]), 1e-5, "losses")
+    assert torch.allclose(acc.cpu(), t(g[f"{mode}_acc"]), atol=1.5 / (b * (t_len - k)))
+    losses.sum().backward()
+    assert_close(c.grad, t(g[f"{mode}_dc"]), 2e-4, "dc")
+    assert_close(z.grad, t(g[f"{mode}_dz"]), 1e-4, "dz")
+    for name, prm in crit.named_parameters():
+        assert_close(prm.grad, t(g[f"{mode}_grad." + name]), 5e-4, f"grad {name}")
+
+
 def test_criterion_multihead_predictor_vs_reference_golden(golden):
     """--multihead_rnn with rnnMode='transformer' (criterion.py:44-94, transformers.py:137-158,190-212), eval mode."""
     g = golden("g9_criterion_multihead_pred.npz")

@@ -275,6 +275,28 @@ def test_criterion_with_transformer_predictors(golden):
     assert torch.allclose(z.grad, t(g["dz"]), atol=1e-8, rtol=1e-4)
 
 
+# ----------------------------------------------------------------------------- G14
+@pytest.mark.parametrize("mode,gates", [("LSTM", 4), ("RNN", 1)])
+def test_criterion_with_recurrent_predictors(golden, mode, gates):
+    """rnnMode='LSTM' / 'RNN' (criterion.py:115-123); the RNN is not batch_first and recurs along the batch axis."""
+    g = golden("g14_criterion_recurrent_pred.npz")
+    b, t_len, har, henc, k, nn, seed = (int(v) for v in g["cfg"])
+    p = {}
+    for i in range(k):
+        p.update(synth.gru_params(har, henc, 1, seed=110 + i, prefix=f"wPrediction.predictors.{i}.", gates=gates))
+    p = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+    c = synth.features((b, t_len, har), 120).requires_grad_(True)
+    z = synth.features((b, t_len, henc), 121, relu=True).requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(seed), b, t_len, t_len - k, nn)
+    losses, acc = O.criterion_forward(c, z, O.recurrent_predictors(p, k, mode), ext, nn)
+    losses.sum().backward()
+    assert torch.allclose(losses, t(g[f"{mode}_losses"]), atol=0, rtol=1e-6)
+    assert torch.allclose(c.grad, t(g[f"{mode}_dc"]), atol=1e-8, rtol=1e-4)
+    assert torch.allclose(z.grad, t(g[f"{mode}_dz"]), atol=1e-8, rtol=1e-4)
+    for n, v in p.items():
+        assert torch.allclose(v.grad, t(g[f"{mode}_grad." + n]), atol=1e-8, rtol=1e-4), n
+
+
 # ----------------------------------------------------------------------------- G9
 def test_criterion_with_multihead_predictor(golden):
     """--multihead_rnn (criterion.py:44-94): one transformer head with nPredicts residual branches."""

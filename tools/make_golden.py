@@ -454,7 +454,31 @@ def g13():
          ramp4_step3_resumed5=make(3, 4, 5))
 
 
+# ------------------------------------------------------------------ G14 recurrent predictors
+def g14():
+    """rnnMode='LSTM' (nn.LSTM, batch_first) and rnnMode='RNN' (nn.RNN -- NOT batch_first: the recurrence then runs
+    over the batch axis of c, criterion.py:115-123,163) as predictors; forward + backward."""
+    d = {}
+    b, t_len, har, henc, k, nn, seed = 4, 32, 24, 32, 4, 8, 7
+    for mode, gates in (("LSTM", 4), ("RNN", 1)):
+        crit = ref_crit.CPCUnsupersivedCriterion(k, har, henc, nn, rnnMode=mode, sizeInputSeq=t_len)
+        sd = {}
+        for i in range(k):
+            sd.update(synth.gru_params(har, henc, 1, seed=110 + i, prefix=f"wPrediction.predictors.{i}.", gates=gates))
+        crit.load_state_dict(sd)
+        c = synth.features((b, t_len, har), seed=120).requires_grad_(True)
+        z = synth.features((b, t_len, henc), seed=121, relu=True).requires_grad_(True)
+        torch.manual_seed(seed)
+        losses, acc = crit(c, z, None)
+        losses.sum().backward()
+        d[f"{mode}_losses"], d[f"{mode}_acc"], d[f"{mode}_dc"], d[f"{mode}_dz"] = losses, acc, c.grad, z.grad
+        for name, prm in crit.named_parameters():
+            d[f"{mode}_grad." + name] = prm.grad
+    d["cfg"] = np.array([b, t_len, har, henc, k, nn, seed])
+    save("g14_criterion_recurrent_pred.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for name in which:
         globals()[name]()
