@@ -297,6 +297,63 @@ class CPCAR(nn.Module):
         return x
 
 
+class NoAr(nn.Module):
+    """model.py:210-216 (arMode='no_ar'): the context IS the encoder output."""
+
+    def __init__(self, *args):
+        super(NoAr, self).__init__()
+
+    def forward(self, x):
+        return x
+
+
+def _gru_layer_params(gru, layer, suffix=""):
+    return [getattr(gru, f"{n}_l{layer}{suffix}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+
+
+class BiDIRARTangled(nn.Module):
+    """model.py:219-241 (cpc_mode='bert'): one bidirectional multi-layer GRU (keys `ARNet.*`, the backward direction's
+    with the `_reverse` suffix).  Every (layer, direction) is one single-layer run of the GRU kernels; a layer's input is
+    the concatenation of both directions of the layer below, as in torch.nn.GRU."""
+
+    def __init__(self, dimEncoded, dimOutput, nLevelsGRU):
+        super(BiDIRARTangled, self).__init__()
+        assert dimOutput % 2 == 0
+        self.ARNet = nn.GRU(dimEncoded, dimOutput // 2, num_layers=nLevelsGRU, batch_first=True, bidirectional=True)
+
+    def getDimOutput(self):
+        return self.ARNet.hidden_size * 2
+
+    def forward(self, x):
+        for layer in range(self.ARNet.num_layers):
+            xf = _GruFn.apply(x, None, 1, False, "gru", *_gru_layer_params(self.ARNet, layer))[0]
+            xb = _GruFn.apply(torch.flip(x, [1]), None, 1, False, "gru", *_gru_layer_params(self.ARNet, layer, "_reverse"))[0]
+            x = torch.cat([xf, torch.flip(xb, [1])], dim=2)
+        return x
+
+
+class BiDIRAR(nn.Module):
+    """model.py:244-272: two independent GRUs, one over the sequence and one over its mirror image."""
+
+    def __init__(self, dimEncoded, dimOutput, nLevelsGRU):
+        super(BiDIRAR, self).__init__()
+        assert dimOutput % 2 == 0
+        self.netForward = nn.GRU(dimEncoded, dimOutput // 2, num_layers=nLevelsGRU, batch_first=True)
+        self.netBackward = nn.GRU(dimEncoded, dimOutput // 2, num_layers=nLevelsGRU, batch_first=True)
+
+    def getDimOutput(self):
+        return self.netForward.hidden_size * 2
+
+    def _run(self, gru, x):
+        params = [p for layer in range(gru.num_layers) for p in _gru_layer_params(gru, layer)]
+        return _GruFn.apply(x, None, gru.num_layers, False, "gru", *params)[0]
+
+    def forward(self, x):
+        xf = self._run(self.netForward, x)
+        xb = self._run(self.netBackward, torch.flip(x, [1]))
+        return torch.cat([xf, torch.flip(xb, [1])], dim=2)
+
+
 class LSTMPredictor(nn.LSTM):
     """nn.LSTM(dimOutputAR, dimOutputEncoder, batch_first=True) as a predictor (criterion.py:119-123): same parameters and
     state-dict keys, forward on the HIP kernels; returns (output, None) -- the criterion only takes element 0."""

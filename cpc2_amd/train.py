@@ -29,13 +29,19 @@ def getEncoder(args):
 
 
 def getAR(args):
-    """feature_loader.py:215-235 (CPCAR / transformer branches)."""
+    """feature_loader.py:215-235: every branch (transformer, the bidirectional GRU of cpc_mode='bert', no_ar, CPCAR)."""
     if args.arMode == "transformer":
         from .transformers import buildTransformerAR
         arNet = buildTransformerAR(args.hiddenEncoder, args.hiddenGar, args.nLevelsGRU,
                                    args.sizeWindow // 160, args.abspos)
         args.hiddenGar = args.hiddenEncoder
         return arNet
+    if getattr(args, "cpc_mode", None) == "bert":
+        from .model import BiDIRARTangled
+        return BiDIRARTangled(args.hiddenEncoder, args.hiddenGar, args.nLevelsGRU)
+    if args.arMode == "no_ar":
+        from .model import NoAr
+        return NoAr()
     return CPCAR(args.hiddenEncoder, args.hiddenGar, args.samplingType == "sequential", args.nLevelsGRU,
                  mode=args.arMode, reverse=getattr(args, "cpc_mode", None) == "reverse")
 

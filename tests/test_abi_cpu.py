@@ -160,6 +160,10 @@ def test_build_ar_like_reference_TestARBuilder():
     lstm = getAR(_default_args(arMode="LSTM", nLevelsGRU=2))                 # the fork's default arMode
     assert isinstance(lstm.baseNet, torch.nn.LSTM) and lstm.baseNet.num_layers == 2 and lstm.getDimOutput() == 256
     assert isinstance(getAR(_default_args(arMode="RNN")).baseNet, torch.nn.RNN)
+    from cpc2_amd.model import BiDIRARTangled, NoAr
+    bert = getAR(_default_args(cpc_mode="bert", nLevelsGRU=2))
+    assert isinstance(bert, BiDIRARTangled) and bert.ARNet.bidirectional and bert.getDimOutput() == 256
+    assert isinstance(getAR(_default_args(arMode="no_ar")), NoAr)
 
 
 def test_build_criterion_variants():

@@ -1035,3 +1035,24 @@ def test_run_epoch_loop_checkpoints_and_resumes(tmp_path):
     assert saved_logs["epoch"] == [0, 1, 2] and os.path.exists(f"{ckpt}_2.pt")
     reloaded = loadModel([f"{ckpt}_2.pt"])[0]
     assert torch.equal(reloaded.gEncoder.conv0.weight.cpu(), model.gEncoder.conv0.weight.detach().cpu())
+
+
+@pytest.mark.parametrize("name", ["tangled", "bidir"])
+def test_bidirectional_context_networks_vs_reference_golden(golden, name):
+    """BiDIRARTangled (cpc_mode='bert', model.py:219-241) and BiDIRAR (model.py:244-272) on the GRU kernels."""
+    from cpc2_amd.model import BiDIRAR, BiDIRARTangled
+    g = golden("g15_bidirectional_ar.npz")
+    hin, hout, layers, n, t_len = (int(v) for v in g["cfg"])
+    net = (BiDIRARTangled if name == "tangled" else BiDIRAR)(hin, hout, layers)
+    sd = {k[len(name) + 7:]: t(g[k]) for k in g.files if k.startswith(f"{name}_param.")}
+    assert sorted(sd) == sorted(net.state_dict())
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    assert net.getDimOutput() == hout
+    x = synth.features((n, t_len, hin), 131, relu=True).to(DEV).requires_grad_(True)
+    out = net(x)
+    assert_close(out, t(g[f"{name}_out"]), 1e-5, "out")
+    (out * synth.features((n, t_len, hout), 132).to(DEV)).sum().backward()
+    assert_close(x.grad, t(g[f"{name}_dx"]), 1e-4, "dx")
+    for k, p in net.named_parameters():
+        assert_close(p.grad, t(g[f"{name}_grad." + k]), 1e-4, f"grad {k}")

@@ -478,7 +478,29 @@ def g14():
     save("g14_criterion_recurrent_pred.npz", **d)
 
 
+# ------------------------------------------------------------------ G15 bidirectional context networks
+def g15():
+    """BiDIRARTangled (cpc_mode='bert', model.py:219-241) and BiDIRAR (model.py:244-272), forward + backward, with the
+    modules' default initialisation under a fixed torch seed (the state dict is stored)."""
+    d = {}
+    hin, hout, layers, n, t_len = 24, 32, 2, 3, 20
+    for name, cls in (("tangled", ref_model.BiDIRARTangled), ("bidir", ref_model.BiDIRAR)):
+        torch.manual_seed(31)
+        net = cls(hin, hout, layers)
+        x = synth.features((n, t_len, hin), seed=131, relu=True).requires_grad_(True)
+        g = synth.features((n, t_len, hout), seed=132)
+        out = net(x)
+        (out * g).sum().backward()
+        d[f"{name}_out"], d[f"{name}_dx"] = out, x.grad
+        for k, v in net.state_dict().items():
+            d[f"{name}_param." + k] = v
+        for k, v in net.named_parameters():
+            d[f"{name}_grad." + k] = v.grad
+    d["cfg"] = np.array([hin, hout, layers, n, t_len])
+    save("g15_bidirectional_ar.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for name in which:
         globals()[name]()
