@@ -1056,3 +1056,27 @@ def test_bidirectional_context_networks_vs_reference_golden(golden, name):
     assert_close(x.grad, t(g[f"{name}_dx"]), 1e-4, "dx")
     for k, p in net.named_parameters():
         assert_close(p.grad, t(g[f"{name}_grad." + k]), 1e-4, f"grad {k}")
+
+
+def test_full_size_step_is_window_independent():
+    """BASELINE config C2 sizes (H=256, 128 windows of 20480 samples through encoder + GRU): every op up to the criterion is
+    per window, so a window's features must not depend on which other windows share the batch.  Not bit for bit: the last
+    two convolutions have few enough tiles that their GEMMs split K over workgroups (atomic partial sums, a split that
+    depends on the batch); anything leaking between windows would show at the 1e-1 level, rounding stays below 1e-5."""
+    hidden = 256
+    mp = synth.encoder_params(hidden, 31)
+    mp.update(synth.gru_params(hidden, hidden, 1, 32))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+    model.load_state_dict(mp)
+    model = model.to(DEV)
+    x = synth.audio_windows(128, 20480, 33).to(DEV)
+    with torch.no_grad():
+        c_all, z_all, _ = model(x, None)
+        c_lo, z_lo, _ = model(x[:64].contiguous(), None)
+        c_hi, z_hi, _ = model(x[64:].contiguous(), None)
+        c_one, z_one, _ = model(x[77:78].contiguous(), None)
+    assert torch.isfinite(c_all).all() and float(z_all.abs().max()) > 0
+    assert_close(torch.cat([z_lo, z_hi]), z_all, 1e-5, "z, two halves")
+    assert_close(torch.cat([c_lo, c_hi]), c_all, 1e-5, "c, two halves")
+    assert_close(z_one, z_all[77:78], 1e-5, "z, one window")
+    assert_close(c_one, c_all[77:78], 1e-5, "c, one window")
