@@ -91,11 +91,17 @@ struct RowMap {
     // independent of `enabled`: M is made of segments of seg_rows virtual rows of which only the first seg_valid
     // need computing (a sample's trailing junk rows); the split kernels then tile each segment separately
     int seg_rows, seg_valid;
+    // optional: room for the partial products of a K split (few output tiles, long K).  With it the partial sums go to
+    // slabs that a second kernel adds in a fixed order; without it (or when too small) they are added to C with fp32
+    // atomics, in whatever order the workgroups arrive.  Size: gemm_nt_scratch_bytes(M, N, K)
+    void *splitk_scratch;
+    size_t splitk_bytes;
 };
 
 // ---- internal launchers (defined in gemm_f32.hip / rowops.hip) ----
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
             long M, int N, int K, const RowMap &map, hipStream_t st);
+size_t gemm_nt_scratch_bytes(long M, int N, int K);      // upper bound of what RowMap::splitk_scratch can need
 size_t gemm_tn_scratch_bytes(int M, int N, long R);
 // conv_cin > 0: C is a Conv1d weight [M][conv_cin][conv_k] and column j*conv_cin+ci goes to [ci][j]
 int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, long R,

@@ -529,7 +529,8 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
     e.cs = sc.take<float>(colsum_split_scratch_bytes(13 * H) / sizeof(float));
     e.tn_bytes = 0;
     for (int i = 1; i < 5; ++i)
-        e.tn_bytes = std::max(e.tn_bytes, gemm_tn_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]));
+        e.tn_bytes = std::max(e.tn_bytes, std::max(gemm_tn_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]),
+                                                    gemm_nt_scratch_bytes((long)N * e.Rv[i], H, kConv[i].k * H)));   // + forward K split
     e.tn = sc.take<float>(e.tn_bytes / sizeof(float));
     e.scratch_bytes = sc.used();
     return CPC_OK;
@@ -573,6 +574,7 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
         const int k = kConv[i].k, s = kConv[i].s;
         RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk
         vrows.seg_rows = e.Rv[i]; vrows.seg_valid = e.L[i + 1];
+        vrows.splitk_scratch = e.tn; vrows.splitk_bytes = e.tn_bytes;
         CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wf[i], (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
                         k * H, vrows, st));
         NormArgs na{};

@@ -43,6 +43,7 @@ struct GemmNTArgs {
     // segmented rows (x6 kernels): M = segments of seg_rows rows of which the first seg_valid are computed, tiles
     // never straddle a segment (the junk virtual rows of a sample are then never multiplied).  seg_rows = 0: off
     int seg_rows, seg_valid;
+    float *slabs;      // K split with ordered reduction: partial product of blockIdx.y goes to slabs + blockIdx.y * M * N
 };
 
 // acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
@@ -75,12 +76,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[M
                 l = (long)t * p.map.out_stride + p.map.out_off;
                 crow = g * p.map.rows_out + l;
             }
-            float *crowp = p.C + crow * p.ldc;
+            float *crowp = p.slabs != nullptr ? p.slabs + ((long)blockIdx.y * p.M + crow) * p.N : p.C + crow * p.ldc;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (p.map.enabled && (l + jrow[j] < 0 || l + jrow[j] >= p.map.l_max)) continue;
                 if (ncol[j] < p.N) {
-                    if (gridDim.y > 1) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
+                    if (gridDim.y > 1 && p.slabs == nullptr) atomicAdd(&crowp[ncol[j]], acc[i][j][e] + bias_v[j]);
                     else crowp[ncol[j]] = acc[i][j][e] + bias_v[j];
                 }
             }
@@ -372,6 +373,23 @@ template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) voi
     nt_epilogue<MI, NJ>(p, acc, m0, m_end, n0, wm, wn, r32, h);
 }
 
+__global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k);
+
+// few tiles but a long K (e.g. dC = dP . W, K = 12 H): K is split over blockIdx.y
+static int nt_splits(long blocks, int K)
+{
+    if (blocks >= 2 * 256 || K < 8 * BK) return 1;
+    return (int)std::max<long>(1, std::min<long>(cdiv(3 * 256, blocks), K / (4 * BK)));
+}
+
+size_t gemm_nt_scratch_bytes(long M, int N, int K)
+{
+    // whichever tile the launcher picks: 64- or 128-row tiles, 128-column panels
+    const long s1 = nt_splits(cdiv(M, 64) * cdiv(N, 128), K), s2 = nt_splits(cdiv(M, 128) * cdiv(N, 128), K);
+    const long s = std::max(s1, s2);
+    return s > 1 ? align_up(sizeof(float) * (size_t)(s + 1) * M * N, 256) : 0;
+}
+
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
             long M, int N, int K, const RowMap &map, hipStream_t st)
 {
@@ -398,12 +416,16 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     // few tiles but a long K (e.g. dC = dP . W, K = 12 H): split K over blockIdx.y, partial products are
     // atomically added into a zeroed C (dense, unmapped outputs only)
     int splits = 1;
-    if (a.aligned && !map.enabled && ldc == N && blocks < 2 * 256 && K >= 8 * BK)
-        splits = (int)std::min<long>(cdiv(3 * 256, blocks), K / (4 * BK));
+    if (a.aligned && !map.enabled && ldc == N) splits = nt_splits(blocks, K);
     a.kchunk = (int)(cdiv(cdiv(K, splits), BK) * BK);
     splits = (int)cdiv(K, a.kchunk);
-
-    if (splits > 1) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
+    // the partial products go to slabs summed in a fixed order when the caller lent the room, else straight into a zeroed
+    // C with atomics
+    a.slabs = nullptr;
+    if (splits > 1 && map.splitk_scratch != nullptr && map.splitk_bytes >= sizeof(float) * (size_t)splits * M * N &&
+        reinterpret_cast<uintptr_t>(map.splitk_scratch) % 16 == 0 && M <= 2147483647L)
+        a.slabs = static_cast<float *>(map.splitk_scratch);
+    if (splits > 1 && a.slabs == nullptr) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
     dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);
     if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
@@ -413,6 +435,12 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 2>), grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
+    if (a.slabs != nullptr) {
+        const long total = M * N;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, a.slabs,
+                           splits, (int)M, N, C, ldc, 0, 0);
+        CPC_CHECK_LAUNCH("gemm_nt split-K reduce");
+    }
     return CPC_OK;
 }
 

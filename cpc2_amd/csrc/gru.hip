@@ -534,6 +534,8 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     g.comm = sc.take<unsigned long long>(g.comm_bytes / sizeof(unsigned long long));
     g.tn_bytes = std::max(gemm_tn_scratch_bytes(3 * H, H, (long)N * (T + 1)), gemm_tn_scratch_bytes(3 * H, dmax, (long)N * T));
     g.tn_bytes = std::max(g.tn_bytes, gemm_tn_scratch_bytes(3 * H, Din, (long)N * T));
+    // the same room serves an ordered K split of the projections (GI = X W_ih^T, dX = dGI W_ih) when they have few tiles
+    g.tn_bytes = std::max(g.tn_bytes, std::max(gemm_nt_scratch_bytes((long)N * T, 3 * H, dmax), gemm_nt_scratch_bytes((long)N * T, dmax, 3 * H)));
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
     g.scratch_bytes = sc.used();
     return CPC_OK;
@@ -551,6 +553,7 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
     for (int l = 0; l < layers; ++l) {
         const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1], *b_ih = prm[4 * l + 2], *b_hh = prm[4 * l + 3];
         RowMap none{};
+        none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
         CPC_TRY(gemm_nt(xin, din, w_ih, din, g.gi, 3L * H, b_ih, (long)N * T, 3 * H, din, none, st));
         hipLaunchKernelGGL(gru_pack_fwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);
         CPC_CHECK_LAUNCH("gru_pack_fwd_kernel");
@@ -636,6 +639,7 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         if (dxl != nullptr) {
             CPC_TRY(transpose2d(w_ih, g.wt, 3 * H, din, st));                      // [din][3H]
             RowMap none{};
+        none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
             CPC_TRY(gemm_nt(g.dgi, 3L * H, g.wt, 3L * H, dxl, din, nullptr, (long)N * T, din, 3 * H, none, st));
         }
         dcur = dxl;

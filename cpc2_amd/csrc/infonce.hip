@@ -535,7 +535,7 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.hit = sc.take<float>((size_t)b * l.W * K);
     l.dP = sc.take<float>((size_t)b * T * K * Henc);
     l.wt = sc.take<float>((size_t)K * Henc * Har);
-    l.tn_bytes = gemm_tn_scratch_bytes(K * Henc, Har, (long)b * T);
+    l.tn_bytes = std::max(gemm_tn_scratch_bytes(K * Henc, Har, (long)b * T), gemm_nt_scratch_bytes((long)b * T, Har, K * Henc));
     l.tn = sc.take<float>(l.tn_bytes / sizeof(float));
     l.counts = sc.take<int>((size_t)b * T);
     l.offsets = sc.take<int>((size_t)b * T + 1);
@@ -691,6 +691,7 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
     // dc = dP . W  (rows t >= W of dP are zero)
     CPC_TRY(transpose2d(wpred, l.wt, K * Henc, Har, st));                        // [Har][K*Henc]
     RowMap none{};
+    none.splitk_scratch = l.tn; none.splitk_bytes = l.tn_bytes;                  // few tiles, K = 12 H: ordered K split
     CPC_TRY(gemm_nt(l.dP, (long)K * Henc, l.wt, (long)K * Henc, dc, Har, nullptr, (long)b * T, Har, K * Henc, none, st));
     // dW_k[e][a] = sum_{b,t} dP[(b,t)][k*Henc + e] * c[b,t,a]
     CPC_TRY(gemm_tn(l.dP, (long)K * Henc, c, Har, dwpred, Har, K * Henc, Har, (long)b * T, l.tn, l.tn_bytes, 0, 0, st));

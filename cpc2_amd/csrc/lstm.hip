@@ -564,6 +564,8 @@ int lstm_layout(LstmLayout &g, int G, int N, int T, int Din, int H, int layers, 
     g.comm = sc.take<gu64_t>(g.comm_bytes / sizeof(gu64_t));
     g.tn_bytes = std::max(gemm_tn_scratch_bytes(G * H, H, (long)N * (T + 1)), gemm_tn_scratch_bytes(G * H, dmax, (long)N * T));
     g.tn_bytes = std::max(g.tn_bytes, gemm_tn_scratch_bytes(G * H, Din, (long)N * T));
+    // the same room serves an ordered K split of the projections when they have few tiles
+    g.tn_bytes = std::max(g.tn_bytes, std::max(gemm_nt_scratch_bytes((long)N * T, G * H, dmax), gemm_nt_scratch_bytes((long)N * T, dmax, G * H)));
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
     g.scratch_bytes = sc.used();
     return CPC_OK;
@@ -600,6 +602,7 @@ static int lstm_forward(const float *x, const float *const *prm, const float *h0
     for (int l = 0; l < layers; ++l) {
         const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1], *b_ih = prm[4 * l + 2], *b_hh = prm[4 * l + 3];
         RowMap none{};
+        none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
         CPC_TRY(gemm_nt(xin, din, w_ih, din, g.gi, (long)G * H, b_ih, (long)N * T, G * H, din, none, st));
         LstmArgs a{};
         a.gi = g.gi; a.wpack = g.wpack; a.whh = w_hh; a.bhh = b_hh;
@@ -683,6 +686,7 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         if (dxl != nullptr) {
             CPC_TRY(transpose2d(w_ih, g.wt, GH, din, st));                         // [din][G*H]
             RowMap none{};
+        none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
             CPC_TRY(gemm_nt(g.dgi, GH, g.wt, GH, dxl, din, nullptr, (long)N * T, din, GH, none, st));
         }
         dcur = dxl;

@@ -860,6 +860,8 @@ static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int lay
     L.cs = sc.take<float>(colsum_rows_scratch_bytes(std::max(TR_DFF, nc * D)) / sizeof(float));
     L.tn_bytes = std::max(gemm_tn_scratch_bytes(TR_DFF, dmax, L.rows), gemm_tn_scratch_bytes(dmax * nc, TR_DFF, L.rows));
     L.tn_bytes = std::max(L.tn_bytes, gemm_tn_scratch_bytes(dmax, dmax, L.rows * nc));
+    // the same room serves an ordered K split of the layer's products when they have few tiles
+    L.tn_bytes = std::max(L.tn_bytes, std::max(gemm_nt_scratch_bytes(L.rows * nc, dmax, TR_DFF), gemm_nt_scratch_bytes(L.rows, dmax, 3 * dmax)));
     L.tn = sc.take<float>(L.tn_bytes / sizeof(float));
     L.scratch_bytes = sc.used();
     const size_t ldk = L.dk + 1, ldp = SS + 1;
@@ -913,6 +915,7 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
     const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thresh = drop_thresh(p_drop);
     RowMap none{};
+    none.splitk_scratch = L.tn; none.splitk_bytes = L.tn_bytes;
     const float *xin = x;
     for (int l = 0; l < layers; ++l) {
         const float *const *p = prm + (size_t)l * P_COUNT;
@@ -966,6 +969,7 @@ static int transformer_backward(const float *x, const float *const *prm, const f
     const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thresh = drop_thresh(p_drop);
     RowMap none{};
+    none.splitk_scratch = L.tn; none.splitk_bytes = L.tn_bytes;
     const float *dcur = dout;
     for (int l = layers - 1; l >= 0; --l) {
         const float *const *p = prm + (size_t)l * P_COUNT;

@@ -61,6 +61,8 @@ int cpc_prof_read(const char *name, double *total_ms, long *count);
  * exact three-term bf16 split of every operand (six partial products, error <= that of the f32
  * MFMA path, tests/test_gpu_parity.py::test_gemm_split_accuracy); mode 1 uses the f32 MFMA
  * (v_mfma_f32_32x32x2_f32).  cpc_gemm_set_mode returns the previous mode; other values only query.
+ * cpc_gemm_nt splits K over workgroups when the output has few tiles and then adds the partial sums with
+ * fp32 atomics (C is zeroed first); the module entry points below lend scratch for an ordered reduction instead.
  * ------------------------------------------------------------------------------------------ */
 int cpc_gemm_set_mode(int mode);
 int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,

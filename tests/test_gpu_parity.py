@@ -1080,3 +1080,30 @@ def test_full_size_step_is_window_independent():
     assert_close(torch.cat([c_lo, c_hi]), c_all, 1e-5, "c, two halves")
     assert_close(z_one, z_all[77:78], 1e-5, "z, one window")
     assert_close(c_one, c_all[77:78], 1e-5, "c, one window")
+
+
+def test_training_steps_are_reproducible_bit_for_bit():
+    """No fp32 atomics are left on the step's path (criterion dz from sorted lists, K splits reduced in a fixed order):
+    the same seeds give the same parameters after three steps, bit for bit -- at a small size where the K splits and the
+    streaming recurrent kernels are used, and at a size that takes the cooperative GRU."""
+    for hidden, b, t_windows in ((64, 3, 20480), (256, 8, 20480)):
+        finals = []
+        for _run in range(2):
+            mp = synth.encoder_params(hidden, 21)
+            mp.update(synth.gru_params(hidden, hidden, 1, 22))
+            model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+            model.load_state_dict(mp)
+            crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 16, rnnMode="linear", sizeInputSeq=128)
+            crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 23))
+            model, crit = model.to(DEV), crit.to(DEV)
+            opt = buildOptimizer(model, crit, lr=2e-4)
+            crit.seed(5)
+            x = synth.audio_windows(b, t_windows, 24).to(DEV)
+            label = torch.zeros(b, dtype=torch.long, device=DEV)
+            for _ in range(3):
+                tot, _losses, _acc = cpcStep(x, x, label, model, crit)
+                tot.backward()
+                opt.step()
+                opt.zero_grad()
+            finals.append(opt.flat.detach().clone())
+        assert torch.equal(finals[0], finals[1]), f"hidden {hidden}: parameters differ between two identical runs"
