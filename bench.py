@@ -275,7 +275,7 @@ def main():
                                             f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s",
                                # HBM bytes per launch from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE KiB, mean over
                                # the step's 15 launches: profiles/r01_v4_pmc_summary.md), valid for the default workload only
-                               "traffic": 3.47e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
+                               "traffic": 2.60e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
                                "algorithmic_gflop_per_launch": round(flops / max(k["launches_per_step"], 1.0) / 1e9, 3),
                                "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
         out["kernels"] = kernels

@@ -44,6 +44,7 @@ struct GemmNTArgs {
     // never straddle a segment (the junk virtual rows of a sample are then never multiplied).  seg_rows = 0: off
     int seg_rows, seg_valid;
     float *slabs;      // K split with ordered reduction: partial product of blockIdx.y goes to slabs + blockIdx.y * M * N
+    int xcd_remap;     // split kernels: column panels of a row tile on one XCD (row tile count % 8 == 0, several panels)
 };
 
 // acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
@@ -276,8 +277,15 @@ template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) voi
     const int r32 = lane & 31, h = lane >> 5;
 
     const int tiles_n = (p.N + BNX - 1) / BNX;
-    const long mt = blockIdx.x / tiles_n;
-    const int n0 = (int)(blockIdx.x % tiles_n) * BNX;
+    long mt = blockIdx.x / tiles_n;
+    int n0 = (int)(blockIdx.x % tiles_n) * BNX;
+    if (p.xcd_remap) {
+        // workgroups go to the 8 XCDs round robin: give the column panels of one row tile to ONE XCD, back to back, so that
+        // the A rows they share are fetched into one L2 once instead of into tiles_n of them
+        const long j = blockIdx.x >> 3;
+        mt = (j / tiles_n) * 8 + (blockIdx.x & 7);
+        n0 = (int)(j % tiles_n) * BNX;
+    }
     long m0 = mt * BM, m_end = p.M;
     if (p.seg_rows > 0) {
         const int tps = (p.seg_valid + BM - 1) / BM;       // tiles per segment
@@ -419,6 +427,8 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     if (a.aligned && !map.enabled && ldc == N) splits = nt_splits(blocks, K);
     a.kchunk = (int)(cdiv(cdiv(K, splits), BK) * BK);
     splits = (int)cdiv(K, a.kchunk);
+    static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
+    a.xcd_remap = (split_kernels && !no_remap && cdiv(N, 64 * nj) > 1 && m_tiles(64 * mi) % 8 == 0) ? 1 : 0;
     // the partial products go to slabs summed in a fixed order when the caller lent the room, else straight into a zeroed
     // C with atomics
     a.slabs = nullptr;
@@ -452,6 +462,7 @@ struct GemmTNArgs {
     int M, N;
     long R, chunk;     // rows per split (multiple of BK)
     int aligned;
+    int xcd_remap;     // split kernel: all tiles of a row slab on one XCD (slab count % 8 == 0)
 };
 
 template <bool ALIGNED> __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p)
@@ -579,9 +590,19 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_x6_kernel(GemmTNArgs p)
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int i0 = blockIdx.y * BM;
-    const int j0 = blockIdx.x * BN;
-    const long rbeg = (long)blockIdx.z * p.chunk;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        // workgroups go to the 8 XCDs round robin in dispatch order (x fastest): give ALL tiles of one row slab to one XCD,
+        // so that the slab's A and B rows are fetched into one L2 instead of into eight
+        const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned tiles = gridDim.x * gridDim.y, j = b >> 3, tile = j % tiles;
+        bz = (int)((j / tiles) * 8 + (b & 7));
+        by = (int)(tile / gridDim.x);
+        bx = (int)(tile % gridDim.x);
+    }
+    const int i0 = by * BM;
+    const int j0 = bx * BN;
+    const long rbeg = (long)bz * p.chunk;
     long rend = rbeg + p.chunk;
     if (rend > p.R) rend = p.R;
 
@@ -662,7 +683,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_x6_kernel(GemmTNArgs p)
     }
 
     // slab[z][i][j]: i = i0 + wm*64 + it*32 + (e&3) + 8*(e>>2) + 4h ; j = j0 + wn*64 + jt*32 + r32
-    float *slab = p.slab + (long)blockIdx.z * p.M * p.N;
+    float *slab = p.slab + (long)bz * p.M * p.N;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -730,6 +751,8 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
     a.aligned = (M % 4 == 0) && (N % 4 == 0) && (M >= 4) && (N >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
     dim3 grid((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM), (unsigned)S);
+    static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
+    a.xcd_remap = (!no_remap && S % 8 == 0 && grid.x * grid.y > 1) ? 1 : 0;
     ProfScope prof(PROF_GEMM_TN, st);
     const bool native = g_gemm_mode == 1;
     if (a.aligned && !native) hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, dim3(256), 0, st, a);
