@@ -213,3 +213,47 @@ def test_lr_schedules_follow_the_reference(tag, step, ramp, done):
             opt.step()
             sched.step()
     assert np.allclose(lrs, ref, rtol=1e-12, atol=0)
+
+
+# ----------------------------------------------------------------------------- sampler: random shapes (criterion.py:247-266)
+def test_sampler_matches_torch_randint_on_random_shapes():
+    """Property test over ragged shapes: the native MT19937 sampler reproduces, bit for bit, the index arithmetic of
+    sampleClean run on torch's own CPU generator -- and the oracle's restatement does too -- for any (b, T, K, Nneg),
+    both index layouts, two consecutive steps on one stream."""
+    import numpy as np
+    import torch
+    from hypothesis import given, settings, strategies as st
+    from oracle.mt19937 import MT19937, negative_indices
+
+    @settings(max_examples=40, deadline=None)
+    @given(b=st.integers(1, 9), t_len=st.integers(3, 70), k_frac=st.floats(0.05, 0.9), nn=st.integers(1, 17),
+           seed=st.integers(0, 2 ** 31 - 1))
+    def check(b, t_len, k_frac, nn, seed):
+        k = min(t_len - 2, max(1, int(k_frac * t_len)))
+        w = t_len - k
+        n = b * nn * w
+        s = cpc2_amd.criterion.NegativeSampler()
+        s.seed(seed)
+        mt = MT19937(seed)
+        torch.manual_seed(seed)
+        for _step in range(2):
+            batch_idx = torch.randint(low=0, high=b, size=(n,))                       # criterion.py:247-251
+            seq_idx = torch.randint(low=1, high=t_len, size=(n,))                     # :254-256
+            base = torch.arange(0, w).expand(b, nn, w).contiguous().view(-1)          # :258-262
+            ref = torch.remainder(seq_idx + base, t_len) + batch_idx * t_len          # :264-266
+            ext, bi, si = s.sample_host(b, t_len, w, nn, want_parts=True, time_major=False)
+            assert np.array_equal(bi.numpy(), batch_idx.numpy()) and np.array_equal(si.numpy(), seq_idx.numpy())
+            assert np.array_equal(ext.numpy().astype(np.int64), ref.numpy())
+            o_bi, o_si, o_ext = negative_indices(mt, b, t_len, w, nn)
+            assert np.array_equal(np.asarray(o_ext, dtype=np.int64), ref.numpy())
+        # the kernels' time-major layout holds the same indices, negatives of one (b, t) contiguous
+        s.seed(seed)
+        tm = s.sample_host(b, t_len, w, nn, time_major=True).numpy().astype(np.int64)
+        torch.manual_seed(seed)
+        batch_idx = torch.randint(low=0, high=b, size=(n,))
+        seq_idx = torch.randint(low=1, high=t_len, size=(n,))
+        base = torch.arange(0, w).expand(b, nn, w).contiguous().view(-1)
+        ref = (torch.remainder(seq_idx + base, t_len) + batch_idx * t_len).view(b, nn, w)
+        assert np.array_equal(tm.reshape(b, w, nn), ref.permute(0, 2, 1).numpy())
+
+    check()
