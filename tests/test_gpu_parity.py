@@ -415,6 +415,32 @@ def test_criterion_full_shape_vs_reference_golden(golden):
         assert_close(w[:4, :8], t(g[f"dW{i}_head"]), 2e-4, f"dW{i} head")
 
 
+@pytest.mark.parametrize("b,t_len,har,henc,k,nn", [(1, 14, 32, 32, 1, 1), (3, 20, 32, 64, 5, 3), (2, 40, 64, 32, 16, 17),
+                                                   (5, 33, 128, 128, 7, 129), (2, 64, 32, 512, 12, 40), (9, 17, 24, 32, 3, 250)])
+def test_criterion_odd_shapes_vs_oracle_fp64(b, t_len, har, henc, k, nn):
+    """Shapes off every tile size of the criterion kernels (candidate tiles of 16 / 32, 16 prediction rows, lane groups):
+    one window, one step, one negative, more negatives than a tile, all supported encoder widths -- vs the fp64 oracle."""
+    crit = make_criterion(k, har, henc, nn, 200 + k, scale=3.0)
+    cp = synth.predictor_params(k, har, henc, seed=200 + k, scale=3.0)
+    c = synth.features((b, t_len, har), 201)
+    z = synth.features((b, t_len, henc), 202, relu=True)
+    cd, zd = c.to(DEV).requires_grad_(True), z.to(DEV).requires_grad_(True)
+    crit.seed(77)
+    losses, acc = crit(cd, zd, None)
+    losses.sum().backward()
+    p64 = {n: v.double().requires_grad_(True) for n, v in cp.items()}
+    c64, z64 = c.double().requires_grad_(True), z.double().requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(77), b, t_len, t_len - k, nn)
+    ref_losses, ref_acc = O.criterion_forward(c64, z64, O.predictor_list(p64, k), ext, nn)
+    ref_losses.sum().backward()
+    assert_close(losses, ref_losses, 1e-5, "losses")
+    assert torch.allclose(acc.cpu().double(), ref_acc, atol=2.5 / (b * (t_len - k)))     # a float tie may flip an argmax
+    assert_close(cd.grad, c64.grad, 1e-4, "dc")
+    assert_close(zd.grad, z64.grad, 1e-4, "dz")
+    for i in range(k):
+        assert_close(crit.wPrediction.predictors[i].weight.grad, p64[f"wPrediction.predictors.{i}.weight"].grad, 2e-4, f"dW{i}")
+
+
 def test_criterion_transformer_predictors_vs_reference_golden(golden):
     """rnnMode='transformer' (the fork's default predictors, criterion.py:136-143), eval mode."""
     g = golden("g8_criterion_transformer_pred.npz")
@@ -523,6 +549,23 @@ def test_criterion_indices_on_device_are_bit_exact(golden):
     torch.manual_seed(seed)                     # kernel layout: same values, [b, W, n_neg]
     ext_tm = crit.sampleIndices(b, t_len, t_len - k, torch.device(DEV)).cpu().numpy().astype(np.int64)
     assert np.array_equal(ext_tm.reshape(b, t_len - k, nn), g["mid_extIdx"].reshape(b, nn, t_len - k).transpose(0, 2, 1))
+
+
+def test_device_index_expansion_on_ragged_shapes():
+    """The device half of the sampler (raw words -> indices) against the host sampler on odd shapes, incl. one window,
+    one negative, a window as long as the sequence minus one, and the large-config sizes."""
+    rs = np.random.RandomState(3)
+    shapes = [(1, 3, 1, 1), (2, 5, 4, 1), (7, 33, 20, 5), (3, 128, 127, 9), (64, 128, 116, 256)]
+    shapes += [(int(rs.randint(1, 12)), int(t), int(rs.randint(1, t)), int(rs.randint(1, 40))) for t in rs.randint(3, 200, size=6)]
+    for b, t_len, w, nn in shapes:
+        host, dev = cpc2_amd.criterion.NegativeSampler(), cpc2_amd.criterion.NegativeSampler()
+        host.seed(b * 1000 + w)
+        dev.seed(b * 1000 + w)
+        for _ in range(2):
+            want = host.sample_host(b, t_len, w, nn, time_major=True)
+            got = dev.sample(b, t_len, w, nn, torch.device(DEV)).cpu()
+            assert torch.equal(got, want), (b, t_len, w, nn)
+            assert int(got.min()) >= 0 and int(got.max()) < b * t_len
 
 
 def test_device_index_expansion_and_prefetch_are_bit_exact():
