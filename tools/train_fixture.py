@@ -31,7 +31,7 @@ random.seed(0)
 np.random.seed(0)
 dev = torch.device("cuda:0")
 seqs, speakers = findAllSeqs(DB, extension=".flac")
-seqs = filterSeqs(SEQS, seqs)
+seqs = sorted(filterSeqs(SEQS, seqs), key=lambda sq: sq[1])          # os.walk order differs from box to box
 data = AudioBatchData(DB, args.sizeWindow, seqs, None, len(speakers), device=dev)
 model = cpc2_amd.CPCModel(getEncoder(args), getAR(args)).to(dev)
 crit = getCriterion(args, model.gEncoder.DOWNSAMPLING).to(dev)
@@ -42,7 +42,7 @@ ckpt = os.path.join(out_dir, "checkpoint")
 with open(ckpt + "_args.json", "w") as fh:
     json.dump(vars(args), fh, indent=2)
 logs = {"epoch": [], "iter": [], "saveStep": max(1, epochs // 2), "logging_step": 10 ** 9}
-print(f"{len(seqs)} sequences, {len(data)} samples = {len(data) / 16000:.0f} s of audio, {len(speakers)} speakers; checkpoints in {out_dir}")
+print(f"{len(seqs)} sequences, {len(data)} windows = {len(data) * 1.28:.0f} s of audio, {len(speakers)} speakers; checkpoints in {out_dir}")
 run(data, data, 8, args.samplingType, model, crit, epochs, ckpt, opt, sched, logs)
 for e in logs["epoch"]:
     print(f"epoch {e:3d}: train loss {np.mean(logs['locLoss_train'][e]):.4f} acc {np.mean(logs['locAcc_train'][e]):.4f} | "
