@@ -9,7 +9,8 @@ the flat vector lives in HBM (288 GB: the reference's 4e9-sample pack is 16 GB) 
 by one gather kernel (cpc_window_gather); the host only produces b int64 offsets per step.  Files are decoded
 by the library's own FLAC / WAV readers (cpc2_amd/audio.py).
 
-Not on this path: data augmentation (sox / WavAugment), phone labels, signal-quality side files.
+Signal-quality side files (per-file snr / c50 estimates, dataset.py:69-77,106-120,257-281) are read too and come out as
+the third element of a batch.  Not on this path: data augmentation (sox / WavAugment), phone labels.
 Without augmentation the reference yields past == future (dataset.py:308-321): batches are returned as an
 expanded [b, 2, 1, W] view whose two halves alias, which cpcStep(dedup=True) can exploit.
 """
@@ -107,8 +108,8 @@ class AudioBatchData:
                  MAX_SIZE_LOADED=4000000000, transform=None, augment_past=False, augment_future=False,
                  augmentation=None, keep_temporality=True, past_equal_future=False, signal_quality_path=None,
                  signal_quality_step=1600, signal_quality_mode=None, device=None):
-        if phoneLabelsDict is not None or signal_quality_path is not None:
-            raise NotImplementedError("phone labels / signal-quality files are not on the MI355X feeder path")
+        if phoneLabelsDict is not None:
+            raise NotImplementedError("phone labels are not on the MI355X feeder path")
         if transform is not None or augment_past or augment_future or augmentation is not None:
             raise NotImplementedError("audio augmentation is not on the MI355X feeder path")
         self.MAX_SIZE_LOADED = MAX_SIZE_LOADED
@@ -121,9 +122,37 @@ class AudioBatchData:
             torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.doubleLabels = False
         self.phoneSize = 0
+        # signal-quality estimates (dataset.py:69-77,106-120): one .pt per audio file under signal_quality_path (a list of
+        # tensors that concatenate along dim 1 to [frames, 2] = (snr, c50), one frame per signal_quality_step samples) and
+        # min_max.csv with the normalisation bounds
+        self.signal_quality_path = Path(signal_quality_path) if signal_quality_path is not None else None
+        self.signal_quality_step = signal_quality_step
+        self.signal_quality_size = sizeWindow // signal_quality_step
+        self.signal_quality_mode = signal_quality_mode
+        self.data_quality = None
+        if self.signal_quality_path is not None:
+            self._init_min_max_signal_quality()
         self.prepare()
         self.loadNextPack(first=True)
         self.loadNextPack()
+
+    def _init_min_max_signal_quality(self):
+        import csv
+        file_path = self.signal_quality_path / "min_max.csv"
+        if not file_path.is_file():
+            raise FileNotFoundError("Can not find file containing min/max values of snr and c50 under: %s" % file_path)
+        with open(file_path, "r") as fin:
+            reader = csv.reader(fin)
+            bounds = dict(zip(next(reader), next(reader)))
+        try:
+            self.min_snr, self.max_snr = float(bounds["min_snr"]), float(bounds["max_snr"])
+            self.min_c50, self.max_c50 = float(bounds["min_c50"]), float(bounds["max_c50"])
+        except (KeyError, ValueError):
+            raise ValueError("min_max.csv should contain the following keys: min_snr, max_snr, min_c50, max_c50.")
+
+    def _quality_file(self, audio_path):
+        rel = os.path.relpath(str(audio_path), str(self.dbPath))
+        return self.signal_quality_path / (os.path.splitext(rel)[0] + ".pt")       # dataset.py:166-168
 
     # ---- pack bookkeeping (dataset.py:147-223)
     def prepare(self):
@@ -161,7 +190,11 @@ class AudioBatchData:
         items = []
         for speaker, p in self.seqNames[start:end]:
             wav = audio.load(p)[0].mean(dim=0)              # dataset.py:425: mono mix
-            items.append((speaker, os.path.splitext(os.path.basename(str(p)))[0], wav))
+            item = (speaker, os.path.splitext(os.path.basename(str(p)))[0], wav)
+            if self.signal_quality_path is not None:        # dataset.py:427-430: the audio is cut to whole quality frames
+                quality = torch.cat(torch.load(self._quality_file(p)), dim=1).float()
+                item = item[:2] + (wav[:quality.shape[0] * self.signal_quality_step], quality)
+            items.append(item)
         return items
 
     def loadNextPack(self, first=False):
@@ -179,22 +212,36 @@ class AudioBatchData:
         self.speakerLabel, self.seqLabel = [0], [0]
         speakerSize, indexSpeaker = 0, 0
         nextData.sort(key=lambda x: (x[0], x[1]))
-        chunks = []
-        for speaker, _name, seq in nextData:
+        chunks, quality = [], []
+        for speaker, _name, seq, *seq_quality in nextData:
             while self.speakers[indexSpeaker] < speaker:
                 indexSpeaker += 1
                 self.speakerLabel.append(speakerSize)
             if self.speakers[indexSpeaker] != speaker:
                 raise ValueError(f'{speaker} invalid speaker')
             chunks.append(seq)
+            quality += seq_quality
             self.seqLabel.append(self.seqLabel[-1] + seq.size(0))
             speakerSize += seq.size(0)
         self.speakerLabel.append(speakerSize)
         self.data = torch.cat(chunks, dim=0).to(self.device)     # ONE flat vector, resident on the device
+        if quality:                                              # dataset.py:257-265: min-max normalised, third column = mean
+            q = torch.cat(quality, dim=0)
+            q[:, 0] = (q[:, 0] - self.min_snr) / (self.max_snr - self.min_snr)
+            q[:, 1] = (q[:, 1] - self.min_c50) / (self.max_c50 - self.min_c50)
+            self.data_quality = torch.cat((q, torch.mean(q, dim=1).view(-1, 1)), dim=1).to(self.device)
 
     # ---- accessors
     def getSpeakerLabel(self, idx):
         return next(i for i, v in enumerate(self.speakerLabel) if v > idx) - 1
+
+    def getSignalQuality(self, idx):
+        """dataset.py:271-281: the window's signal_quality_size estimates of the selected kind."""
+        column = {"snr": 0, "c50": 1, "snr_c50": 2}.get(self.signal_quality_mode)
+        if column is None:
+            raise ValueError("--signal_quality_mode should be in ['snr', 'c50', 'snr_c50'].")
+        first = idx // self.signal_quality_step
+        return self.data_quality[first:first + self.signal_quality_size, column]
 
     def __len__(self):
         return self.totSize // self.sizeWindow
@@ -272,6 +319,9 @@ class _AudioLoader:
                 if not batch:
                     continue
                 label = torch.tensor([d.getSpeakerLabel(o) for o in batch], dtype=torch.long, device=d.device)
-                yield d.windows(batch), label
+                if d.signal_quality_path is not None:        # dataset.py:327-330: a third element per sample
+                    yield d.windows(batch), label, torch.stack([d.getSignalQuality(o) for o in batch])
+                else:
+                    yield d.windows(batch), label
             if loop + 1 < self.nLoops or len(d.packageIndex) > 1:
                 d.loadNextPack()

@@ -100,3 +100,46 @@ def test_other_samplers_yield_valid_windows():
     # a window is a verbatim slice of the flat vector
     w = data.windows([12345])
     assert torch.equal(w[0, 0, 0], flat[12345:12345 + 20480])
+
+
+def test_signal_quality_side_files(tmp_path):
+    """dataset.py:69-77,106-120,166-168,257-281,327-330: per-file estimates (snr, c50) every signal_quality_step samples,
+    min-max normalised with min_max.csv, a third column with their mean, the audio cut to whole estimate frames, and one
+    [signal_quality_size] slice per window as a third element of every batch."""
+    seq_names, _ = _filtered()
+    step, window = 1600, 20480
+    truth = {}
+    for i, (_spk, rel) in enumerate(seq_names):
+        frames = audio.info(DB / rel)[2] // step - (i % 2)             # some files carry fewer estimate frames than audio
+        snr = torch.linspace(-5.0, 30.0, frames) + i
+        c50 = torch.linspace(60.0, 0.0, frames) - i
+        out = tmp_path / (os.path.splitext(rel)[0] + ".pt")
+        out.parent.mkdir(parents=True, exist_ok=True)
+        torch.save([snr.view(-1, 1), c50.view(-1, 1)], out)          # a list that concatenates along dim 1
+        truth[os.path.splitext(os.path.basename(rel))[0]] = (snr, c50)
+    with open(tmp_path / "min_max.csv", "w") as fh:
+        fh.write("min_snr,max_snr,min_c50,max_c50\n-10,40,-10,70\n")
+    for mode, column in (("snr", 0), ("c50", 1), ("snr_c50", 2)):
+        data = AudioBatchData(DB, window, seq_names, None, 9, device="cpu", signal_quality_path=tmp_path,
+                              signal_quality_step=step, signal_quality_mode=mode)
+        assert data.signal_quality_size == 12
+        # the flat audio holds whole estimate frames only, and as many frames as the quality table
+        assert data.data.numel() == data.data_quality.shape[0] * step and data.data_quality.shape[1] == 3
+        assert torch.allclose(data.data_quality[:, 2], data.data_quality[:, :2].mean(dim=1))
+        batches = list(data.getDataLoader(4, "sequential", False))
+        assert batches and all(len(bt) == 3 for bt in batches)
+        seq, label, quality = batches[0]
+        assert seq.shape == (4, 2, 1, window) and quality.shape == (4, 12) and quality.dtype == torch.float32
+        # first window of the flat vector = start of the first sequence in (speaker, name) order
+        first = sorted(seq_names, key=lambda x: (x[0], os.path.basename(x[1])))[0][1]
+        snr, c50 = truth[os.path.splitext(os.path.basename(first))[0]]
+        n_snr, n_c50 = (snr[:12] + 10) / 50, (c50[:12] + 10) / 80
+        want = (n_snr, n_c50, (n_snr + n_c50) / 2)[column]
+        assert torch.allclose(quality[0], want, atol=1e-6)
+    # errors of the reference
+    import pytest
+    with pytest.raises(ValueError):
+        AudioBatchData(DB, window, seq_names, None, 9, device="cpu", signal_quality_path=tmp_path,
+                       signal_quality_mode="loudness").getSignalQuality(0)
+    with pytest.raises(FileNotFoundError):
+        AudioBatchData(DB, window, seq_names, None, 9, device="cpu", signal_quality_path=tmp_path / "nowhere")

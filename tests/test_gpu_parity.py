@@ -1150,3 +1150,39 @@ def test_training_steps_are_reproducible_bit_for_bit():
                 opt.zero_grad()
             finals.append(opt.flat.detach().clone())
         assert torch.equal(finals[0], finals[1]), f"hidden {hidden}: parameters differ between two identical runs"
+
+
+def test_train_step_with_signal_quality_files(tmp_path):
+    """The feeder's third batch element (dataset.py:327-330) reaches the criterion's quality weighting
+    (train.py:88-94,107; criterion.py:230,334-338): an epoch of trainStep on the fixture with generated estimate files."""
+    import random
+    from cpc2_amd import audio
+    from cpc2_amd.dataset import AudioBatchData, filterSeqs, findAllSeqs
+    from cpc2_amd.train import trainStep
+    seq_names, speakers = findAllSeqs(GOLD_DB, extension=".flac")
+    seq_names = filterSeqs(SEQ_LIST, seq_names)
+    for i, (_spk, rel) in enumerate(seq_names):
+        frames = audio.info(os.path.join(GOLD_DB, rel))[2] // 1600
+        out = tmp_path / (os.path.splitext(rel)[0] + ".pt")
+        out.parent.mkdir(parents=True, exist_ok=True)
+        torch.save([torch.linspace(0.0, 30.0, frames).view(-1, 1), torch.linspace(50.0, 5.0, frames).view(-1, 1)], out)
+    (tmp_path / "min_max.csv").write_text("min_snr,max_snr,min_c50,max_c50\n0,30,0,60\n")
+    random.seed(0)
+    data = AudioBatchData(GOLD_DB, 20480, seq_names, None, len(speakers), device=DEV, signal_quality_path=tmp_path,
+                          signal_quality_mode="snr_c50")
+    model, _ = _small_model(64)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, 64, 64, 32, rnnMode="linear", sizeInputSeq=128, growth_rate=2.0,
+                                             inflection_point_x=0.4).to(DEV)
+    crit.seed(3)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    loader = data.getDataLoader(8, "uniform", True)
+    seq, label, quality = next(iter(loader))
+    assert quality.is_cuda and quality.shape == (8, 12) and 0.0 <= float(quality.min()) and float(quality.max()) <= 1.0
+    # weighted loss = weights (criterion.py:230) times the unweighted per-position losses, checked on one batch
+    crit.seed(3)
+    weighted, _ = crit(*model(seq[:, 0], label)[:2], label, quality)
+    crit.seed(3)
+    plain, _ = crit(*model(seq[:, 0], label)[:2], label, None)
+    assert not torch.allclose(weighted, plain)
+    logs = trainStep(loader, model, crit, opt, None, 1000)
+    assert logs["iter"] >= 5 and np.isfinite(logs["locLoss_train"]).all()
