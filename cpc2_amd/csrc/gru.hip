@@ -327,10 +327,10 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     const int idx = tid + 512 * i;
-                    hs[nxt][idx / H][coop_pad(idx % H)] = __uint_as_float((unsigned)x[i]);
+                    hs[nxt][idx / H][coop_pad(idx % H)] = dead ? NAN : __uint_as_float((unsigned)x[i]);
                 }
             }
-            dead = __syncthreads_or(dead);
+            __syncthreads();            // `dead` stays with the thread that timed out: what it gathered is poisoned above
         }
     }
     if (a.hlast != nullptr && q < NB && n0 + q < a.N)
@@ -469,9 +469,10 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
                 }
 #pragma unroll
                 for (int d = 0; d < G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
-                carry = sum;
+                carry = dead ? NAN : sum;
             }
-            dead = __syncthreads_or(dead);
+            // no barrier here: dgs is rewritten before the next step's first barrier, part after it, and every thread has
+            // finished reading both when it gets there; `dead` stays with the thread that timed out (its carry is poisoned)
         }
     }
 }
