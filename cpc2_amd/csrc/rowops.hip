@@ -33,7 +33,8 @@ static const char *kProfNames[PROF_SLOTS] = {"gemm_nt", "gemm_tn", "infonce_fwd"
 
 ProfScope::ProfScope(int slot, hipStream_t st) : slot_(slot), st_(st), active_(false)
 {
-    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    const int on = g_prof_on.load(std::memory_order_relaxed);
+    if (on == 0 || (on == 2 && slot != PROF_GEMM_NT)) return;
     if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) return;
     active_ = hipEventRecord(a_, st_) == hipSuccess;
 }
@@ -301,7 +302,7 @@ extern "C" int cpc_version(void) { return 100; }
 
 extern "C" int cpc_prof_enable(int on)
 {
-    cpc::g_prof_on.store(on ? 1 : 0);
+    cpc::g_prof_on.store(on == 2 ? 2 : (on ? 1 : 0));
     return CPC_OK;
 }
 
