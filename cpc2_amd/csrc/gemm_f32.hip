@@ -417,8 +417,15 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     // 256-column panels and the grid still fills the chip twice over; else 128 x 128 (three per CU); 64 x 128 when
     // even that leaves CUs with fewer than two workgroups
     int mi = 2, nj = 2;
-    if (split_kernels && N % 256 == 0 && m_tiles(128) * (N / 256) >= 2 * 256) nj = 4;
-    else if (a.aligned && m_tiles(128) * cdiv(N, BN) < 2 * 256) mi = 1;
+    if (split_kernels && N % 256 == 0 && m_tiles(128) * (N / 256) >= 2 * 256) {
+        // ... unless the 128 x 128 tiling fills its rounds so much better that it wins anyway (e.g. the predictor product,
+        // 768 tiles on 512 places = two rounds at 75 %, against 1536 on 768 = two full rounds).  Measured full-grid rates:
+        // 165 (128 x 256) against 150 (128 x 128) TFLOP/s; with ONE column panel the wide tile also reads A once.
+        auto fill = [](long blocks, long places) { return (double)blocks / (double)(cdiv(blocks, places) * places); };
+        const double wide = 165.0 * fill(m_tiles(128) * (N / 256), 2 * 256), narrow = 150.0 * fill(m_tiles(128) * (N / 128), 3 * 256);
+        static const bool wide_always = getenv("CPC_GEMM_WIDE_ALWAYS") != nullptr;        // A/B switch
+        nj = (N == 256 || wide >= narrow || wide_always) ? 4 : 2;
+    } else if (a.aligned && m_tiles(128) * cdiv(N, BN) < 2 * 256) mi = 1;
     const long blocks = m_tiles(64 * mi) * cdiv(N, 64 * nj);
     CPC_REQUIRE(blocks <= 2147483647L, "gemm_nt: grid too large (%ld blocks)", blocks);
     // few tiles but a long K (e.g. dC = dP . W, K = 12 H): split K over blockIdx.y, partial products are
