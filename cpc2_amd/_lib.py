@@ -28,6 +28,11 @@ SIGNATURES = {
     "cpc_gemm_nt": (c_int, [c_ptr, c_long, c_ptr, c_long, c_ptr, c_long, c_ptr, c_int, c_int, c_int, c_ptr]),
     "cpc_gemm_tn_scratch_bytes": (c_size_t, [c_int, c_int, c_long]),
     "cpc_gemm_tn": (c_int, [c_ptr, c_long, c_ptr, c_long, c_ptr, c_long, c_int, c_int, c_long, c_ptr, c_size_t, c_ptr]),
+    "cpc_split_planes": (c_int, [c_ptr, c_long, c_long, c_int, c_ptr, c_long, c_int, c_long, c_ptr]),
+    "cpc_gemm_nt_planes": (c_int, [c_ptr, c_long, c_int, c_int, c_long, c_int, c_long, c_ptr, c_long, c_ptr, c_long, c_ptr, c_long, c_int, c_int, c_ptr]),
+    "cpc_gemm_tn_planes_scratch_bytes": (c_size_t, [c_int, c_int, c_long]),
+    "cpc_gemm_tn_planes": (c_int, [c_ptr, c_long, c_int, c_long, c_int, c_int, c_ptr, c_long, c_int, c_long, c_int, c_int, c_ptr, c_long,
+                                   c_int, c_int, c_long, c_ptr, c_size_t, c_ptr]),
     "cpc_channelnorm_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_channelnorm_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_encoder_frames": (c_int, [c_int]),

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcpc2_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm_f32.hip", "rowops.hip", "encoder.hip", "gru.hip", "lstm.hip", "infonce.hip", "transformer.hip", "negidx.cpp", "flac.cpp"]
+SOURCES = ["gemm_f32.hip", "gemm_planes.hip", "rowops.hip", "encoder.hip", "gru.hip", "lstm.hip", "infonce.hip", "transformer.hip", "negidx.cpp", "flac.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
 
 

@@ -120,4 +120,41 @@ int colsum_rows(const float *a, long ld, long rows, int width, float *out, void 
 
 int transpose2d(const float *a, float *at, int rows, int cols, hipStream_t st);                      // at[c][r]=a[r][c]
 
+// ---- operands stored as their three bf16 terms (gemm_planes.hip) ----
+// Chunked planes: the 16 consecutive K elements (channels) 16c .. 16c+15 of signal row R are 32 contiguous bytes at chunk
+// index (c * s + R % s) * rts + R / s of every plane (s = 1 << sshift: the stride of the Conv1d that reads the signal; its
+// phases are stored apart so that the rows t*s + j of consecutive output frames t are consecutive chunks).
+// K step ks of a GEMM over it is chunk c = ks >> kshift of tap j = (jj >> 1) + (jj & 1) * s, jj = ks & (k - 1), k = 1 << kshift
+// taps (k = 2 s, or 1): chunk-major, the taps j and j + s -- which read the same signal rows one apart -- next to each other.
+// kshift = 0 for an operand whose K is one run of chunks (weights [N][K] stored in that K order, plain matrices).
+// GEMM row m starts at signal row s * ((m / segv) * seg_q + m % segv).
+struct PlanesOperand {
+    const unsigned short *p;
+    long plane;          // elements between planes
+    int kshift;          // log2(taps)
+    int sshift;          // log2(s)
+    long rts;            // chunks per (c, phase): rows_total / s
+    int segv;            // GEMM rows per segment (sample); <= 0: one segment
+    long seg_q;          // row distance between segments, in units of s rows
+};
+int split_planes(const float *x, long ld, long rows, int cols, unsigned short *planes, long plane, int sshift, long rts,
+                 hipStream_t st);
+bool gemm_nt_planes_ok(long M, int N, int K);
+int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
+                   const RowMap &map, hipStream_t st);
+// weight-gradient form: C[i][j] = sum_{r < R} X(r, i) * Y(r, j); column x of an operand is channel x % C of tap tap0 + x / C,
+// i.e. element x % C of signal row r * s + tap.  Rows R .. round_up(R, 32) - 1 of A must be ZERO and those of B finite.
+struct PlanesTNOperand {
+    const unsigned short *p;
+    long plane;
+    int sshift;
+    long rts;
+    int tap0;            // first tap (a row shift for s = 1)
+    int C;               // channels per tap (multiple of 32)
+};
+bool gemm_tn_planes_ok(int M, int N, long R);
+size_t gemm_tn_planes_scratch_bytes(int M, int N, long R);
+int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
+                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st);
+
 }  // namespace cpc

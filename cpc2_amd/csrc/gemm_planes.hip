@@ -1,0 +1,598 @@
+// f32 GEMMs on the bf16 matrix pipe whose operands arrive ALREADY split into their three bf16 terms ("planes").
+//
+// The split x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest) is exact to
+// 2^-27 |x| (see gemm_f32.hip), so whoever produces an activation or lays out a weight can store it as the three planes
+// without losing anything, and the product a.b = a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 then needs no arithmetic besides
+// its MFMAs: the tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4), never through registers.
+//
+// Plane layout (PlanesOperand, common.h): 16-element chunks, chunk-major.  The 16 consecutive K elements (channels)
+// 16c .. 16c+15 of signal row R are 32 contiguous bytes at chunk index (c * s + R % s) * rts + R / s: consecutive rows
+// (of the same phase R % s, for the input of a stride-s Conv1d) are consecutive chunks, so the 32 rows x 16 k piece an
+// MFMA operand is made of is ONE contiguous KiB whatever the row overlap of the implicit GEMM -- an LDS-DMA instruction
+// then fetches whole cache lines (with row-major planes each lane would touch its own line and use a quarter of it).
+//
+//   gemm_nt_planes : C[map(m)][n] = sum_k A(m, k) * B(n, k) (+ bias[n]),  k = 16 ks + kl, ks -> (chunk c, tap j)
+//
+// Tile 256 x 256, 512 threads = 8 waves (2 x 4, wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32), K step 16:
+// a stage is 48 pieces of 1 KiB = (operand, plane, 32-row block): piece q holds, at byte lane * 16, the 8 consecutive k
+// (k half = lane >> 5) of row (lane & 31) of its block -- the operand layout of v_mfma_f32_32x32x16_bf16, so a fragment
+// read is ds_read_b128 at lane * 16 + constant (conflict free by construction).  Three stages (144 KiB) form a ring.
+// Schedule of stage t per wave (one s_barrier per stage, no point where the matrix pipe has nothing queued):
+//   row blocks 0, 1, 2: the A fragments of block i + 1 are read while block i is multiplied;
+//   after block 2: s_waitcnt vmcnt (the wave's own pieces of stage t + 1 have landed, stage t + 2 stays in flight),
+//     s_barrier (=> stage t + 1 landed for everyone, everyone has read all of stage t), request stage t + 3 into
+//     stage t's slot, read the B fragments and the first A fragments of stage t + 1 (second register set);
+//   row block 3 is multiplied while those reads and the new requests are under way.
+// All LDS traffic is issued from inline asm: hipcc drains vmcnt to 0 before any LDS read it can see behind an LDS-DMA.
+#include "common.h"
+
+#include <algorithm>
+
+namespace cpc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // one MFMA operand (8 bf16) as four dwords: hipcc handles
+                                                                // a bf16x8 value that crosses a branch element by element
+
+constexpr int PT_BM = 256, PT_BN = 256, PT_BK = 16;
+constexpr int PT_PIECE = 1024;                    // bytes: 32 rows x 16 k x bf16
+constexpr int PT_STAGE = 48 * PT_PIECE;           // A: 3 planes x 8 blocks, B: 3 planes x 8 blocks
+constexpr int PT_RING = 3;
+constexpr int PT_LDS = PT_RING * PT_STAGE;        // 147456 bytes
+
+struct PlanesSide {                               // device view of a PlanesOperand
+    const bf16_t *p; long plane;
+    int kshift, sshift; long rts;
+    int segv; long seg_q;
+};
+
+// weight-gradient form (TN): C[i][j] = sum_r X(r, i) * Y(r, j); column x of an operand is channel x % C of tap
+// tap0 + x / C, i.e. element (x % C) of signal row r * s + tap (s = 1 << sshift)
+struct PlanesTNSide { const bf16_t *p; long plane; int sshift; long rts; int tap0, C; };
+
+struct PlanesNTArgs {
+    PlanesSide A, B;
+    PlanesTNSide TA, TB;                          // TN kernel only
+    long R;                                       // TN: reduction rows (multiple of 32); blockIdx.z takes rchunk of them
+    long rchunk;
+    float *C; long ldc;
+    const float *bias;
+    long M; int N; int K;
+    RowMap map;
+    int tiles_m, tiles_n, xcd_remap;
+    int kchunk;                                   // K range per blockIdx.y (multiple of 32)
+    float *slabs;                                 // K split: partial product of blockIdx.y -> slabs + blockIdx.y * M * N
+    int dbg;                                      // probes: 1 no loads after the prologue, 2 no MFMAs, 8 clock stamps
+    unsigned long long *stamps;                   // dbg & 8: [workgroup][8] = memtime, memrealtime at loop start and end, ...
+};
+
+// chunk index of K step ks, row q = 0
+__device__ __forceinline__ long chunk0(const PlanesSide &o, int ks)
+{
+    // K order: chunk-major, and within a chunk the taps j and j + s next to each other (0, s, 1, s + 1, ...): they read the
+    // same rows of the signal one apart, so the second one finds them in L2
+    const int c = ks >> o.kshift, jj = ks - (c << o.kshift);
+    const int j = (jj >> 1) + ((jj & 1) << o.sshift);
+    const int smask = (1 << o.sshift) - 1;
+    return (long)((c << o.sshift) + (j & smask)) * o.rts + (j >> o.sshift);
+}
+
+// one LDS-DMA piece: lane l writes 16 bytes at lds_dst + 16 l, read from sbase + voff (bytes)
+__device__ __forceinline__ void glds16(unsigned lds_dst, unsigned voff, const void *sbase)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_dst), "v"(voff), "s"(sbase)
+                 : "memory");
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// NT: the piece holds the operand layout itself, one ds_read_b128 at lane * 16.  TN: the piece holds [4 r][2 chunks][4 r][16 x]
+// (r = reduction row, x = output row / column) and the operand is read transposed, two ds_read_b64_tr_b16 (4 r each).
+template <bool TN, int OFF> __device__ __forceinline__ frag_t lds_frag(unsigned addr)
+{
+    if constexpr (!TN) {
+        frag_t v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+        return v;
+    } else {
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(lo), "=&v"(hi)
+                     : "v"(addr), "n"(OFF), "n"(OFF + 256)
+                     : "memory");
+        frag_t v = {lo[0], lo[1], hi[0], hi[1]};
+        return v;
+    }
+}
+__device__ __forceinline__ void lds_wait3(frag_t (&f)[3])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
+}
+__device__ __forceinline__ void lds_wait9(frag_t (&f)[3], frag_t (&g)[2][3])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[1][0]), "+v"(g[1][1]),
+                   "+v"(g[1][2])
+                 :
+                 : "memory");
+}
+
+// product q (0..5, smallest terms first) of row block fragments a with column block fragments b, into c
+template <int Q> __device__ __forceinline__ void mma1(f32x16 &c, const frag_t (&a)[3], const frag_t (&b)[3])
+{
+    constexpr int ia = Q == 0 ? 2 : Q == 1 ? 0 : Q == 2 ? 1 : Q == 3 ? 1 : 0;
+    constexpr int ib = Q == 0 ? 0 : Q == 1 ? 2 : Q == 2 ? 1 : Q == 3 ? 0 : Q == 4 ? 1 : 0;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ia]), __builtin_bit_cast(bf16x8_t, b[ib]), c, 0, 0, 0);
+}
+// the two column tiles alternate (each accumulator chain gets a slot of slack)
+template <int Q> __device__ __forceinline__ void mma2(f32x16 &c0, f32x16 &c1, const frag_t (&a)[3], const frag_t (&b)[2][3])
+{
+    mma1<Q>(c0, a, b[0]);
+    mma1<Q>(c1, a, b[1]);
+}
+__device__ __forceinline__ void mma6(f32x16 &c0, f32x16 &c1, const frag_t (&a)[3], const frag_t (&b)[2][3], bool skip)
+{
+    if (skip) {
+        asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]));
+        return;
+    }
+    mma2<0>(c0, c1, a, b); mma2<1>(c0, c1, a, b); mma2<2>(c0, c1, a, b);
+    mma2<3>(c0, c1, a, b); mma2<4>(c0, c1, a, b); mma2<5>(c0, c1, a, b);
+}
+
+template <bool TN, int BLK> __device__ __forceinline__ void read_a(frag_t (&a)[3], unsigned fa)
+{
+    a[0] = lds_frag<TN, BLK * PT_PIECE>(fa);
+    a[1] = lds_frag<TN, (8 + BLK) * PT_PIECE>(fa);
+    a[2] = lds_frag<TN, (16 + BLK) * PT_PIECE>(fa);
+}
+template <bool TN> __device__ __forceinline__ void read_b(frag_t (&b)[2][3], unsigned fb)
+{
+    b[0][0] = lds_frag<TN, 0>(fb);        b[0][1] = lds_frag<TN, 8 * PT_PIECE>(fb);    b[0][2] = lds_frag<TN, 16 * PT_PIECE>(fb);
+    b[1][0] = lds_frag<TN, PT_PIECE>(fb); b[1][1] = lds_frag<TN, 9 * PT_PIECE>(fb);    b[1][2] = lds_frag<TN, 17 * PT_PIECE>(fb);
+}
+
+template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const unsigned long long rentry = (p.dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    long m0;
+    int n0, ks0, nst;
+    unsigned a_vo, b_vo;                                                // LDS-DMA: byte offset of this lane's 16 bytes
+    long rbeg = 0;
+    if constexpr (!TN) {
+        long mt = blockIdx.x / p.tiles_n;
+        int nt = (int)(blockIdx.x % p.tiles_n);
+        if (p.xcd_remap) {
+            // workgroups go to the 8 XCDs round robin: the column tiles of one row tile run on ONE XCD, back to back
+            const long j = blockIdx.x >> 3;
+            mt = (j / p.tiles_n) * 8 + (blockIdx.x & 7);
+            nt = (int)(j % p.tiles_n);
+        }
+        m0 = mt * PT_BM;
+        n0 = nt * PT_BN;
+        ks0 = blockIdx.y * (p.kchunk / PT_BK);
+        nst = (min(p.K, (int)(blockIdx.y + 1) * p.kchunk) - (int)blockIdx.y * p.kchunk) / PT_BK;      // even, >= 2
+        // wave w fills row block w of A and of B, all three planes (pieces w, 8 + w, ... 40 + w)
+        const long ma = min(m0 + wave * 32 + r32, p.M - 1);             // rows past the end feed discarded outputs only
+        const long aseg = ma / p.A.segv;
+        a_vo = (unsigned)(32 * (aseg * p.A.seg_q + (ma - aseg * p.A.segv)) + 16 * h);
+        const long nb = min((long)n0 + wave * 32 + r32, (long)p.N - 1);
+        const long bseg = nb / p.B.segv;
+        b_vo = (unsigned)(32 * (bseg * p.B.seg_q + (nb - bseg * p.B.segv)) + 16 * h);
+    } else {
+        // blockIdx.x: column tile (j), .y: row tile (i), .z: slab of rchunk reduction rows
+        m0 = (long)blockIdx.y * PT_BM;
+        n0 = (int)blockIdx.x * PT_BN;
+        ks0 = 0;
+        rbeg = (long)blockIdx.z * p.rchunk;
+        nst = (int)((min(p.R, rbeg + p.rchunk) - rbeg) / PT_BK);        // even, >= 2
+        // wave w fills the 32 columns (two chunks) 32 w .. 32 w + 31 of both tiles; lane -> (4-row group, chunk, row, half)
+        const int rowp = 4 * (lane >> 4) + ((lane >> 1) & 3), ch = (lane >> 3) & 1, half = lane & 1;
+        auto vo = [&](const PlanesTNSide &o, long x0) {
+            const int tap = o.tap0 + (int)(x0 / o.C), c = (int)(x0 % o.C) / 16 + 2 * wave + ch;
+            const int smask = (1 << o.sshift) - 1;
+            return (unsigned)(32 * ((long)((c << o.sshift) + (tap & smask)) * o.rts + (tap >> o.sshift) + rowp) + 16 * half);
+        };
+        a_vo = vo(p.TA, m0);
+        b_vo = vo(p.TB, n0);
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)lds;
+    constexpr bool noload = (DBG & 1) != 0, nomma = (DBG & 2) != 0;     // probes only
+    // stage t -> ring slot at byte offset `slot`: six pieces per wave, piece i of the stage requested by issue1<i>
+    struct Src { unsigned dst; const char *ab, *bb; };
+    auto stage_src = [&](int t, unsigned slot) {
+        Src q;
+        q.dst = lds0 + slot + wave * PT_PIECE;
+        if constexpr (!TN) {
+            q.ab = reinterpret_cast<const char *>(p.A.p) + 32 * chunk0(p.A, ks0 + t);
+            q.bb = reinterpret_cast<const char *>(p.B.p) + 32 * chunk0(p.B, ks0 + t);
+        } else {
+            q.ab = reinterpret_cast<const char *>(p.TA.p) + 32 * (rbeg + (long)t * PT_BK);
+            q.bb = reinterpret_cast<const char *>(p.TB.p) + 32 * (rbeg + (long)t * PT_BK);
+        }
+        return q;
+    };
+    auto issue1 = [&](const Src &q, int i) {
+        const long pla = TN ? p.TA.plane : p.A.plane, plb = TN ? p.TB.plane : p.B.plane;
+        if (i < 3) glds16(q.dst + i * 8 * PT_PIECE, a_vo, q.ab + 2 * i * pla);
+        else glds16(q.dst + i * 8 * PT_PIECE, b_vo, q.bb + 2 * (i - 3) * plb);
+    };
+    auto issue = [&](int t, unsigned slot) {
+        const Src q = stage_src(t, slot);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue1(q, i);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses inside a stage: A piece (plane, block wr * 4 + i), B piece 24 + (plane, block wc * 2 + j)
+    const unsigned flane = TN ? h * 512 + ((lane >> 4) & 1) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8 : lane * 16;
+    const unsigned fa0 = lds0 + flane + wr * 4 * PT_PIECE;
+    const unsigned fb0 = lds0 + flane + (24 + wc * 2) * PT_PIECE;
+
+    // ---- prologue: stages 0, 1, 2 requested; stage 0's fragments in registers
+    issue(0, 0);
+    issue(1, PT_STAGE);
+    if (nst > 2) {
+        issue(2, 2 * PT_STAGE);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    frag_t b0[2][3], b1[2][3], ax[3], ay[3];
+    read_b<TN>(b0, fb0);
+    read_a<TN, 0>(ax, fa0);
+    lds_wait9(ax, b0);
+
+    // one stage; bc: B fragments of this stage, bn: of the next one; ax holds block 0 on entry (and on exit)
+    unsigned slot = 0;                                                   // ring slot of stage t (byte offset)
+    auto stage = [&](int t, frag_t (&bc)[2][3], frag_t (&bn)[2][3]) {
+        const unsigned fa = fa0 + slot;
+        const unsigned nslot = slot == (PT_RING - 1) * PT_STAGE ? 0 : slot + PT_STAGE;
+        read_a<TN, 1>(ay, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(acc[0][0], acc[0][1], ax, bc, nomma);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait3(ay);
+        read_a<TN, 2>(ax, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(acc[1][0], acc[1][1], ay, bc, nomma);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait3(ax);
+        read_a<TN, 3>(ay, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(acc[2][0], acc[2][1], ax, bc, nomma);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait3(ay);                          // every LDS read of stage t by this wave is done
+        // (no branch may enclose an asm LDS read: hipcc would copy its destination registers at the join, before the wait)
+        if (t + 2 < nst && !noload) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // stage t + 1 has landed for everyone; everyone has read all of stage t
+        // row block 3, with the requests for stage t + 3 and the reads of stage t + 1's first fragments BETWEEN its MFMAs:
+        // the eight waves leave the barrier together, and an LDS-DMA piece holds a wave's issue for ~100 cycles
+        const bool req = t + 3 < nst && !noload;
+        const Src q = stage_src(req ? t + 3 : t, slot);
+        const unsigned fbn = fb0 + nslot, fan = fa0 + nslot;
+#define PT_SB __builtin_amdgcn_sched_barrier(0)
+        if (!nomma) { mma2<0>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        bn[0][0] = lds_frag<TN, 0>(fbn); bn[0][1] = lds_frag<TN, 8 * PT_PIECE>(fbn); bn[0][2] = lds_frag<TN, 16 * PT_PIECE>(fbn); PT_SB;
+        if (!nomma) { mma2<1>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        bn[1][0] = lds_frag<TN, PT_PIECE>(fbn); bn[1][1] = lds_frag<TN, 9 * PT_PIECE>(fbn); bn[1][2] = lds_frag<TN, 17 * PT_PIECE>(fbn); PT_SB;
+        if (!nomma) { mma2<2>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        read_a<TN, 0>(ax, fan); PT_SB;
+        if (req) { issue1(q, 0); issue1(q, 1); } PT_SB;
+        if (!nomma) { mma2<3>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        if (req) { issue1(q, 2); issue1(q, 3); } PT_SB;
+        if (!nomma) { mma2<4>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        if (req) { issue1(q, 4); issue1(q, 5); } PT_SB;
+        if (!nomma) { mma2<5>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+#undef PT_SB
+        lds_wait9(ax, bn);
+        slot = nslot;
+    };
+    unsigned long long c0 = 0, r0 = 0;
+    if (p.dbg & 8) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int t = 0; t < nst; t += 2) {
+        stage(t, b0, b1);
+        stage(t + 1, b1, b0);
+    }
+    if ((p.dbg & 8) && tid == 0) {
+        p.stamps[blockIdx.x * 8 + 0] = c0; p.stamps[blockIdx.x * 8 + 1] = r0;
+        p.stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[blockIdx.x * 8 + 4] = rentry;
+    }
+
+    // ---- epilogue: acc[i][j][e] is C[m][n], m = m0 + wr*128 + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wc*64 + j*32 + r32.
+    // The wave's 128 x 64 tile goes through LDS (its own 16 KiB, two passes of 64 rows) so that every lane stores 16 bytes
+    // of a row: 16 store instructions per lane instead of 128.
+    __builtin_amdgcn_s_barrier();                      // everyone has left the ring
+    float *const stg = reinterpret_cast<float *>(lds) + wave * 4096;
+    const int nw = n0 + wc * 64;                       // first column of the wave
+    const int c4 = (lane & 15) * 4;
+    float bias_v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias_v[j] = (!TN && p.bias != nullptr && blockIdx.y == 0) ? p.bias[nw + j * 32 + r32] : 0.f;
+    const int jrow = (p.map.enabled && p.map.col_rows > 0) ? nw / p.map.col_rows : 0;
+    const long rv = p.map.enabled ? p.map.rv : (1L << 62);
+    float *const out = TN ? p.slabs + (long)blockIdx.z * p.M * p.N : p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.M * p.N : p.C;
+    const long ldo = (TN || p.slabs != nullptr) ? p.N : p.ldc;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    stg[(i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r32] = acc[pass * 2 + i2][j][e] + bias_v[j];
+        // rows of this pass: m = mrow + 4 it + (lane >> 4); (group g, row t) follow by carrying (no division per row)
+        const long mrow = m0 + wr * 128 + pass * 64 + (lane >> 4);
+        long g = mrow / rv, t = mrow - g * rv;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const float4 v = *reinterpret_cast<const float4 *>(stg + (it * 4 + (lane >> 4)) * 64 + c4);
+            const long m = mrow + 4 * it;
+            long crow = m, l = 0;
+            if (p.map.enabled) {
+                l = t * p.map.out_stride + p.map.out_off;
+                crow = g * p.map.rows_out + l;
+            }
+            const bool ok = m < p.M && (!p.map.enabled || (l + jrow >= 0 && l + jrow < p.map.l_max));
+            if (ok) *reinterpret_cast<float4 *>(out + crow * ldo + nw + c4) = v;
+            t += 4;
+            while (t >= rv) { t -= rv; ++g; }
+        }
+    }
+    if (p.dbg & 8) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) p.stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// x[rows][ld] (f32, `cols` columns used, cols % 16 == 0) -> chunked planes (layout: PlanesOperand)
+__global__ void split_planes_kernel(const float *x, long ld, long rows, int cols, bf16_t *planes, long plane, int sshift, long rts)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const int chunks = cols / 16;
+    const long total = rows * chunks * 2;                    // one thread per 8 elements (half a chunk)
+    const long smask = (1L << sshift) - 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int half = (int)(i & 1);
+        const long rc = i >> 1;
+        const int c = (int)(rc % chunks);
+        const long R = rc / chunks;
+        const float4 u = *reinterpret_cast<const float4 *>(x + R * ld + c * 16 + half * 8);
+        const float4 v = *reinterpret_cast<const float4 *>(x + R * ld + c * 16 + half * 8 + 4);
+        float a[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        uint32_t w[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float lo = a[2 * q], hi = a[2 * q + 1];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                f2 pr = {lo, hi};
+                const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, b2));
+                w[t][q] = pk;
+                lo -= __uint_as_float(pk << 16);
+                hi -= __uint_as_float(pk & 0xffff0000u);
+            }
+        }
+        const long chunk = (((long)c << sshift) + (R & smask)) * rts + (R >> sshift);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            *reinterpret_cast<uint4 *>(planes + t * plane + chunk * 16 + half * 8) = make_uint4(w[t][0], w[t][1], w[t][2], w[t][3]);
+    }
+}
+
+int split_planes(const float *x, long ld, long rows, int cols, bf16_t *planes, long plane, int sshift, long rts, hipStream_t st)
+{
+    CPC_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && ld % 4 == 0 && plane % 8 == 0 && sshift >= 0 && sshift < 8 &&
+                    rts >= cdiv(rows, 1L << sshift) && plane >= (long)(cols / 16) * (rts << sshift) * 16 &&
+                    reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(planes) % 16 == 0,
+                "split_planes: bad arguments (rows=%ld cols=%d ld=%ld plane=%ld sshift=%d rts=%ld)", rows, cols, ld, plane, sshift, rts);
+    const long total = rows * (cols / 16) * 2;
+    const long blocks = std::min<long>(cdiv(total, 256), 8192);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, rows, cols, planes, plane, sshift, rts);
+    CPC_CHECK_LAUNCH("split_planes_kernel");
+    return CPC_OK;
+}
+
+bool gemm_nt_planes_ok(long M, int N, int K)
+{
+    return N % PT_BN == 0 && K % (2 * PT_BK) == 0 && K >= 4 * PT_BK && M >= 1;
+}
+
+static int side_of(const PlanesOperand &o, PlanesSide &s, const char *name)
+{
+    CPC_REQUIRE(o.p != nullptr && reinterpret_cast<uintptr_t>(o.p) % 32 == 0 && o.plane % 16 == 0 && o.plane > 0 &&
+                    2 * o.plane < (1L << 31) && o.sshift >= 0 && o.sshift < 8 && o.kshift >= 0 && o.kshift <= 8 && o.rts > 0,
+                "gemm_nt_planes: bad %s operand", name);
+    s.p = o.p; s.plane = o.plane; s.kshift = o.kshift; s.sshift = o.sshift; s.rts = o.rts;
+    s.segv = o.segv > 0 ? o.segv : 0x7fffffff; s.seg_q = o.seg_q;
+    return CPC_OK;
+}
+
+int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
+                   const RowMap &map, hipStream_t st)
+{
+    CPC_REQUIRE(gemm_nt_planes_ok(M, N, K), "gemm_nt_planes: shape M=%ld N=%d K=%d not supported", M, N, K);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<1, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<2, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        attr_set = true;
+    }
+    PlanesNTArgs a{};
+    CPC_TRY(side_of(A, a.A, "A"));
+    CPC_TRY(side_of(B, a.B, "B"));
+    a.C = C; a.ldc = ldc; a.bias = bias; a.M = M; a.N = N; a.K = K; a.map = map;
+    a.tiles_m = (int)cdiv(M, PT_BM); a.tiles_n = N / PT_BN;
+    static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
+    a.xcd_remap = (!no_remap && a.tiles_n > 1 && a.tiles_m % 8 == 0) ? 1 : 0;
+    a.kchunk = K; a.slabs = nullptr;
+    a.dbg = getenv("CPC_PLANES_DBG") ? atoi(getenv("CPC_PLANES_DBG")) : 0;
+    static unsigned long long *stamps = nullptr;
+    if (a.dbg & 8) {
+        if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 65536 * 8 * sizeof(unsigned long long)));
+        a.stamps = stamps;
+    }
+    const long blocks = (long)a.tiles_m * a.tiles_n;
+    ProfScope prof(PROF_GEMM_NT, st);
+    if ((a.dbg & 3) == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, false>), dim3((unsigned)blocks, 1), dim3(512), PT_LDS, st, a);
+    else if ((a.dbg & 3) == 2) hipLaunchKernelGGL((gemm_planes_kernel<2, false>), dim3((unsigned)blocks, 1), dim3(512), PT_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_planes_kernel<0, false>), dim3((unsigned)blocks, 1), dim3(512), PT_LDS, st, a);
+    CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");
+    if (a.dbg & 8) {
+        static unsigned long long host[65536 * 8];
+        CPC_CHECK_HIP(hipStreamSynchronize(st));
+        const long nb = std::min<long>(blocks, 65536);
+        CPC_CHECK_HIP(hipMemcpy(host, stamps, nb * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double cyc = 0, real = 0, pro = 0, epi = 0;
+        unsigned long long first = ~0ull, last = 0;
+        for (long i = 0; i < nb; ++i) {
+            cyc += (double)(host[i * 8 + 2] - host[i * 8]); real += (double)(host[i * 8 + 3] - host[i * 8 + 1]);
+            pro += (double)(host[i * 8 + 1] - host[i * 8 + 4]); epi += (double)(host[i * 8 + 5] - host[i * 8 + 3]);
+            first = std::min(first, host[i * 8 + 4]); last = std::max(last, host[i * 8 + 5]);
+        }
+        fprintf(stderr, "planes stamps: %ld tiles, loop %.0f cycles = %.2f us per tile, clock %.3f GHz; prologue %.2f us, epilogue %.2f us, kernel span %.1f us\n",
+                nb, cyc / nb, real / nb * 0.01, cyc / real * 0.1, pro / nb * 0.01, epi / nb * 0.01, (double)(last - first) * 0.01);
+    }
+    return CPC_OK;
+}
+
+// out = sum over slabs, in slab order (bitwise reproducible); optional Conv1d weight re-layout (column jj*cin+ci -> [ci][jj])
+__global__ void planes_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k)
+{
+    const long total = (long)M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += slab[(long)z * total + idx];
+        const int i = (int)(idx / N), j = (int)(idx - (long)i * N);
+        if (conv_cin > 0) {
+            const int jj = j / conv_cin, ci = j - jj * conv_cin;
+            C[(long)i * conv_cin * conv_k + (long)ci * conv_k + jj] = s;
+        } else {
+            C[(long)i * ldc + j] = s;
+        }
+    }
+}
+
+static int tn_planes_splits(int M, int N, long R, long *chunk_out)
+{
+    const long tiles = (long)(M / PT_BM) * (N / PT_BN);
+    const long Rp = cdiv(R, 32) * 32;
+    long S = std::max<long>(1, (256 + tiles / 2) / tiles);            // one workgroup per CU, one round
+    S = std::min(S, std::max<long>(1, Rp / 128));
+    const long chunk = cdiv(cdiv(Rp, S), 32) * 32;
+    *chunk_out = chunk;
+    return (int)cdiv(Rp, chunk);
+}
+
+bool gemm_tn_planes_ok(int M, int N, long R) { return M % PT_BM == 0 && N % PT_BN == 0 && R >= 64; }
+
+size_t gemm_tn_planes_scratch_bytes(int M, int N, long R)
+{
+    long chunk;
+    const int S = tn_planes_splits(M, N, R, &chunk);
+    return align_up((size_t)S * M * N * sizeof(float), 256);
+}
+
+int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
+                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st)
+{
+    CPC_REQUIRE(gemm_tn_planes_ok(M, N, R), "gemm_tn_planes: shape M=%d N=%d R=%ld not supported", M, N, R);
+    auto bad = [](const PlanesTNOperand &o) {
+        return o.p == nullptr || reinterpret_cast<uintptr_t>(o.p) % 32 != 0 || o.plane % 16 != 0 || o.plane <= 0 ||
+               2 * o.plane >= (1L << 31) || o.sshift < 0 || o.sshift > 7 || o.rts <= 0 || o.C % 32 != 0 || o.C <= 0 || o.tap0 < 0;
+    };
+    CPC_REQUIRE(!bad(A) && !bad(B), "gemm_tn_planes: bad operand");
+    long chunk;
+    const int S = tn_planes_splits(M, N, R, &chunk);
+    if ((size_t)S * M * N * sizeof(float) > scratch_bytes) {
+        set_error("gemm_tn_planes: scratch too small (%zu < %zu)", scratch_bytes, (size_t)S * M * N * sizeof(float));
+        return CPC_ERR_WORKSPACE;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        attr_set = true;
+    }
+    PlanesNTArgs a{};
+    a.TA = PlanesTNSide{A.p, A.plane, A.sshift, A.rts, A.tap0, A.C};
+    a.TB = PlanesTNSide{B.p, B.plane, B.sshift, B.rts, B.tap0, B.C};
+    a.R = cdiv(R, 32) * 32;            // rows R .. of A are zero (caller), of B finite
+    a.rchunk = chunk;
+    a.M = M; a.N = N; a.K = 0; a.slabs = static_cast<float *>(scratch);
+    a.dbg = 0;
+    {
+        ProfScope prof(PROF_GEMM_TN, st);
+        hipLaunchKernelGGL((gemm_planes_kernel<0, true>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
+                           st, a);
+    }
+    CPC_CHECK_LAUNCH("gemm_planes_kernel (tn)");
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, a.slabs, S, M, N, C,
+                       ldc, conv_cin, conv_k);
+    CPC_CHECK_LAUNCH("planes_tn_reduce_kernel");
+    return CPC_OK;
+}
+
+}  // namespace cpc
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cpc_split_planes(const float *x, long ld, long rows, int cols, void *planes, long plane_stride, int stride_log2,
+                                long rows_per_phase, cpc_stream_t stream)
+{
+    return cpc::split_planes(x, ld, rows, cols, static_cast<cpc::bf16_t *>(planes), plane_stride, stride_log2, rows_per_phase,
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_gemm_nt_planes(const void *a_planes, long a_plane_stride, int a_taps_log2, int a_stride_log2,
+                                  long a_rows_per_phase, int a_seg_rows, long a_seg_q, const void *b_planes, long b_plane_stride,
+                                  float *C, long ldc, const float *bias, long M, int N, int K, cpc_stream_t stream)
+{
+    cpc::PlanesOperand A{static_cast<const cpc::bf16_t *>(a_planes), a_plane_stride, a_taps_log2, a_stride_log2, a_rows_per_phase,
+                         a_seg_rows, a_seg_q};
+    cpc::PlanesOperand B{static_cast<const cpc::bf16_t *>(b_planes), b_plane_stride, 0, 0, N, 0, 0};
+    cpc::RowMap map{};
+    return cpc::gemm_nt_planes(A, B, C, ldc, bias, M, N, K, map, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t cpc_gemm_tn_planes_scratch_bytes(int M, int N, long R) { return cpc::gemm_tn_planes_scratch_bytes(M, N, R); }
+
+extern "C" int cpc_gemm_tn_planes(const void *a_planes, long a_plane_stride, int a_stride_log2, long a_rows_per_phase, int a_tap,
+                                  int a_channels, const void *b_planes, long b_plane_stride, int b_stride_log2,
+                                  long b_rows_per_phase, int b_tap, int b_channels, float *C, long ldc, int M, int N, long R,
+                                  void *scratch, size_t scratch_bytes, cpc_stream_t stream)
+{
+    cpc::PlanesTNOperand A{static_cast<const cpc::bf16_t *>(a_planes), a_plane_stride, a_stride_log2, a_rows_per_phase, a_tap, a_channels};
+    cpc::PlanesTNOperand B{static_cast<const cpc::bf16_t *>(b_planes), b_plane_stride, b_stride_log2, b_rows_per_phase, b_tap, b_channels};
+    return cpc::gemm_tn_planes(A, B, C, ldc, M, N, R, scratch, scratch_bytes, 0, 0, static_cast<hipStream_t>(stream));
+}

@@ -72,6 +72,35 @@ size_t cpc_gemm_tn_scratch_bytes(int M, int N, long R);
 int cpc_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc,
                 int M, int N, long R, void *scratch, size_t scratch_bytes, cpc_stream_t stream);
 
+/* The same products with operands stored as their three bf16 terms ("planes": x = p0 + p1 + p2, p0 = bf16(x),
+ * p1 = bf16(x - p0), p2 = bf16(x - p0 - p1); bf16 stored as 16-bit words, planes `plane_stride` elements apart).
+ * The encoder's kernels write activations and weights in this form so that the GEMM tiles go global -> LDS by
+ * LDS-DMA with no arithmetic besides the MFMAs; these two entries expose the format for tests and probes.
+ * Layout of a plane: 16-element chunks; columns 16c .. 16c+15 of row R at chunk (c * s + R % s) * rows_per_phase + R / s,
+ * s = 1 << stride_log2 (the stride of the Conv1d that will read the rows; 0 for a plain matrix).
+ *   cpc_split_planes:   x[rows][ld] (f32, `cols` columns, cols % 16 == 0) -> planes[3][plane_stride]
+ *   cpc_gemm_nt_planes: C[M,N] = A . B^T (+ bias).  K step ks (16 elements) of A is chunk c = ks >> a_taps_log2 of tap
+ *                       j = (jj >> 1) + (jj & 1) * s, jj = ks & (k - 1) -- a Conv1d with k = 2 s taps over a C-channel signal:
+ *                       K = k * C in the order (chunk, tap 0, s, 1, s + 1, ...); a plain matrix: a_taps_log2 = 0 --;
+ *                       GEMM row m starts at signal row s * ((m / a_seg_rows) * a_seg_q + m % a_seg_rows)
+ *                       (a_seg_rows <= 0: one segment).
+ *                       B: planes of a plain [N][K] matrix in the same K order (stride_log2 0, rows_per_phase N).
+ *                       N % 256 == 0, K % 32 == 0, K >= 64. */
+int cpc_split_planes(const float *x, long ld, long rows, int cols, void *planes, long plane_stride, int stride_log2,
+                     long rows_per_phase, cpc_stream_t stream);
+int cpc_gemm_nt_planes(const void *a_planes, long a_plane_stride, int a_taps_log2, int a_stride_log2,
+                       long a_rows_per_phase, int a_seg_rows, long a_seg_q, const void *b_planes, long b_plane_stride,
+                       float *C, long ldc, const float *bias, long M, int N, int K, cpc_stream_t stream);
+/*   cpc_gemm_tn_planes: C[M,N] = sum_{r<R} X(r, .)^T Y(r, .)  (weight gradients).  Column x of an operand is channel
+ *                       x % channels of signal row r * s + tap + x / channels (s = 1 << stride_log2) of its planes.
+ *                       M % 256 == 0, N % 256 == 0, R >= 64; rows R .. round_up(R, 32) - 1 of A must be zero, of B finite.
+ *                       The partial sums of the row slabs are added in a fixed order (bitwise reproducible). */
+size_t cpc_gemm_tn_planes_scratch_bytes(int M, int N, long R);
+int cpc_gemm_tn_planes(const void *a_planes, long a_plane_stride, int a_stride_log2, long a_rows_per_phase, int a_tap,
+                       int a_channels, const void *b_planes, long b_plane_stride, int b_stride_log2,
+                       long b_rows_per_phase, int b_tap, int b_channels, float *C, long ldc, int M, int N, long R,
+                       void *scratch, size_t scratch_bytes, cpc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * ChannelNorm on a channel-FIRST tensor x[N,C,L] (standalone module API, model.py:27-60):
  * per (n,l) statistics over C, UNBIASED variance, y = (x-mean)*rsqrt(var+eps)*w[c]+b[c].
