@@ -430,6 +430,348 @@ template <int H> __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Producers of chunked bf16 planes (gemm_planes.hip, PlanesOperand in common.h) for H = 256 / 512.  A block turns 16
+// consecutive signal rows into whole cache lines of the three planes: the row kernels keep their lane layout (a lane
+// owns 4 channels of a row), drop the split values into an LDS tile [plane][row][channel] (rows padded by 32 bytes:
+// the flush reads the same 32-byte column of different rows), and the flush copies 16-byte pieces so that the
+// (16 / s) rows of a phase of a chunk -- contiguous in the plane -- leave through neighbouring lanes.
+struct PlaneOut { unsigned short *p; long plane; int sshift; long rts; };
+#define CPC_DISPATCH_HP(H, ...)                                 \
+    switch (H) {                                                \
+    case 256: { constexpr int HH = 256; __VA_ARGS__; } break;  \
+    case 512: { constexpr int HH = 512; __VA_ARGS__; } break;  \
+    default: break;                                             \
+    }
+
+template <int H> struct PlaneTile {
+    static constexpr int ROWB = 2 * H + 32;
+    static constexpr int BYTES = 3 * 16 * ROWB;
+};
+
+__device__ __forceinline__ void split4_planes(const float (&a)[4], uint2 (&w)[3])
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    float lo0 = a[0], hi0 = a[1], lo1 = a[2], hi1 = a[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        f2 p0 = {lo0, hi0}, p1 = {lo1, hi1};
+        const uint32_t k0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, b2));
+        const uint32_t k1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, b2));
+        w[t] = make_uint2(k0, k1);
+        lo0 -= __uint_as_float(k0 << 16); hi0 -= __uint_as_float(k0 & 0xffff0000u);
+        lo1 -= __uint_as_float(k1 << 16); hi1 -= __uint_as_float(k1 & 0xffff0000u);
+    }
+}
+
+// float4 number f4 (channels 4 f4 .. 4 f4 + 3) of tile row `row16`
+template <int H> __device__ __forceinline__ void tile_put(char *tile, int row16, int f4, const float (&a)[4])
+{
+    uint2 w[3];
+    split4_planes(a, w);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<uint2 *>(tile + (t * 16 + row16) * PlaneTile<H>::ROWB + f4 * 8) = w[t];
+}
+
+// the tile holds signal rows G0 .. G0 + 15 (G0 % 16 == 0); all 256 threads
+template <int H> __device__ __forceinline__ void tile_flush(const char *tile, const PlaneOut &o, long G0)
+{
+    const int sh = o.sshift, qn = 16 >> sh;
+    for (int u = threadIdx.x; u < (H / 16) * 32; u += 256) {
+        const int c = u >> 5, w = u & 31, half = w & 1, k = w >> 1;
+        const int phi = k >> (4 - sh), qi = k & (qn - 1), row = (qi << sh) + phi;
+        const long chunk = (long)((c << sh) + phi) * o.rts + (G0 >> sh) + qi;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(tile + (t * 16 + row) * PlaneTile<H>::ROWB + c * 32 + half * 16);
+            *reinterpret_cast<uint4 *>(o.p + t * o.plane + chunk * 16 + half * 8) = v;
+        }
+    }
+}
+
+// conv0 + norm + relu -> Y0 as planes.  One block per 64 consecutive rows of Y0 (halo and slack rows included: zeros).
+template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv0Args a, PlaneOut o)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL;
+    static_assert(Cfg::RPW == 1, "plane producers: one row per wave pass");
+    __shared__ float xs[64 * C0_K];
+    __shared__ __attribute__((aligned(16))) char tile[PlaneTile<H>::BYTES];
+    const long G0 = (long)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane;
+
+    for (int i = threadIdx.x; i < 64 * C0_K; i += 256) {
+        const int slot = i / C0_K, j = i - slot * C0_K;
+        const long row = G0 + slot;
+        const long n = row / a.R0;
+        const int t = (int)(row - n * a.R0) - a.halo;
+        const int pos = C0_S * t - C0_P + j;
+        xs[i] = (n < a.N && t >= 0 && t < a.L1 && pos >= 0 && pos < a.L0) ? a.x[n * a.L0 + pos] : 0.f;
+    }
+    float wreg[VPL][4][C0_K], breg[VPL][4], gam[VPL][4], bet[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (v * G + gl) * 4 + e;
+#pragma unroll
+            for (int j = 0; j < C0_K; ++j) wreg[v][e][j] = a.w[c * C0_K + j];
+            breg[v][e] = a.b[c];
+            gam[v][e] = a.gamma[c];
+            bet[v][e] = a.beta[c];
+        }
+    __syncthreads();
+    for (int sub = 0; sub < 4; ++sub) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r16 = pass * 4 + wave, slot = sub * 16 + r16;
+            const long row = G0 + slot;
+            const long n = row / a.R0;
+            const int t = (int)(row - n * a.R0) - a.halo;
+            const bool valid = n < a.N && t >= 0 && t < a.L1;
+            float xr[C0_K];
+#pragma unroll
+            for (int j = 0; j < C0_K; ++j) xr[j] = xs[C0_K * slot + j];
+            float u[VPL][4];
+            float sm = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float acc = breg[v][e];
+#pragma unroll
+                    for (int j = 0; j < C0_K; ++j) acc = fmaf(wreg[v][e][j], xr[j], acc);
+                    u[v][e] = acc;
+                    sm += acc;
+                }
+            const float mean = group_sum<G>(sm) * (1.f / H);
+            float ss = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u[v][e] -= mean;
+                    ss = fmaf(u[v][e], u[v][e], ss);
+                }
+            const float rstd = rsqrtf(group_sum<G>(ss) * (1.f / (H - 1)) + a.eps);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = valid ? fmaxf(fmaf(u[v][e] * rstd, gam[v][e], bet[v][e]), 0.f) : 0.f;
+                tile_put<H>(tile, r16, v * G + gl, y);
+            }
+            if (valid && gl == 0) {
+                a.stats[(n * a.L1 + t) * 2 + 0] = mean;
+                a.stats[(n * a.L1 + t) * 2 + 1] = rstd;
+            }
+        }
+        __syncthreads();
+        tile_flush<H>(tile, o, G0 + sub * 16);
+        __syncthreads();
+    }
+}
+
+// ChannelNorm + ReLU of layers 1..3 -> xhat (f32, in place) and the next layer's input as planes; tiles of 16 rows of Y
+template <int H> __global__ __launch_bounds__(256) void norm_fwd_pl_kernel(NormArgs a, PlaneOut o, long n_tiles)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL;
+    static_assert(Cfg::RPW == 1, "plane producers: one row per wave pass");
+    __shared__ __attribute__((aligned(16))) char tile[PlaneTile<H>::BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane;
+    float gam[VPL][4], bet[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gam[v][e] = a.gamma[(v * G + gl) * 4 + e];
+            bet[v][e] = a.beta[(v * G + gl) * 4 + e];
+        }
+    for (long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        // the four rows of this wave are requested together: a row is a load -> use chain
+        float4 x4[4][VPL];
+        long mrow[4];
+        bool ok[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const long row = tl * 16 + pass * 4 + wave;
+            const long n = row / a.Rnext;
+            const int t = (int)(row - n * a.Rnext) - a.halo;
+            ok[pass] = n < a.N && t >= 0 && t < a.Lout;
+            mrow[pass] = n * a.Rv + (ok[pass] ? t : 0);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                x4[pass][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[pass]) x4[pass][v] = reinterpret_cast<const float4 *>(a.u + mrow[pass] * H)[v * G + gl];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            float sm = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) sm += (x4[pass][v].x + x4[pass][v].y) + (x4[pass][v].z + x4[pass][v].w);
+            const float mean = group_sum<G>(sm) * (1.f / H);
+            float ss = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float4 &q = x4[pass][v];
+                q.x -= mean; q.y -= mean; q.z -= mean; q.w -= mean;
+                ss = fmaf(q.x, q.x, ss); ss = fmaf(q.y, q.y, ss); ss = fmaf(q.z, q.z, ss); ss = fmaf(q.w, q.w, ss);
+            }
+            const float rstd = rsqrtf(group_sum<G>(ss) * (1.f / (H - 1)) + a.eps);
+            if (ok[pass] && gl == 0) a.rstd[mrow[pass]] = rstd;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const float4 q = x4[pass][v];
+                const float xh[4] = {q.x * rstd, q.y * rstd, q.z * rstd, q.w * rstd};
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = ok[pass] ? fmaxf(fmaf(xh[e], gam[v][e], bet[v][e]), 0.f) : 0.f;
+                if (ok[pass]) reinterpret_cast<float4 *>(a.u + mrow[pass] * H)[v * G + gl] = make_float4(xh[0], xh[1], xh[2], xh[3]);
+                tile_put<H>(tile, pass * 4 + wave, v * G + gl, y);
+            }
+        }
+        __syncthreads();
+        tile_flush<H>(tile, o, tl * 16);
+        __syncthreads();
+    }
+}
+
+// backward of ChannelNorm + ReLU -> dU as planes (rows shifted by one, zero rows at the sample borders and in the slack)
+template <int H> __global__ __launch_bounds__(256) void norm_bwd_pl_kernel(NormArgs a, PlaneOut o, long n_tiles)
+{
+    using Cfg = RowCfg<H>;
+    constexpr int G = Cfg::G, VPL = Cfg::VPL;
+    static_assert(Cfg::RPW == 1, "plane producers: one row per wave pass");
+    __shared__ __attribute__((aligned(16))) char tile[PlaneTile<H>::BYTES > 4 * 3 * H * 4 ? PlaneTile<H>::BYTES : 4 * 3 * H * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane;
+    float gam[VPL][4], bet[VPL][4], dg[VPL][4], dbe[VPL][4], dbi[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gam[v][e] = a.gamma[(v * G + gl) * 4 + e];
+            bet[v][e] = a.beta[(v * G + gl) * 4 + e];
+            dg[v][e] = dbe[v][e] = dbi[v][e] = 0.f;
+        }
+    for (long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        float4 x4[4][VPL], g4[4][VPL];
+        float rs[4];
+        bool ok[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const long row = tl * 16 + pass * 4 + wave;
+            const long n = row / a.Rv;
+            const int t = (int)(row - n * a.Rv) - 1;
+            ok[pass] = n < a.N && t >= 0 && t < a.Lout;
+            const long m = n * a.Rv + (ok[pass] ? t : 0);
+            rs[pass] = ok[pass] ? a.rstd[m] : 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                x4[pass][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                g4[pass][v] = x4[pass][v];
+                if (ok[pass]) {
+                    x4[pass][v] = reinterpret_cast<const float4 *>(a.u + m * H)[v * G + gl];
+                    g4[pass][v] = reinterpret_cast<const float4 *>(a.dy + (n * a.Lout + t) * H)[v * G + gl];
+                }
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            float xh[VPL][4], gx[VPL][4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const float xv[4] = {x4[pass][v].x, x4[pass][v].y, x4[pass][v].z, x4[pass][v].w};
+                const float gv[4] = {g4[pass][v].x, g4[pass][v].y, g4[pass][v].z, g4[pass][v].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float act = fmaf(xv[e], gam[v][e], bet[v][e]);
+                    const float g = (ok[pass] && act > 0.f) ? gv[e] : 0.f;
+                    dbe[v][e] += g;
+                    dg[v][e] = fmaf(g, xv[e], dg[v][e]);
+                    xh[v][e] = xv[e];
+                    gx[v][e] = g * gam[v][e];
+                    s1 += gx[v][e];
+                    s2 = fmaf(gx[v][e], xv[e], s2);
+                }
+            }
+            s1 = group_sum<G>(s1) * (1.f / H);
+            s2 = group_sum<G>(s2) * (1.f / (H - 1));
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float du[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    du[e] = rs[pass] * (gx[v][e] - s1 - xh[v][e] * s2);
+                    dbi[v][e] += du[e];
+                }
+                tile_put<H>(tile, pass * 4 + wave, v * G + gl, du);
+            }
+        }
+        __syncthreads();
+        tile_flush<H>(tile, o, tl * 16);
+        __syncthreads();
+    }
+    // block-level sum of the four waves' partials, one row of part[] per block (the tile's LDS is free now)
+    float *red = reinterpret_cast<float *>(tile);            // [4][3 H]
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (v * G + gl) * 4 + e;
+            red[wave * 3 * H + c] = dg[v][e];
+            red[wave * 3 * H + H + c] = dbe[v][e];
+            red[wave * 3 * H + 2 * H + c] = dbi[v][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * H; c += 256)
+        a.part[(long)blockIdx.x * 3 * H + c] = (red[c] + red[3 * H + c]) + (red[6 * H + c] + red[9 * H + c]);
+}
+
+// Conv1d weights as the plane-fed GEMMs' B operands (gemm_planes.hip), one launch for all layers:
+// blockIdx.z = 0: forward operand, rows co, K order (chunk c of ci, tap 0, s, 1, s + 1, ...);
+// blockIdx.z = 1: backward-data operand, rows (phase j, ci), K order (chunk c of co, dU row t_hi - 1 then t_hi).
+// Both are [K / 16][rows][16] per plane, planes H * H * k elements apart.
+struct PermutePlanes { const float *w[4]; unsigned short *wf[4]; unsigned short *wd[4]; int k[4]; int s[4]; int H; };
+__global__ void permute_conv_planes_kernel(PermutePlanes a)
+{
+    const int li = blockIdx.y, H = a.H, k = a.k[li], s = a.s[li];
+    const float *w = a.w[li];
+    const long total = (long)H * H * k;
+    unsigned short *dst = blockIdx.z == 0 ? a.wf[li] : a.wd[li];
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 15);
+        float v;
+        if (blockIdx.z == 0) {
+            const int co = (int)((idx >> 4) % H), ks = (int)((idx >> 4) / H);
+            const int c = ks / k, jj = ks - c * k;
+            const int j = k > 1 ? (jj >> 1) + (jj & 1) * s : 0;
+            v = w[((long)co * H + c * 16 + e) * k + j];
+        } else {
+            const int rows = s * H;
+            const int n = (int)((idx >> 4) % rows), ks = (int)((idx >> 4) / rows);
+            const int c = ks >> 1, first = !(ks & 1);
+            const int jph = n / H, ci = n - jph * H;
+            v = w[((long)(c * 16 + e) * H + ci) * k + (first ? jph + s : jph)];
+        }
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f2 pr = {v, 0.f};
+            const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, b2));
+            dst[t * total + idx] = (unsigned short)(pk & 0xffffu);
+            v -= __uint_as_float(pk << 16);
+        }
+    }
+}
+
 // Every Conv1d weight re-layout of a step in one launch (blockIdx.y = layer - 1, blockIdx.z = 0 forward operand
 // wf[co][j*H + ci], 1 backward-data operand bd[j][ci][kk] -- see rowops.hip permute_conv_*), H x H x k each.
 struct PermuteAll { const float *w[4]; float *wf[4]; float *wd[4]; int k[4]; int s[4]; int H; };
@@ -484,12 +826,25 @@ struct EncLayout {
     float *dYa, *dYb, *dU, *part, *sums, *cs, *tn;
     size_t tn_bytes;
     size_t scratch_bytes;
+    // plane-fed GEMMs (H = 256, 512): Y_i, dU and the weights live as chunked bf16 planes instead of f32
+    int planes;
+    unsigned short *Yp[4];  long Yplane[4], Yrts[4];     // saved: input of layer i + 1, s_{i+1} phases
+    unsigned short *Wdp[5];                               // saved: backward-data operand of layer i
+    unsigned short *Wfp[5];                               // scratch: forward operand of layer i
+    unsigned short *dUp;    long dUplane, dUrows;         // scratch: dU of the current layer (largest: layer 1)
 };
 
 constexpr int NORM_BWD_BLOCKS = 2048;   // 8 per CU: the row loop is a load -> use chain, only occupancy hides its latency
 constexpr int CONV0_BWD_BLOCKS = 768;
 
 static bool supported_hidden(int H) { return H == 32 || H == 64 || H == 128 || H == 256 || H == 512; }
+static int log2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+// the encoder's GEMMs run on pre-split planes when the hidden size is made of 256-column tiles (CPC_NO_PLANES=1: A/B switch)
+static bool use_planes(int H)
+{
+    static const bool off = getenv("CPC_NO_PLANES") != nullptr;
+    return !off && H % 256 == 0;
+}
 
 static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void *scratch)
 {
@@ -505,8 +860,17 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
     e.Rv[0] = 0;
     for (int i = 0; i < 4; ++i) e.R[i] = kConv[i + 1].s * e.Rv[i + 1];
 
+    e.planes = use_planes(H) ? 1 : 0;
     Carver sv(saved);
-    for (int i = 0; i < 4; ++i) e.Y[i] = sv.take<float>(((size_t)N * e.R[i] + kConv[i + 1].k) * H);   // + slack rows
+    for (int i = 0; i < 4; ++i) {
+        e.Y[i] = nullptr; e.Yp[i] = nullptr;
+        if (!e.planes) { e.Y[i] = sv.take<float>(((size_t)N * e.R[i] + kConv[i + 1].k) * H); continue; }   // + slack rows
+        // rows of a phase: the weight-gradient product reads whole 32-row steps of virtual rows (+ a tap beyond)
+        const int s = kConv[i + 1].s;
+        e.Yrts[i] = (cdiv((long)N * e.Rv[i + 1], 32) * 32 + 4 + 15) / 16 * 16;
+        e.Yplane[i] = (long)(H / 16) * s * e.Yrts[i] * 16;
+        e.Yp[i] = sv.take<unsigned short>((size_t)3 * e.Yplane[i]);
+    }
     e.Xh[0] = nullptr; e.rstd[0] = nullptr;
     for (int i = 1; i < 5; ++i) {
         e.Xh[i] = sv.take<float>((size_t)N * e.Rv[i] * H);
@@ -514,23 +878,40 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
     }
     e.stats0 = sv.take<float>((size_t)N * e.L[1] * 2);
     e.Wd[0] = nullptr;
-    for (int i = 1; i < 5; ++i) e.Wd[i] = sv.take<float>((size_t)kConv[i].k * H * H);
+    for (int i = 1; i < 5; ++i) {
+        e.Wd[i] = nullptr; e.Wdp[i] = nullptr;
+        if (e.planes) e.Wdp[i] = sv.take<unsigned short>((size_t)3 * kConv[i].k * H * H);
+        else e.Wd[i] = sv.take<float>((size_t)kConv[i].k * H * H);
+    }
     e.saved_bytes = sv.used();
 
     Carver sc(scratch);
     e.Wf[0] = nullptr;
-    for (int i = 1; i < 5; ++i) e.Wf[i] = sc.take<float>((size_t)kConv[i].k * H * H);
+    for (int i = 1; i < 5; ++i) {
+        e.Wf[i] = nullptr; e.Wfp[i] = nullptr;
+        if (e.planes) e.Wfp[i] = sc.take<unsigned short>((size_t)3 * kConv[i].k * H * H);
+        else e.Wf[i] = sc.take<float>((size_t)kConv[i].k * H * H);
+    }
     e.dYa = sc.take<float>((size_t)N * e.L[1] * H);
     e.dYb = sc.take<float>((size_t)N * e.L[2] * H);
-    e.dU = sc.take<float>(((size_t)N * e.Rv[1] + 2) * H);
+    e.dU = nullptr; e.dUp = nullptr; e.dUrows = 0; e.dUplane = 0;
+    if (e.planes) {
+        e.dUrows = (cdiv((long)N * e.Rv[1], 32) * 32 + 4 + 15) / 16 * 16;
+        e.dUplane = (long)(H / 16) * e.dUrows * 16;
+        e.dUp = sc.take<unsigned short>((size_t)3 * e.dUplane);
+    } else {
+        e.dU = sc.take<float>(((size_t)N * e.Rv[1] + 2) * H);
+    }
     const size_t part_floats = std::max((size_t)CONV0_BWD_BLOCKS * 13 * H, (size_t)NORM_BWD_BLOCKS * 3 * H);
     e.part = sc.take<float>(part_floats);
     e.sums = sc.take<float>((size_t)13 * H);
     e.cs = sc.take<float>(colsum_split_scratch_bytes(13 * H) / sizeof(float));
     e.tn_bytes = 0;
-    for (int i = 1; i < 5; ++i)
+    for (int i = 1; i < 5; ++i) {
         e.tn_bytes = std::max(e.tn_bytes, std::max(gemm_tn_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]),
                                                     gemm_nt_scratch_bytes((long)N * e.Rv[i], H, kConv[i].k * H)));   // + forward K split
+        if (e.planes) e.tn_bytes = std::max(e.tn_bytes, gemm_tn_planes_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]));
+    }
     e.tn = sc.take<float>(e.tn_bytes / sizeof(float));
     e.scratch_bytes = sc.used();
     return CPC_OK;
@@ -549,14 +930,28 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
     c0.N = N; c0.L0 = e.L[0]; c0.L1 = e.L[1]; c0.R0 = e.R[0]; c0.halo = kConv[1].p; c0.eps = eps;
     c0.tiles_per_sample = (int)cdiv(e.L[1], C0_TB);
     c0.n_tiles = N * c0.tiles_per_sample;
-    {
+    for (int i = 1; i < 5; ++i) CPC_REQUIRE(kConv[i].k == 2 * kConv[i].s, "encoder: layer %d needs kernel == 2 * stride", i);
+    if (e.planes) {
+        ProfScope prof(PROF_CONV0_FWD, st);
+        const PlaneOut o{e.Yp[0], e.Yplane[0], log2i(kConv[1].s), e.Yrts[0]};
+        const long rows = (long)kConv[1].s * e.Yrts[0];               // every row of the planes is written (halo, slack: zeros)
+        CPC_DISPATCH_HP(H, hipLaunchKernelGGL(conv0_fwd_pl_kernel<HH>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, c0, o));
+    } else {
         ProfScope prof(PROF_CONV0_FWD, st);
         CPC_DISPATCH_H(H, hipLaunchKernelGGL(conv0_fwd_kernel<HH>, dim3(c0.n_tiles), dim3(256), 0, st, c0));
     }
     CPC_CHECK_LAUNCH("conv0_fwd_kernel");
 
-    // slack rows after each Y_{i-1}: read by junk GEMM rows and by the weight-gradient GEMM -> must be finite
-    {
+    if (e.planes) {
+        PermutePlanes pa{};
+        pa.H = H;
+        for (int i = 1; i < 5; ++i) {
+            pa.w[i - 1] = prm[4 * i]; pa.wf[i - 1] = e.Wfp[i]; pa.wd[i - 1] = e.Wdp[i]; pa.k[i - 1] = kConv[i].k; pa.s[i - 1] = kConv[i].s;
+        }
+        hipLaunchKernelGGL(permute_conv_planes_kernel, dim3(256, 4, 2), dim3(256), 0, st, pa);
+        CPC_CHECK_LAUNCH("permute_conv_planes_kernel");
+    } else {
+        // slack rows after each Y_{i-1}: read by junk GEMM rows and by the weight-gradient GEMM -> must be finite
         ZeroTails zt{};
         for (int i = 1; i < 5; ++i) { zt.p[i - 1] = e.Y[i - 1] + (size_t)N * e.R[i - 1] * H; zt.n[i - 1] = kConv[i].k * H; }
         hipLaunchKernelGGL(zero_tails_kernel, dim3(4), dim3(256), 0, st, zt);
@@ -564,7 +959,6 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
         PermuteAll pa{};
         pa.H = H;
         for (int i = 1; i < 5; ++i) {
-            CPC_REQUIRE(kConv[i].k == 2 * kConv[i].s, "encoder: layer %d needs kernel == 2 * stride", i);
             pa.w[i - 1] = prm[4 * i]; pa.wf[i - 1] = e.Wf[i]; pa.wd[i - 1] = e.Wd[i]; pa.k[i - 1] = kConv[i].k; pa.s[i - 1] = kConv[i].s;
         }
         hipLaunchKernelGGL(permute_conv_all_kernel, dim3(256, 4, 2), dim3(256), 0, st, pa);
@@ -572,20 +966,35 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
     }
     for (int i = 1; i < 5; ++i) {
         const int k = kConv[i].k, s = kConv[i].s;
-        RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk
-        vrows.seg_rows = e.Rv[i]; vrows.seg_valid = e.L[i + 1];
-        vrows.splitk_scratch = e.tn; vrows.splitk_bytes = e.tn_bytes;
-        CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wf[i], (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
-                        k * H, vrows, st));
+        if (e.planes) {
+            // GEMM row m = (sample, frame) over the valid frames only; output row = virtual row of Xh
+            const PlanesOperand A{e.Yp[i - 1], e.Yplane[i - 1], log2i(k), log2i(s), e.Yrts[i - 1], e.L[i + 1], (long)e.Rv[i]};
+            const PlanesOperand B{e.Wfp[i], (long)k * H * H, 0, 0, (long)H, 0, 0};
+            RowMap out{};
+            out.enabled = 1; out.rv = e.L[i + 1]; out.out_stride = 1; out.out_off = 0; out.l_max = e.Rv[i]; out.rows_out = e.Rv[i];
+            CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st));
+        } else {
+            RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk
+            vrows.seg_rows = e.Rv[i]; vrows.seg_valid = e.L[i + 1];
+            vrows.splitk_scratch = e.tn; vrows.splitk_bytes = e.tn_bytes;
+            CPC_TRY(gemm_nt(e.Y[i - 1], (long)s * H, e.Wf[i], (long)k * H, e.Xh[i], H, prm[4 * i + 1], (long)N * e.Rv[i], H,
+                            k * H, vrows, st));
+        }
         NormArgs na{};
         na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
         na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;
         if (i < 4) { na.y = e.Y[i]; na.Rnext = e.R[i]; na.halo = kConv[i + 1].p; }
         else { na.y = z; na.Rnext = e.L[5]; na.halo = 0; }
-        const long rows = (long)N * na.Rnext;
-        const int rpb = 4 * (64 / std::min(64, H / 4));
-        const int blocks = (int)std::min<long>(cdiv(rows, rpb), 4096);
-        CPC_DISPATCH_H(H, hipLaunchKernelGGL(norm_fwd_kernel<HH>, dim3(blocks), dim3(256), 0, st, na));
+        if (e.planes && i < 4) {
+            const PlaneOut o{e.Yp[i], e.Yplane[i], log2i(kConv[i + 1].s), e.Yrts[i]};
+            const long tiles = (long)kConv[i + 1].s * e.Yrts[i] / 16;
+            CPC_DISPATCH_HP(H, hipLaunchKernelGGL(norm_fwd_pl_kernel<HH>, dim3((unsigned)std::min<long>(tiles, 2048)), dim3(256), 0, st, na, o, tiles));
+        } else {
+            const long rows = (long)N * na.Rnext;
+            const int rpb = 4 * (64 / std::min(64, H / 4));
+            const int blocks = (int)std::min<long>(cdiv(rows, rpb), 4096);
+            CPC_DISPATCH_H(H, hipLaunchKernelGGL(norm_fwd_kernel<HH>, dim3(blocks), dim3(256), 0, st, na));
+        }
         CPC_CHECK_LAUNCH("norm_fwd_kernel");
     }
     return CPC_OK;
@@ -605,6 +1014,33 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
         na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;
         na.dy = dy; na.du = e.dU; na.part = e.part;
+        float *dprev = (i % 2 == 0) ? e.dYb : e.dYa;         // i=4 -> dYb, 3 -> dYa, 2 -> dYb, 1 -> dYa
+        if (e.planes) {
+            // dU of layer i as planes: rows of the layer, + the zero rows the weight-gradient product's last step reads
+            const long durows = (cdiv((long)N * e.Rv[i], 32) * 32 + 4 + 15) / 16 * 16;
+            const PlaneOut o{e.dUp, e.dUplane, 0, e.dUrows};
+            CPC_DISPATCH_HP(H, hipLaunchKernelGGL(norm_bwd_pl_kernel<HH>, dim3(NORM_BWD_BLOCKS), dim3(256), 0, st, na, o, durows / 16));
+            CPC_CHECK_LAUNCH("norm_bwd_pl_kernel");
+            CPC_TRY(colsum_split(e.part, NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1], H, e.cs, st));
+            // weight gradient over the virtual rows (dU is zero on a sample's border rows): dW[co][j*H+ci] = sum_m dU(m+1)[co] Y(m s + j)[ci]
+            const PlanesTNOperand TA{e.dUp, e.dUplane, 0, e.dUrows, 1, H};
+            const PlanesTNOperand TB{e.Yp[i - 1], e.Yplane[i - 1], log2i(s), e.Yrts[i - 1], 0, H};
+            CPC_TRY(gemm_tn_planes(TA, TB, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], e.tn, e.tn_bytes, H, k, st));
+            // backward data: rows t_hi = 0 .. L_out - 1 of every sample in whole tiles, then the boundary row t_hi = L_out
+            const PlanesOperand B{e.Wdp[i], (long)k * H * H, 0, 0, (long)s * H, 0, 0};
+            RowMap map{};
+            map.enabled = 1; map.rv = e.L[i + 1]; map.out_stride = s; map.out_off = -p;
+            map.l_max = e.L[i]; map.rows_out = e.L[i]; map.col_rows = H;
+            const PlanesOperand A{e.dUp, e.dUplane, 1, 0, e.dUrows, e.L[i + 1], (long)e.Rv[i]};
+            CPC_TRY(gemm_nt_planes(A, B, dprev, H, nullptr, (long)N * e.L[i + 1], s * H, 2 * H, map, st));
+            RowMap edge{};
+            edge.enabled = 1; edge.rv = 1; edge.out_stride = s; edge.out_off = e.L[i + 1] * s - p;
+            edge.l_max = e.L[i]; edge.rows_out = e.L[i]; edge.col_rows = H;
+            const PlanesOperand Ae{e.dUp + (size_t)e.L[i + 1] * 16, e.dUplane, 1, 0, e.dUrows, 1, (long)e.Rv[i]};
+            CPC_TRY(gemm_nt_planes(Ae, B, dprev, H, nullptr, N, s * H, 2 * H, edge, st));
+            dy = dprev;
+            continue;
+        }
         CPC_DISPATCH_H(H, hipLaunchKernelGGL(norm_bwd_kernel<HH>, dim3(NORM_BWD_BLOCKS), dim3(256), 0, st, na));
         CPC_CHECK_LAUNCH("norm_bwd_kernel");
         // part[block][dgamma | dbeta | dbias] -> the three gradients
@@ -618,7 +1054,6 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         // with the phases side by side in N (Bd is [s*H][2H]); output column j*H + ci of virtual row t_hi is
         // element ci of data row t_hi*s - p + j, i.e. the s*H outputs of a row are contiguous in dY_{i-1}
         // (Bd = e.Wd[i] was laid out by the forward pass)
-        float *dprev = (i % 2 == 0) ? e.dYb : e.dYa;         // i=4 -> dYb, 3 -> dYa, 2 -> dYb, 1 -> dYa
         {
             RowMap map{};
             map.enabled = 1; map.rv = e.Rv[i]; map.out_stride = s; map.out_off = -p;
