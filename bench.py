@@ -48,21 +48,37 @@ GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
 
-def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
-    """Algorithmic FLOPs (2 per MAC) of everything that runs on gemm_nt_kernel in ONE step, and the
-    number of launches (a lower bound: the backward-data products add a one-row-per-window boundary launch where
-    that saves a round of tiles): conv1..4 forward + backward-data (the s phases side by side), GRU input projection
-    + its dX, predictor GEMM + its dC.  Padding / junk virtual rows are NOT counted."""
-    h, n = cfg["hidden"], (b if dedup else 2 * b)
+def encoder_lengths():
     lens = [WINDOW]
     for k, s, p in CONV:
         lens.append((lens[-1] + 2 * p - k) // s + 1)
+    return lens
+
+
+def planes_nt_algorithmic_flops(b, cfg, dedup=False):
+    """Algorithmic FLOPs (2 per MAC) of everything that runs on gemm_planes_kernel<0, false> in ONE step, and its launches:
+    conv1..4 forward and backward-data (the s phases side by side; the boundary row of backward-data is a small VALU
+    kernel and is not counted).  Junk / padding rows are NOT counted."""
+    h, n = cfg["hidden"], (b if dedup else 2 * b)
+    lens = encoder_lengths()
     flops, launches = 0.0, 0
     for i in range(1, 5):
         k, s, _p = CONV[i]
-        conv = 2.0 * n * lens[i + 1] * k * h * h
-        flops += 2 * conv                       # forward + backward-data
+        flops += 2 * (2.0 * n * lens[i + 1] * k * h * h)        # forward + backward-data
         launches += 2
+    return flops, launches
+
+
+def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
+    """Algorithmic FLOPs of what still runs on the split-in-kernel gemm_nt_x6_kernel (operands split while staged): the
+    context network's input projection + its dX, the predictor GEMM + its dC (hidden sizes other than 256 / 512: also the
+    convolutions)."""
+    h, n = cfg["hidden"], (b if dedup else 2 * b)
+    lens = encoder_lengths()
+    flops, launches = 0.0, 0
+    if h % 256 != 0:
+        f, l = planes_nt_algorithmic_flops(b, cfg, dedup)
+        flops, launches = flops + f, launches + l
     t_len = lens[5]
     din = h
     for _layer in range(cfg["layers"]):
@@ -84,6 +100,22 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
         flops += 2 * (2.0 * b * w * cfg["npred"] * h * h)   # P and dC
         launches += 2
     return flops, launches
+
+
+def similarity_algorithmic_flops(b, cfg):
+    """The InfoNCE similarity matmul alone (north_star's kernel target), forward: 2 K W (Nneg + 1) H per window."""
+    w = encoder_lengths()[5] - cfg["npred"]
+    return 2.0 * cfg["npred"] * w * (cfg["nneg"] + 1) * cfg["hidden"] * b
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/summarize_pmc.py from the --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when absent."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return table["kernels"][kernel]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def build(cfg, device):
@@ -220,7 +252,8 @@ def main():
         dist.barrier()
     prof = not args.no_prof
     if prof:
-        lib.cpc_prof_enable(2)              # the roofline kernel only inside the timed region: its launches bracketed by hipEvents
+        roof = "gemm_planes_nt" if cfg["hidden"] % 256 == 0 else "gemm_nt"
+        lib.cpc_prof_enable(2 if roof == "gemm_planes_nt" else 3)   # the roofline kernel only inside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -248,7 +281,7 @@ def main():
                                  "avg_launch_us": round(1e3 * tot.value / cnt.value, 2)}
 
     if prof:
-        read_classes(("gemm_nt",), args.steps)             # measured over the timed region
+        read_classes((roof,), args.steps)                  # measured over the timed region
         # the other classes: a few extra steps after the clock has stopped (timing every class costs ~0.1 ms per step)
         extra = 5
         lib.cpc_prof_enable(1)
@@ -257,8 +290,9 @@ def main():
         torch.cuda.synchronize()
         lib.cpc_prof_enable(0)
         tot, cnt = ctypes.c_double(0), ctypes.c_long(0)
-        lib.cpc_prof_read(b"gemm_nt", ctypes.byref(tot), ctypes.byref(cnt))      # discard: already taken from the timed region
-        read_classes(("gemm_tn", "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd"), extra)
+        lib.cpc_prof_read(roof.encode(), ctypes.byref(tot), ctypes.byref(cnt))   # discard: already taken from the timed region
+        read_classes(tuple(c for c in ("gemm_planes_nt", "gemm_planes_tn", "gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd",
+                                       "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd") if c != roof), extra)
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -275,23 +309,39 @@ def main():
                                                              "reference trainStep semantics (encoder+AR on 2b windows), ")
                                    + "fwd+bwd+allreduce+Adam",
                        "windows_per_gpu": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "final_losses": final_loss},
+                       "parallelism": f"dp{world}", "final_losses": final_loss,
+                       "inputs": "x = 0.05 randn, generator seed 1000 + rank; criterion MT19937 stream seed 1234 + rank; model "
+                                 "init torch.manual_seed(0) on every rank (SURVEY 8d's recipe with per-rank shards)"},
         }
-        if "gemm_nt" in kernels:
-            flops, launches = gemm_nt_algorithmic_flops(args.batch, cfg, args.dedup)
-            k = kernels["gemm_nt"]
+        default_workload = args.batch == 64 and not args.dedup
+        if prof and roof in kernels:
+            planes = roof == "gemm_planes_nt"
+            flops, launches = (planes_nt_algorithmic_flops if planes else gemm_nt_algorithmic_flops)(args.batch, cfg, args.dedup)
+            k = kernels[roof]
             achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_x6_kernel (conv1-4 forward and backward-data, GRU / predictor projections)",
+            kname = "gemm_planes_kernel<0, false>" if planes else "gemm_nt_x6_kernel"
+            out["roofline"] = {"bound": "mfma",
+                               "kernel": kname + (" (conv1-4 forward and backward-data on pre-split bf16 planes)" if planes else
+                                                  " (conv1-4 forward and backward-data, context / predictor projections)"),
                                "achieved": round(achieved, 2), "peak": GEMM_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / GEMM_PEAK_TFLOPS, 4),
                                "peak_note": "algorithmic f32 flops; peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per "
                                             "f32 product (f32-accurate bf16x6 split); the f32 MFMA's own peak is "
                                             f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s",
-                               # HBM bytes per launch from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE KiB, mean over
-                               # the step's 15 launches: profiles/r01_v4_pmc_summary.md), valid for the default workload only
-                               "traffic": 2.60e8 if (args.config == "small" and args.batch == 64 and not args.dedup) else None,
+                               # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes), default workload only
+                               "traffic": measured_traffic(kname + ":" + args.config) if default_workload else None,
                                "algorithmic_gflop_per_launch": round(flops / max(k["launches_per_step"], 1.0) / 1e9, 3),
                                "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
+        if "infonce_fwd" in kernels and cfg.get("rnn", "linear") == "linear":
+            # north_star's one explicit kernel target: the [context x negatives] similarity matmul, >= 60 % of the f32 MFMA peak
+            k = kernels["infonce_fwd"]
+            sim = similarity_algorithmic_flops(args.batch, cfg)
+            ach = sim / (k["ms_per_step"] * 1e-3) / 1e12
+            out["roofline_similarity"] = {"bound": "mfma", "kernel": "infonce_fwd_kernel (gather + similarity + cross-entropy fused)",
+                                          "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                                          "algorithmic_gflop_per_launch": round(sim / 1e9, 3), "avg_launch_us": k["avg_launch_us"],
+                                          "traffic": measured_traffic("infonce_fwd_kernel:" + args.config) if default_workload else None}
         out["kernels"] = kernels
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)

@@ -62,7 +62,7 @@ struct Carver {
 
 // ---- optional in-situ kernel timing (see cpc_prof_* in cpc2_hip.h) ----
 enum ProfSlot { PROF_GEMM_NT = 0, PROF_GEMM_TN, PROF_NCE_FWD, PROF_NCE_BWD, PROF_GRU_FWD, PROF_GRU_BWD, PROF_CONV0_FWD,
-                PROF_CONV0_BWD, PROF_SLOTS };
+                PROF_CONV0_BWD, PROF_PLANES_NT, PROF_PLANES_TN, PROF_SLOTS };
 class ProfScope {
 public:
     ProfScope(int slot, hipStream_t st);
@@ -154,6 +154,7 @@ struct PlanesTNOperand {
 };
 bool gemm_tn_planes_ok(int M, int N, long R);
 size_t gemm_tn_planes_scratch_bytes(int M, int N, long R);
+size_t gemm_nt_planes_scratch_bytes(long M, int N, int K, long out_rows);   // what RowMap::splitk_scratch needs (0: no K split)
 int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
                    size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st);
 

@@ -734,6 +734,43 @@ template <int H> __global__ __launch_bounds__(256) void norm_bwd_pl_kernel(NormA
         a.part[(long)blockIdx.x * 3 * H + c] = (red[c] + red[3 * H + c]) + (red[6 * H + c] + red[9 * H + c]);
 }
 
+// Backward data, boundary rows.  The plane-fed product covers the virtual rows t_hi = 0 .. L_out - 1 of a sample; what
+// is left is t_hi = L_out, whose own dU row is the zero border row, so only dU(L_out - 1) contributes:
+//   dY[n][L_in - p + j][ci] = sum_co dU(n, L_out - 1)[co] * W[co][ci][j + s],  j < p
+// -- N * p rows of H outputs, a dot product of length H each: VALU work on the planes (p0 + p1 + p2 is the f32 value,
+// exactly).  One block per (sample, j); thread = ci (+ 256 per pass); the weights come from the backward-data planes
+// (row j*H + ci, the 16 co of chunk c at K step 2c: consecutive ci are consecutive 32-byte chunks).
+__device__ __forceinline__ float bf16_up(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__global__ __launch_bounds__(256) void bwd_edge_kernel(const unsigned short *dup, long duplane, long durts, const unsigned short *wdp,
+                                                       long wplane, float *dy, int H, int s, int p, int Rv, int Lout, int Lin)
+{
+    extern __shared__ float du[];                           // [H]
+    const int n = blockIdx.x / p, j = blockIdx.x - n * p;
+    const long R = (long)n * Rv + Lout;                      // dU(L_out - 1) is stored one row down
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const long off = ((long)(c >> 4) * durts + R) * 16 + (c & 15);
+        du[c] = (bf16_up(dup[off]) + bf16_up(dup[duplane + off])) + bf16_up(dup[2 * duplane + off]);
+    }
+    __syncthreads();
+    const int rows = s * H;
+    for (int ci = threadIdx.x; ci < H; ci += 256) {
+        float acc = 0.f;
+        for (int c = 0; c < H / 16; ++c) {
+            const long off = ((long)(2 * c) * rows + (long)j * H + ci) * 16;
+            unsigned short w0[16], w1[16], w2[16];
+            *reinterpret_cast<uint4 *>(w0) = *reinterpret_cast<const uint4 *>(wdp + off);
+            *reinterpret_cast<uint4 *>(w0 + 8) = *reinterpret_cast<const uint4 *>(wdp + off + 8);
+            *reinterpret_cast<uint4 *>(w1) = *reinterpret_cast<const uint4 *>(wdp + wplane + off);
+            *reinterpret_cast<uint4 *>(w1 + 8) = *reinterpret_cast<const uint4 *>(wdp + wplane + off + 8);
+            *reinterpret_cast<uint4 *>(w2) = *reinterpret_cast<const uint4 *>(wdp + 2 * wplane + off);
+            *reinterpret_cast<uint4 *>(w2 + 8) = *reinterpret_cast<const uint4 *>(wdp + 2 * wplane + off + 8);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc = fmaf(du[c * 16 + e], (bf16_up(w0[e]) + bf16_up(w1[e])) + bf16_up(w2[e]), acc);
+        }
+        dy[((long)n * Lin + Lin - p + j) * H + ci] = acc;
+    }
+}
+
 // Conv1d weights as the plane-fed GEMMs' B operands (gemm_planes.hip), one launch for all layers:
 // blockIdx.z = 0: forward operand, rows co, K order (chunk c of ci, tap 0, s, 1, s + 1, ...);
 // blockIdx.z = 1: backward-data operand, rows (phase j, ci), K order (chunk c of co, dU row t_hi - 1 then t_hi).
@@ -910,7 +947,9 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
     for (int i = 1; i < 5; ++i) {
         e.tn_bytes = std::max(e.tn_bytes, std::max(gemm_tn_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]),
                                                     gemm_nt_scratch_bytes((long)N * e.Rv[i], H, kConv[i].k * H)));   // + forward K split
-        if (e.planes) e.tn_bytes = std::max(e.tn_bytes, gemm_tn_planes_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]));
+        if (e.planes)
+            e.tn_bytes = std::max(e.tn_bytes, std::max(gemm_tn_planes_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]),
+                                                        gemm_nt_planes_scratch_bytes((long)N * e.L[i + 1], H, kConv[i].k * H, (long)N * e.Rv[i])));
     }
     e.tn = sc.take<float>(e.tn_bytes / sizeof(float));
     e.scratch_bytes = sc.used();
@@ -972,6 +1011,7 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
             const PlanesOperand B{e.Wfp[i], (long)k * H * H, 0, 0, (long)H, 0, 0};
             RowMap out{};
             out.enabled = 1; out.rv = e.L[i + 1]; out.out_stride = 1; out.out_off = 0; out.l_max = e.Rv[i]; out.rows_out = e.Rv[i];
+            out.splitk_scratch = e.tn; out.splitk_bytes = e.tn_bytes;
             CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st));
         } else {
             RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk
@@ -1026,18 +1066,23 @@ static int encoder_backward(const float *x, const float *const *prm, const float
             const PlanesTNOperand TA{e.dUp, e.dUplane, 0, e.dUrows, 1, H};
             const PlanesTNOperand TB{e.Yp[i - 1], e.Yplane[i - 1], log2i(s), e.Yrts[i - 1], 0, H};
             CPC_TRY(gemm_tn_planes(TA, TB, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], e.tn, e.tn_bytes, H, k, st));
-            // backward data: rows t_hi = 0 .. L_out - 1 of every sample in whole tiles, then the boundary row t_hi = L_out
+            // backward data.  Lengths that divide by the stride (training windows): rows t_hi = 0 .. L_out - 1 of every sample
+            // in whole tiles, and a small kernel for the boundary row t_hi = L_out; otherwise all L_out + 1 rows in the product
+            // (the trailing input rows no output frame reads get a zero gradient)
             const PlanesOperand B{e.Wdp[i], (long)k * H * H, 0, 0, (long)s * H, 0, 0};
+            const bool even = e.L[i] == s * e.L[i + 1];
+            const int rows = even ? e.L[i + 1] : e.L[i + 1] + 1;
+            if (!even) CPC_CHECK_HIP(hipMemsetAsync(dprev, 0, sizeof(float) * (size_t)N * e.L[i] * H, st));
             RowMap map{};
-            map.enabled = 1; map.rv = e.L[i + 1]; map.out_stride = s; map.out_off = -p;
+            map.enabled = 1; map.rv = rows; map.out_stride = s; map.out_off = -p;
             map.l_max = e.L[i]; map.rows_out = e.L[i]; map.col_rows = H;
-            const PlanesOperand A{e.dUp, e.dUplane, 1, 0, e.dUrows, e.L[i + 1], (long)e.Rv[i]};
-            CPC_TRY(gemm_nt_planes(A, B, dprev, H, nullptr, (long)N * e.L[i + 1], s * H, 2 * H, map, st));
-            RowMap edge{};
-            edge.enabled = 1; edge.rv = 1; edge.out_stride = s; edge.out_off = e.L[i + 1] * s - p;
-            edge.l_max = e.L[i]; edge.rows_out = e.L[i]; edge.col_rows = H;
-            const PlanesOperand Ae{e.dUp + (size_t)e.L[i + 1] * 16, e.dUplane, 1, 0, e.dUrows, 1, (long)e.Rv[i]};
-            CPC_TRY(gemm_nt_planes(Ae, B, dprev, H, nullptr, N, s * H, 2 * H, edge, st));
+            const PlanesOperand A{e.dUp, e.dUplane, 1, 0, e.dUrows, rows, (long)e.Rv[i]};
+            CPC_TRY(gemm_nt_planes(A, B, dprev, H, nullptr, (long)N * rows, s * H, 2 * H, map, st));
+            if (even) {
+                hipLaunchKernelGGL(bwd_edge_kernel, dim3((unsigned)(N * p)), dim3(256), sizeof(float) * H, st, e.dUp, e.dUplane, e.dUrows,
+                                   e.Wdp[i], (long)k * H * H, dprev, H, s, p, e.Rv[i], e.L[i + 1], e.L[i]);
+                CPC_CHECK_LAUNCH("bwd_edge_kernel");
+            }
             dy = dprev;
             continue;
         }

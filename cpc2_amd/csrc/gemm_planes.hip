@@ -63,7 +63,8 @@ struct PlanesNTArgs {
     RowMap map;
     int tiles_m, tiles_n, xcd_remap;
     int kchunk;                                   // K range per blockIdx.y (multiple of 32)
-    float *slabs;                                 // K split: partial product of blockIdx.y -> slabs + blockIdx.y * M * N
+    float *slabs;                                 // K split: partial product of blockIdx.y -> slabs + blockIdx.y * slab_rows * N
+    long slab_rows;                               // output rows (after the row map)
     int dbg;                                      // probes: 1 no loads after the prologue, 2 no MFMAs, 8 clock stamps
     unsigned long long *stamps;                   // dbg & 8: [workgroup][8] = memtime, memrealtime at loop start and end, ...
 };
@@ -335,7 +336,7 @@ template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_plane
     for (int j = 0; j < 2; ++j) bias_v[j] = (!TN && p.bias != nullptr && blockIdx.y == 0) ? p.bias[nw + j * 32 + r32] : 0.f;
     const int jrow = (p.map.enabled && p.map.col_rows > 0) ? nw / p.map.col_rows : 0;
     const long rv = p.map.enabled ? p.map.rv : (1L << 62);
-    float *const out = TN ? p.slabs + (long)blockIdx.z * p.M * p.N : p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.M * p.N : p.C;
+    float *const out = TN ? p.slabs + (long)blockIdx.z * p.M * p.N : p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.slab_rows * p.N : p.C;
     const long ldo = (TN || p.slabs != nullptr) ? p.N : p.ldc;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -419,9 +420,27 @@ int split_planes(const float *x, long ld, long rows, int cols, bf16_t *planes, l
     return CPC_OK;
 }
 
+__global__ void planes_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k);
+
 bool gemm_nt_planes_ok(long M, int N, int K)
 {
     return N % PT_BN == 0 && K % (2 * PT_BK) == 0 && K >= 4 * PT_BK && M >= 1;
+}
+
+// few tiles and a K long enough: K is split over blockIdx.y so that every CU gets a workgroup (>= 16 stages per split)
+static int nt_planes_splits(long M, int N, int K)
+{
+    const long tiles = cdiv(M, PT_BM) * (N / PT_BN);
+    if (tiles > 160) return 1;
+    int sp = (int)std::min<long>(256 / tiles, K / 256);
+    while (sp > 1 && K % (32 * sp) != 0) --sp;
+    return std::max(sp, 1);
+}
+
+size_t gemm_nt_planes_scratch_bytes(long M, int N, int K, long out_rows)
+{
+    const int sp = nt_planes_splits(M, N, K);
+    return sp > 1 ? align_up((size_t)sp * out_rows * N * sizeof(float), 256) : 0;
 }
 
 static int side_of(const PlanesOperand &o, PlanesSide &s, const char *name)
@@ -455,7 +474,21 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     a.tiles_m = (int)cdiv(M, PT_BM); a.tiles_n = N / PT_BN;
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
     a.xcd_remap = (!no_remap && a.tiles_n > 1 && a.tiles_m % 8 == 0) ? 1 : 0;
-    a.kchunk = K; a.slabs = nullptr;
+    a.kchunk = K; a.slabs = nullptr; a.slab_rows = 0;
+    // few tiles and a K long enough: split K over blockIdx.y (one workgroup per CU), partial products to slabs that a
+    // second kernel adds in a fixed order -- when the caller lent the room (RowMap::splitk_scratch)
+    int splits = 1;
+    {
+        const long out_rows = map.enabled ? cdiv(M, map.rv) * map.rows_out : M;
+        const int sp = nt_planes_splits(M, N, K);
+        if (sp > 1 && map.splitk_scratch != nullptr && (!map.enabled || map.col_rows == 0) &&
+            reinterpret_cast<uintptr_t>(map.splitk_scratch) % 16 == 0 && (size_t)sp * out_rows * N * sizeof(float) <= map.splitk_bytes) {
+            splits = sp;
+            a.kchunk = K / sp;
+            a.slabs = static_cast<float *>(map.splitk_scratch);
+            a.slab_rows = out_rows;
+        }
+    }
     a.dbg = getenv("CPC_PLANES_DBG") ? atoi(getenv("CPC_PLANES_DBG")) : 0;
     static unsigned long long *stamps = nullptr;
     if (a.dbg & 8) {
@@ -463,11 +496,17 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
         a.stamps = stamps;
     }
     const long blocks = (long)a.tiles_m * a.tiles_n;
-    ProfScope prof(PROF_GEMM_NT, st);
-    if ((a.dbg & 3) == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, false>), dim3((unsigned)blocks, 1), dim3(512), PT_LDS, st, a);
-    else if ((a.dbg & 3) == 2) hipLaunchKernelGGL((gemm_planes_kernel<2, false>), dim3((unsigned)blocks, 1), dim3(512), PT_LDS, st, a);
-    else hipLaunchKernelGGL((gemm_planes_kernel<0, false>), dim3((unsigned)blocks, 1), dim3(512), PT_LDS, st, a);
+    ProfScope prof(PROF_PLANES_NT, st);
+    if ((a.dbg & 3) == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
+    else if ((a.dbg & 3) == 2) hipLaunchKernelGGL((gemm_planes_kernel<2, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_planes_kernel<0, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");
+    if (splits > 1) {
+        const long total = a.slab_rows * N;
+        hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, st, a.slabs, splits,
+                           (int)a.slab_rows, N, C, ldc, 0, 0);
+        CPC_CHECK_LAUNCH("planes split-K reduce");
+    }
     if (a.dbg & 8) {
         static unsigned long long host[65536 * 8];
         CPC_CHECK_HIP(hipStreamSynchronize(st));
@@ -552,7 +591,7 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     a.M = M; a.N = N; a.K = 0; a.slabs = static_cast<float *>(scratch);
     a.dbg = 0;
     {
-        ProfScope prof(PROF_GEMM_TN, st);
+        ProfScope prof(PROF_PLANES_TN, st);
         hipLaunchKernelGGL((gemm_planes_kernel<0, true>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
                            st, a);
     }

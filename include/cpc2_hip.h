@@ -46,9 +46,10 @@ const char *cpc_last_error(void);
 
 /* In-situ kernel timing for bench.py: when enabled, the launchers bracket each launch of the named
  * kernel class with hipEvents on the launch stream.  cpc_prof_read sums and releases the finished
- * records of one class: "gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd",
- * "conv0_fwd", "conv0_bwd" ("gru_*" times whichever recurrent kernel runs: GRU, LSTM or RNN).  on = 1: every
- * class; on = 2: "gemm_nt" only (the events cost about 0.1 ms per step when every class is timed); 0 (default): off. */
+ * records of one class: "gemm_planes_nt", "gemm_planes_tn" (the plane-fed products of the encoder), "gemm_nt", "gemm_tn"
+ * (the split-in-kernel products), "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd" ("gru_*"
+ * times whichever recurrent kernel runs: GRU, LSTM or RNN).  on = 1: every class; on = 2: "gemm_planes_nt" only, on = 3:
+ * "gemm_nt" only (the events cost about 0.1 ms per step when every class is timed); 0 (default): off. */
 int cpc_prof_enable(int on);
 int cpc_prof_read(const char *name, double *total_ms, long *count);
 
