@@ -257,6 +257,41 @@ class _InfoNCEPredFn(torch.autograd.Function):
         return (dz, None, None, None) + tuple(dpreds)
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T on the library's GEMMs (x [..., K], W [N, K]): the predictions of the linear predictors as tensors, for the
+    paths that need them outside the fused kernel (predictor dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        require_gpu(x, weight)
+        lib = _lib.load()
+        x2 = f32c(x).reshape(-1, x.shape[-1])
+        w = f32c(weight.detach())
+        m, kdim = x2.shape
+        n = w.shape[0]
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        check(lib.cpc_gemm_nt(ptr(x2), kdim, ptr(w), kdim, ptr(y), n, None, m, n, kdim, stream_ptr(x.device)), "gemm_nt")
+        ctx.save_for_backward(x2, w)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, w = ctx.saved_tensors
+        m, kdim = x2.shape
+        n = w.shape[0]
+        dy2 = f32c(dy).reshape(m, n)
+        wt = w.t().contiguous()                                     # [K, N]: the NT form's B operand of dx = dy W
+        dx = torch.empty(m, kdim, dtype=torch.float32, device=dy.device)
+        check(lib.cpc_gemm_nt(ptr(dy2), n, ptr(wt), n, ptr(dx), kdim, None, m, kdim, n, stream_ptr(dy.device)), "gemm_nt")
+        dw = torch.empty(n, kdim, dtype=torch.float32, device=dy.device)
+        nb = lib.cpc_gemm_tn_scratch_bytes(n, kdim, m)
+        sc = scratch(nb, dy.device)
+        check(lib.cpc_gemm_tn(ptr(dy2), n, ptr(x2), kdim, ptr(dw), kdim, n, kdim, m, ptr(sc), nb, stream_ptr(dy.device)), "gemm_tn")
+        return dx.view(ctx.xshape), dw
+
+
 # --------------------------------------------------------------------------- modules
 class PredictionNetwork(nn.Module):
     """criterion.py:97-173: K predictors under `predictors` (same keys / init as the reference):
@@ -270,12 +305,12 @@ class PredictionNetwork(nn.Module):
         if rnnMode in ("ffd", "conv4", "conv8", "conv12"):
             raise NotImplementedError(
                 f"rnnMode={rnnMode!r}: only 'linear', 'transformer', 'LSTM' and 'RNN' predictors have an MI355X kernel path")
-        if dropout:
-            raise NotImplementedError("predictor dropout is not supported by the MI355X hot path")
         self.predictors = nn.ModuleList()
         self.RESIDUAL_STD = 0.01
         self.dimOutputAR = dimOutputAR
-        self.dropout = None
+        # criterion.py:113,168-169: nn.Dropout(0.5) on every prediction in training mode.  The mask comes from torch's
+        # generator of the prediction's device (as in the reference's own GPU run: not reproducible against a CPU run)
+        self.dropout = nn.Dropout(p=0.5) if dropout else None
         self.rnnMode = rnnMode
         if rnnMode == 'transformer':
             from .transformers import buildTransformerAR
@@ -314,11 +349,9 @@ class MultiHeadPredictionNetwork(nn.Module):
             if rnnMode == 'transformer_adaptive_span':
                 raise NotImplementedError("rnnMode='transformer_adaptive_span' is not on the MI355X hot path")
             raise ValueError(f"unknown mode {rnnMode}")
-        if dropout:
-            raise NotImplementedError("predictor dropout is not supported by the MI355X hot path")
         from .transformers import buildMultHeadTransformerAR
         self.dimOutputAR = dimOutputAR
-        self.dropout = None
+        self.dropout = nn.Dropout(p=0.5) if dropout else None      # criterion.py:63,86-87
         self.nPredicts = nPredicts
         self.rnnMode = 'transformer_multi'
         self.predictor = buildMultHeadTransformerAR(dimOutputEncoder, dimOutputAR, nLayers=1, sizeSeq=sizeInputSeq,
@@ -395,6 +428,96 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         return self.sampler.sample(batchSize, nNegativeExt, windowSize, self.negativeSamplingExt, device,
                                    time_major=time_major)
 
+    def _predictions(self, cW):
+        """The K prediction tensors [b, W, dim_enc] of the predictor modules on cW = c[:, :W] (criterion.py:161-169), or
+        None when the predictors are linear and no dropout is active: the fused kernel then computes them itself."""
+        net = self.wPrediction
+        drop = net.dropout if (net.dropout is not None and self.training) else None
+        if net.rnnMode == 'transformer_multi':
+            preds = list(torch.unbind(net.predictor(cW), dim=2))            # criterion.py:85 prediction[:, :, k]
+        elif net.rnnMode in ('transformer', 'LSTM', 'RNN'):
+            preds = [predictor(cW) for predictor in net.predictors]
+            preds = [p[0] if isinstance(p, tuple) else p for p in preds]   # criterion.py:164-165
+        elif drop is not None:
+            preds = [_LinearFn.apply(cW, predictor.weight) for predictor in net.predictors]
+        else:
+            return None
+        if drop is not None:
+            preds = [drop(p) for p in preds]                                # criterion.py:168-169
+        return preds
+
+    def sampleClean(self, encodedData, windowSize):
+        """criterion.py:237-286: the K candidate tensors [b, 1 + negativeSamplingExt, windowSize, dimEncoded] (positive first)
+        and the all-zero labels.  The negative indices are the reference's, bit for bit (same generator stream, same
+        order); the rows are gathered on the device.  The training step never calls this -- its kernel gathers on the
+        fly -- it is the reference's inspection API."""
+        batchSize, nNegativeExt, dimEncoded = encodedData.size()
+        extIdx = self.sampler.sample(batchSize, nNegativeExt, windowSize, self.negativeSamplingExt, encodedData.device,
+                                     time_major=False).long()
+        rows = encodedData.contiguous().view(-1, dimEncoded)
+        negExt = rows.index_select(0, extIdx).view(batchSize, self.negativeSamplingExt, windowSize, dimEncoded)
+        labelLoss = torch.zeros(batchSize * windowSize, dtype=torch.long, device=encodedData.device)
+        outputs = []
+        for k in range(1, self.nPredicts + 1):
+            posSeq = encodedData[:, k:k + windowSize].reshape(batchSize, 1, windowSize, dimEncoded)
+            outputs.append(torch.cat((posSeq, negExt), dim=1))
+        return outputs, labelLoss
+
+    def _logits(self, cFeature, encodedData, extIdx, n_neg):
+        """float [b, W, K, 1 + n_neg] straight from the fused forward kernel (no loss, no graph)."""
+        lib = _lib.load()
+        with torch.no_grad():
+            windowSize = cFeature.size(1) - self.nPredicts
+            preds = self._predictions(cFeature[:, :windowSize].contiguous())
+            z = f32c(encodedData)
+            b, t, dim_enc = z.shape
+            k = self.nPredicts
+            losses = torch.empty(k, dtype=torch.float32, device=z.device)
+            acc = torch.empty(k, dtype=torch.float32, device=z.device)
+            dim_ar = dim_enc if preds is not None else cFeature.size(2)
+            nsaved = lib.cpc_infonce_saved_bytes(b, t, k, dim_ar, dim_enc, n_neg)
+            if nsaved == 0:
+                check(-1, "infonce shape query")
+            saved = torch.empty(nsaved, dtype=torch.uint8, device=z.device)
+            sc = scratch(lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg), z.device)
+            if preds is None:
+                c = f32c(cFeature)
+                wpred = torch.stack([f32c(p.weight.detach()) for p in self.wPrediction.predictors], dim=0)
+                check(lib.cpc_infonce_forward(ptr(c), ptr(z), ptr(wpred), ptr(extIdx), None, ptr(losses), ptr(acc), ptr(saved),
+                                              ptr(sc), b, t, k, dim_ar, dim_enc, n_neg, stream_ptr(z.device)), "infonce_forward")
+            else:
+                preds = [f32c(p) for p in preds]
+                check(lib.cpc_infonce_forward_pred(_lib.ptr_array(preds), ptr(z), ptr(extIdx), None, ptr(losses), ptr(acc),
+                                                   ptr(saved), ptr(sc), b, t, k, dim_enc, n_neg, stream_ptr(z.device)),
+                      "infonce_forward_pred")
+            off = lib.cpc_infonce_logits_offset(b, t, k, dim_ar, dim_enc, n_neg)
+            n = b * windowSize * k * (n_neg + 1)
+            return saved[off:off + 4 * n].view(torch.float32).view(b, windowSize, k, n_neg + 1).clone()
+
+    def getPrediction(self, cFeature, encodedData, label):
+        """criterion.py:291-302: the K score tensors [b, 1 + negativeSamplingExt, W] (candidate 0 = the positive; score =
+        mean over channels of prediction * candidate) and the all-zero labels, computed by the fused forward kernel --
+        the candidate tensors are not built.  Detached: training goes through forward()."""
+        require_gpu(cFeature, encodedData)
+        cFeature, encodedData = self._prepare(cFeature, encodedData)
+        batchSize, seqSize, _ = cFeature.size()
+        windowSize = seqSize - self.nPredicts
+        extIdx = self.sampleIndices(batchSize, seqSize, windowSize, cFeature.device)
+        logits = self._logits(cFeature, encodedData, extIdx, self.negativeSamplingExt)
+        labelLoss = torch.zeros(batchSize * windowSize, dtype=torch.long, device=cFeature.device)
+        return [logits[:, :, k].transpose(1, 2).contiguous() for k in range(self.nPredicts)], labelLoss
+
+    def getCosineDistances(self, cFeature, encodedData):
+        """criterion.py:304-327: the positive candidate's score alone, K tensors [b, 1, W].  No negative is drawn (the
+        generator stream is left untouched): the kernel runs with one dummy negative per position, whose score is dropped."""
+        require_gpu(cFeature, encodedData)
+        cFeature, encodedData = self._prepare(cFeature, encodedData)
+        batchSize, seqSize, _ = cFeature.size()
+        windowSize = seqSize - self.nPredicts
+        dummy = torch.zeros(batchSize * windowSize, dtype=torch.int32, device=cFeature.device)
+        logits = self._logits(cFeature, encodedData, dummy, 1)
+        return [logits[:, :, k, :1].transpose(1, 2).contiguous() for k in range(self.nPredicts)]
+
     def forward(self, cFeature, encodedData, label, signal_quality=None):
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
@@ -405,17 +528,15 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         else:
             quality_weighting = None                    # ones (criterion.py:340)
         extIdx = self.sampleIndices(batchSize, seqSize, windowSize, cFeature.device)
-        if self.wPrediction.rnnMode == 'transformer_multi':
-            cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
-            preds = torch.unbind(self.wPrediction.predictor(cW), dim=2)    # criterion.py:85 prediction[:, :, k]
-            losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
-        elif self.wPrediction.rnnMode in ('transformer', 'LSTM', 'RNN'):
-            cW = cFeature[:, :windowSize].contiguous()                     # criterion.py:297
-            preds = [predictor(cW) for predictor in self.wPrediction.predictors]
-            preds = [p[0] if isinstance(p, tuple) else p for p in preds]   # criterion.py:164-165
+        preds = self._predictions(cFeature[:, :windowSize].contiguous()) if self._needs_modules() else None
+        if preds is not None:
             losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
         else:
             losses, acc = _InfoNCEFn.apply(cFeature, encodedData, extIdx, quality_weighting, self.negativeSamplingExt,
                                            *[p.weight for p in self.wPrediction.predictors])
         losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
         return losses.view(1, -1), acc.view(1, -1)
+
+    def _needs_modules(self):
+        net = self.wPrediction
+        return net.rnnMode in ('transformer_multi', 'transformer', 'LSTM', 'RNN') or (net.dropout is not None and self.training)

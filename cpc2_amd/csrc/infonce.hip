@@ -747,6 +747,14 @@ extern "C" size_t cpc_infonce_saved_bytes(int b, int t, int k, int dim_ar, int d
     return l.saved_bytes;
 }
 
+extern "C" size_t cpc_infonce_logits_offset(int b, int t, int k, int dim_ar, int dim_enc, int n_neg)
+{
+    cpc::NceLayout l;
+    char *const base = reinterpret_cast<char *>(4096);   // a fake base, never dereferenced: the layout only does arithmetic
+    if (cpc::nce_layout(l, b, t, k, dim_ar, dim_enc, n_neg, base, nullptr) != CPC_OK) return (size_t)-1;
+    return (size_t)(reinterpret_cast<char *>(l.logits) - base);
+}
+
 extern "C" size_t cpc_infonce_scratch_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg)
 {
     cpc::NceLayout l;

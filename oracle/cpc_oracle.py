@@ -305,6 +305,35 @@ def criterion_forward(c, z, predictors, ext_idx, n_neg, mode=None, n_skipped=0, 
     return torch.cat(losses, dim=1), torch.cat(accs, dim=1) / (w_len * b)
 
 
+def candidates(z, ext_idx, n_neg, k_steps):
+    """sampleClean (criterion.py:237-286) given the indices: K tensors [b, 1 + n_neg, W, Henc], positive first."""
+    b, t_len, h_enc = z.shape
+    w_len = t_len - k_steps
+    idx = torch.as_tensor(np.asarray(ext_idx), dtype=torch.long)
+    neg = z.reshape(-1, h_enc)[idx].view(b, n_neg, w_len, h_enc)
+    return [torch.cat([z[:, k:k + w_len].unsqueeze(1), neg], dim=1) for k in range(1, k_steps + 1)]
+
+
+def prediction_scores(c, z, predictors, ext_idx, n_neg, mode=None):
+    """getPrediction (criterion.py:291-302): K score tensors [b, 1 + n_neg, W] = mean over channels of
+    prediction * candidate.  ext_idx None: getCosineDistances (:304-327), the positive alone, [b, 1, W]."""
+    if mode == "reverse":
+        z = torch.flip(z, [1])
+        c = torch.flip(c, [1])
+    k_steps = len(predictors)
+    w_len = z.shape[1] - k_steps
+    c = c[:, :w_len]
+    if ext_idx is None:
+        cands = [z[:, k:k + w_len].unsqueeze(1) for k in range(1, k_steps + 1)]
+    else:
+        cands = candidates(z, ext_idx, n_neg, k_steps)
+    out = []
+    for wk, cand in zip(predictors, cands):
+        pred = (wk(c) if callable(wk) else c @ wk.t()).unsqueeze(1)
+        out.append((pred * cand).mean(dim=3))
+    return out
+
+
 # --------------------------------------------------------------------------- #
 # Adam (torch.optim.Adam defaults as used at train.py:477-479: no weight decay, no amsgrad)
 # --------------------------------------------------------------------------- #

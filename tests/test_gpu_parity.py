@@ -31,9 +31,17 @@ def rel_err(got, ref):
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
 
 
-def assert_close(got, ref, tol, what=""):
+def assert_close(got, ref, tol, what="", rtol=None):
+    """max-norm check |got - ref|_inf <= tol * |ref|_inf AND, element by element, |got - ref| <= atol + rtol * |ref| with
+    atol = tol * |ref|_inf (rounding noise scales with the largest terms of a sum) and rtol = 64 * tol by default: a
+    small element may be off by the noise floor, but not arbitrarily."""
     e = rel_err(got, ref)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+    g, r = got.detach().double().cpu(), ref.detach().double().cpu()
+    atol = tol * float(r.abs().max()) + 1e-30
+    rt = 64 * tol if rtol is None else rtol
+    bad = (g - r).abs() > atol + rt * r.abs()
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} of {bad.numel()} elements outside atol {atol:.2e} + {rt:.1e} |ref|"
 
 
 def load_encoder(hidden, params):
@@ -1186,3 +1194,170 @@ def test_train_step_with_signal_quality_files(tmp_path):
     assert not torch.allclose(weighted, plain)
     logs = trainStep(loader, model, crit, opt, None, 1000)
     assert logs["iter"] >= 5 and np.isfinite(logs["locLoss_train"]).all()
+
+
+# ----------------------------------------------------------------------------- criterion, inference-side API (g16)
+@pytest.mark.parametrize("tag,mode", [("plain", None), ("reverse", "reverse")])
+def test_get_prediction_cosine_sample_clean_vs_reference_golden(golden, tag, mode):
+    """getPrediction / getCosineDistances / sampleClean of the reference (criterion.py:237-327) on the HIP kernels."""
+    g = golden("g16_criterion_inference.npz")
+    crit = make_criterion(4, 32, 32, 16, 50, mode=mode).eval()
+    c = synth.features((4, 32, 32), 51).to(DEV)
+    z = synth.features((4, 32, 32), 52, relu=True).to(DEV)
+    torch.manual_seed(99)
+    preds, label = crit.getPrediction(c, z, None)
+    assert len(preds) == 4 and preds[0].shape == (4, 17, 28) and label.dtype == torch.long and label.shape == (4 * 28,)
+    assert int(label.abs().sum()) == 0
+    assert_close(torch.stack(preds), t(g[f"{tag}_pred"]), 2e-6, "getPrediction")
+    # the CPU generator was advanced exactly as by the reference's call
+    assert torch.equal(torch.randint(0, 1000, (4,)), t(g[f"{tag}_next_draws"]))
+    state = torch.get_rng_state()
+    cos = crit.getCosineDistances(c, z)
+    assert torch.equal(torch.get_rng_state(), state), "getCosineDistances must not draw"
+    assert cos[0].shape == (4, 1, 28)
+    assert_close(torch.stack(cos), t(g[f"{tag}_cos"]), 2e-6, "getCosineDistances")
+    torch.manual_seed(99)
+    cands, lab2 = crit.sampleClean(z, 28)
+    assert len(cands) == 4 and torch.equal(cands[0].cpu(), t(g[f"{tag}_cand_first"])) and torch.equal(cands[-1].cpu(), t(g[f"{tag}_cand_last"]))
+    assert lab2.shape == (4 * 28,) and int(lab2.abs().sum()) == 0
+
+
+def test_get_prediction_is_what_forward_scores():
+    """CE of getPrediction's scores == forward()'s losses (same negatives), also with module predictors."""
+    for rnn in ("linear", "transformer"):
+        torch.manual_seed(3)
+        crit = cpc2_amd.CPCUnsupersivedCriterion(4, 64, 64, 16, rnnMode=rnn, sizeInputSeq=32).to(DEV).eval()
+        c = synth.features((3, 32, 64), 71).to(DEV)
+        z = synth.features((3, 32, 64), 72, relu=True).to(DEV)
+        crit.seed(11)
+        losses, acc = crit(c, z, None)
+        crit.seed(11)
+        preds, label = crit.getPrediction(c, z, None)
+        for k in range(4):
+            lg = preds[k].permute(0, 2, 1).reshape(-1, 17)
+            ce = torch.nn.functional.cross_entropy(lg, label)
+            assert abs(float(ce) - float(losses[0, k])) <= 2e-5 * abs(float(ce)), (rnn, k)
+            assert abs(float((lg.argmax(1) == 0).float().mean()) - float(acc[0, k])) <= 1.5 / lg.shape[0]
+
+
+def test_cpc_module_matches_its_parts():
+    """CPCModule (feature_loader.py:57-82) = model -> criterion scores -> softmax over the candidates."""
+    from cpc2_amd.feature_loader import CPCModule
+    model, _mp = _small_model()
+    crit = make_criterion(12, 64, 64, 16, 23).eval()
+    x = synth.audio_windows(2, 20480, 24)
+    full = CPCModule(model.eval(), crit, main_distance_only=False, n_pred=-1)
+    main = CPCModule(model.eval(), crit, main_distance_only=True, n_pred=2)
+    assert full.getDownsamplingFactor() == 160
+    crit.seed(5)
+    probs = full((x, None))
+    assert probs.shape == (2, 17, 116) and torch.allclose(probs.sum(1), torch.ones(2, 116, device=DEV), atol=1e-5)
+    with torch.no_grad():
+        cf, ef, _ = model(x.to(DEV), None)
+    crit.seed(5)
+    ref = torch.softmax(crit.getPrediction(cf, ef, None)[0][-1], dim=1)
+    assert torch.equal(probs, ref)
+    d = main((x, None))
+    assert d.shape == (2, 1, 116) and torch.equal(d, crit.getCosineDistances(cf, ef)[2])
+    # against the oracle: the positive's score of step 3
+    p64 = to64(_mp)
+    c64, z64 = O.model_forward(x.double(), p64)
+    preds = [crit.wPrediction.predictors[i].weight.detach().double().cpu() for i in range(12)]
+    want = O.prediction_scores(c64, z64, preds, None, 16)[2]
+    assert_close(d, want, 5e-5, "main distance vs oracle")
+
+
+def test_predictor_dropout_trains_and_is_off_in_eval():
+    """dropout=True (criterion.py:113,168-169): nn.Dropout(0.5) on the predictions in training mode only."""
+    crit = cpc2_amd.CPCUnsupersivedCriterion(4, 64, 64, 16, rnnMode="linear", dropout=True, sizeInputSeq=32).to(DEV)
+    ref = cpc2_amd.CPCUnsupersivedCriterion(4, 64, 64, 16, rnnMode="linear", dropout=False, sizeInputSeq=32).to(DEV)
+    ref.load_state_dict(crit.state_dict())
+    assert isinstance(crit.wPrediction.dropout, torch.nn.Dropout) and crit.wPrediction.dropout.p == 0.5
+    c = synth.features((3, 32, 64), 81).to(DEV).requires_grad_(True)
+    z = synth.features((3, 32, 64), 82, relu=True).to(DEV).requires_grad_(True)
+    crit.eval(); ref.eval()
+    crit.seed(7); ref.seed(7)
+    assert torch.equal(crit(c, z, None)[0], ref(c, z, None)[0])           # eval: identity
+    crit.train()
+    crit.seed(7)
+    torch.manual_seed(0)
+    la, _ = crit(c, z, None)
+    la.sum().backward()
+    assert torch.isfinite(la).all() and c.grad is not None and torch.isfinite(c.grad).all()
+    g = [p.weight.grad for p in crit.wPrediction.predictors]
+    assert all(x is not None and torch.isfinite(x).all() and float(x.abs().max()) > 0 for x in g)
+    # the training-mode value is the no-dropout criterion applied to predictions masked by the same draw
+    crit.seed(7)
+    torch.manual_seed(0)
+    cw = c[:, :28].detach()
+    masked = [crit.wPrediction.dropout(torch.nn.functional.linear(cw, p.weight.detach())) for p in crit.wPrediction.predictors]
+    from cpc2_amd.criterion import _InfoNCEPredFn
+    ext = crit.sampleIndices(3, 32, 28, DEV)
+    lb, _ = _InfoNCEPredFn.apply(z.detach(), ext, None, 16, *masked)
+    assert_close(la.view(-1), lb.view(-1), 2e-5, "dropout path")
+
+
+# ----------------------------------------------------------------------------- feature extraction (f3)
+def test_build_feature_batch_and_streaming():
+    """buildFeature_batch (feature_loader.py:370-433) == chunk-wise model calls; buildFeature streams a keepHidden model."""
+    from cpc2_amd import audio
+    from cpc2_amd.feature_loader import FeatureModule, buildFeature, buildFeature_batch
+    model, mp = _small_model()
+    path = os.path.join(GOLD_DB, "4397", "15668", "4397-15668-0003.flac")
+    wav = audio.load(path)[0]
+    n = wav.shape[1]
+    fm = FeatureModule(model, False).eval()
+    p64 = to64(mp)
+    for strict in (False, True):
+        got = buildFeature_batch(fm, path, strict=strict, maxSizeSeq=8000, batch_size=8)
+        ref = []
+        n_full = n // 8000
+        for i in range(n_full):
+            ref.append(O.model_forward(wav[:, i * 8000:(i + 1) * 8000].double().view(1, 1, -1), p64)[0])
+        rest = n % 8000
+        if rest >= 160:
+            if strict:
+                ref.append(O.model_forward(wav[:, -8000:].double().view(1, 1, -1), p64)[0][:, -(rest // 160):])
+            else:
+                ref.append(O.model_forward(wav[:, -rest:].double().view(1, 1, -1), p64)[0])
+        ref = torch.cat(ref, dim=1)
+        assert got.shape == ref.shape
+        assert_close(got, ref, 5e-5, f"buildFeature_batch strict={strict}")
+    # batch size does not matter; seqNorm normalises each chunk
+    a = buildFeature_batch(fm, path, maxSizeSeq=8000, batch_size=3, seqNorm=True)
+    b = buildFeature_batch(fm, path, maxSizeSeq=8000, batch_size=64, seqNorm=True)
+    assert torch.allclose(a, b, atol=1e-5)
+    assert float(a[:, :50].mean(dim=1).abs().max()) < 1e-4
+    # keepHidden: chunked streaming through buildFeature == one pass over the whole file
+    ks = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(64), cpc2_amd.CPCAR(64, 64, True, 1))
+    ks.load_state_dict(mp)
+    ks = ks.to(DEV).eval()
+    whole_len = (n // 16000) * 16000                       # chunk borders on frame borders: the encoder sees the same frames
+    streamed = buildFeature(FeatureModule(ks, False).eval(), wav[:, :whole_len], maxSizeSeq=16000)
+    ks.gAR.hidden = None
+    with torch.no_grad():
+        z_chunks = [ks.gEncoder(wav[:, s:s + 16000].view(1, 1, -1).to(DEV)).permute(0, 2, 1) for s in range(0, whole_len, 16000)]
+        ks.gAR.hidden = None
+        whole = ks.gAR(torch.cat(z_chunks, dim=1)).cpu()
+    assert streamed.shape == whole.shape
+    assert_close(streamed, whole, 2e-5, "keepHidden streaming")
+
+
+def test_reference_written_checkpoint_loads_into_hip_modules(golden):
+    """tests/golden/ref_checkpoint was written by the reference's classes (tools/make_golden.py g17): loadModel builds the
+    HIP modules from its args and weights; outputs match what the reference computed."""
+    from cpc2_amd.feature_loader import getCheckpointData, loadModel
+    g = golden("g17_ref_checkpoint_outputs.npz")
+    run = os.path.join(os.path.dirname(GOLD_DB), "ref_checkpoint")
+    path, logs, args = getCheckpointData(run)
+    assert path.endswith("checkpoint_7.pt") and logs["epoch"] == [7] and args.hiddenEncoder == 32
+    model, h_ar, h_enc = loadModel([path])
+    assert (h_ar, h_enc) == (32, 32)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        c, z, _ = model(t(g["x"]).to(DEV), None)
+    assert_close(z, t(g["z"]), 2e-5, "encoder of the reference checkpoint")
+    assert_close(c, t(g["c"]), 5e-5, "context of the reference checkpoint")
+    crit = cpc2_amd.CPCUnsupersivedCriterion(args.nPredicts, args.hiddenGar, args.hiddenEncoder, args.negativeSamplingExt,
+                                             rnnMode=args.rnnMode, sizeInputSeq=args.sizeWindow // 160)
+    crit.load_state_dict(torch.load(path, "cpu")["cpcCriterion"])

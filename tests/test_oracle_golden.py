@@ -339,3 +339,26 @@ def test_transformer_variants(golden, tag):
     for k, v in p.items():
         ref = t(g[tag + "_grad." + layer + k[len("gAR.0."):]])
         assert torch.allclose(v.grad, ref, atol=2e-5 * float(ref.abs().max()) + 1e-7, rtol=1e-4), k
+
+
+# ----------------------------------------------------------------------------- G16 criterion, inference-side API
+@pytest.mark.parametrize("tag,mode", [("plain", None), ("reverse", "reverse")])
+def test_prediction_scores_and_candidates(golden, tag, mode):
+    """getPrediction / getCosineDistances / sampleClean (criterion.py:237-327) restated by the oracle."""
+    g = golden("g16_criterion_inference.npz")
+    b, t_len, har, henc, k, nn, seed, pseed = 4, 32, 32, 32, 4, 16, 99, 50
+    p = synth.predictor_params(k, har, henc, seed=pseed, scale=4.0)
+    c = synth.features((b, t_len, har), pseed + 1)
+    z = synth.features((b, t_len, henc), pseed + 2, relu=True)
+    mt = MT19937(seed)
+    _, _, ext = negative_indices(mt, b, t_len, t_len - k, nn)
+    scores = O.prediction_scores(c, z, O.predictor_list(p, k), ext, nn, mode=mode)
+    assert torch.allclose(torch.stack(scores), t(g[f"{tag}_pred"]), atol=1e-7, rtol=2e-6)
+    assert (g[f"{tag}_label"] == 0).all() and g[f"{tag}_label"].shape == (b * (t_len - k),)
+    # the generator stands where the reference's stood after the call
+    assert np.array_equal(mt.randint(0, 1000, 4), g[f"{tag}_next_draws"])
+    cos = O.prediction_scores(c, z, O.predictor_list(p, k), None, nn, mode=mode)
+    assert torch.allclose(torch.stack(cos), t(g[f"{tag}_cos"]), atol=1e-7, rtol=2e-6)
+    # sampleClean is called on the tensors as given (no flip): candidates of the unflipped z
+    cands = O.candidates(z, ext, nn, k)
+    assert torch.equal(cands[0], t(g[f"{tag}_cand_first"])) and torch.equal(cands[-1], t(g[f"{tag}_cand_last"]))

@@ -500,7 +500,65 @@ def g15():
     save("g15_bidirectional_ar.npz", **d)
 
 
+# ------------------------------------------------------------------ G16 criterion, inference-side API
+def g16():
+    """getPrediction / getCosineDistances / sampleClean (criterion.py:237-327) on the g5 'plain' / 'reverse' setting."""
+    b, t_len, har, henc, k, nn, seed, pseed = 4, 32, 32, 32, 4, 16, 99, 50
+    d = {}
+    for tag, mode in (("plain", None), ("reverse", "reverse")):
+        crit = ref_crit.CPCUnsupersivedCriterion(k, har, henc, nn, mode=mode, rnnMode="linear", sizeInputSeq=t_len)
+        crit.load_state_dict(synth.predictor_params(k, har, henc, seed=pseed, scale=4.0))
+        c = synth.features((b, t_len, har), seed=pseed + 1)
+        z = synth.features((b, t_len, henc), seed=pseed + 2, relu=True)
+        with torch.no_grad():
+            torch.manual_seed(seed)
+            preds, label = crit.getPrediction(c, z, None)
+            after_pred = torch.randint(0, 1000, (4,))            # where the generator stands after the call
+            cos = crit.getCosineDistances(c, z)
+            torch.manual_seed(seed)
+            cands, label2 = crit.sampleClean(z, t_len - k)
+        d[f"{tag}_pred"] = torch.stack(preds)                       # [K, b, 1 + nn, W]
+        d[f"{tag}_label"] = label
+        d[f"{tag}_next_draws"] = after_pred
+        d[f"{tag}_cos"] = torch.stack(cos)                          # [K, b, 1, W]
+        d[f"{tag}_cand_first"], d[f"{tag}_cand_last"] = cands[0], cands[-1]      # [b, 1 + nn, W, henc]
+        d[f"{tag}_cand_label"] = label2
+    save("g16_criterion_inference.npz", **d)
+
+
+# ------------------------------------------------------------------ G17 a checkpoint WRITTEN by the reference
+def g17():
+    """A run directory as the reference leaves it (checkpoint_N.pt in its {"gEncoder", "cpcCriterion", "optimizer", "best"}
+    layout, checkpoint_args.json, checkpoint_logs.json) + what its model computes on a fixed input."""
+    import argparse
+    import json
+    from cpc.cpc_default_config import set_default_cpc_config
+    parser = set_default_cpc_config(argparse.ArgumentParser())
+    args = parser.parse_args([])
+    args.hiddenEncoder, args.hiddenGar, args.arMode, args.nLevelsGRU = 32, 32, "GRU", 1
+    args.negativeSamplingExt, args.nPredicts, args.rnnMode, args.sizeWindow = 16, 4, "linear", 20480
+    torch.manual_seed(4242)
+    enc = ref_model.CPCEncoder(args.hiddenEncoder, args.normMode)
+    ar = ref_model.CPCAR(args.hiddenEncoder, args.hiddenGar, False, args.nLevelsGRU, mode=args.arMode)
+    model = ref_model.CPCModel(enc, ar)
+    crit = ref_crit.CPCUnsupersivedCriterion(args.nPredicts, args.hiddenGar, args.hiddenEncoder, args.negativeSamplingExt,
+                                             rnnMode=args.rnnMode, sizeInputSeq=args.sizeWindow // 160)
+    opt = torch.optim.Adam(list(crit.parameters()) + list(model.parameters()), lr=2e-4)
+    x = synth.audio_windows(2, 20480, 5)
+    with torch.no_grad():
+        c, z, _ = model(x, None)
+    out = os.path.join(OUT, "ref_checkpoint")
+    os.makedirs(out, exist_ok=True)
+    torch.save({"gEncoder": model.state_dict(), "cpcCriterion": crit.state_dict(), "optimizer": opt.state_dict(),
+                "best": model.state_dict()}, os.path.join(out, "checkpoint_7.pt"))
+    with open(os.path.join(out, "checkpoint_args.json"), "w") as f:
+        json.dump(vars(args), f, indent=2)
+    with open(os.path.join(out, "checkpoint_logs.json"), "w") as f:
+        json.dump({"epoch": [7], "locLoss_train": [[4.8] * args.nPredicts]}, f)
+    save("g17_ref_checkpoint_outputs.npz", x=x, c=c, z=z)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for name in which:
         globals()[name]()
