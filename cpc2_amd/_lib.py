@@ -22,6 +22,7 @@ c_float = ctypes.c_float
 SIGNATURES = {
     "cpc_version": (c_int, []),
     "cpc_last_error": (ctypes.c_char_p, []),
+    "cpc_async_error_check": (c_int, [c_ptr]),
     "cpc_prof_enable": (c_int, [c_int]),
     "cpc_gemm_set_mode": (c_int, [c_int]),
     "cpc_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_long)]),

@@ -74,6 +74,28 @@ static inline int coop_cu_count()
     return v;
 }
 
+// ---- failing loudly -------------------------------------------------------------------------------------------------
+// The cooperative kernels need every workgroup of a launch resident at once.  (1) Before choosing them the launcher asks
+// the occupancy API whether the kernel fits a CU at all and compares the grid with the CU count (coop_fits).  (2) Every
+// wait is bounded; a wave whose wait runs out still poisons its outputs with NaN, and writes a code into ONE host-visible
+// word (mapped, coherent host memory: no synchronisation needed to read it).  The recurrent entry points look at that word
+// before they launch anything and cpc_async_error_check(stream) after synchronising the stream: both return CPC_ERR_HIP
+// with a message and clear the word -- like a HIP asynchronous error, a time-out surfaces at the next call.
+int *coop_error_word();                         // device-visible address of the word (nullptr: allocation failed)
+int coop_error_take(const char *where);         // host: CPC_OK, or CPC_ERR_HIP (message set, word cleared)
+int coop_fault_injection();                     // tests: CPC_COOP_FAULT=1 makes member 0 of group 0 withhold one publish
+enum { COOP_ERR_FWD_WAIT = 1, COOP_ERR_BWD_WAIT = 2 };
+__device__ __forceinline__ void coop_report(int *err, int code)
+{
+    if (err != nullptr) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <typename K> static inline bool coop_fits(K kernel, unsigned grid, int n_cus)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, 0) != hipSuccess) return false;
+    return per_cu >= 1 && (int)grid <= n_cus;   // one workgroup per CU is what the grouping assumes
+}
+
 // granules of the backward kernels: [groups][2][G][NB][H] with groups*NB < N + 8 windows and G <= 16
 static inline size_t coop_comm_bytes(int H, int N)
 {

@@ -207,6 +207,8 @@ struct GruCoopArgs {
     GruArgs g;
     gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
     int groups, xcd_map;
+    int *err;              // host-visible error word (coop.h), or nullptr
+    int fault;             // tests: member 0 of group 0 withholds its publish of step 1
 };
 
 template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(GruCoopArgs ca)
@@ -291,8 +293,9 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
             // publish first (also for padding windows, so that every granule of the epoch gets written): the other
             // members wait for this store, nobody waits for the saved activations below
             COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
-            __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(ca.fault && group == 0 && member == 0 && t == 1))
+                __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine) {
                 const long row = (long)ns * T + t;
                 float *gs = a.gates + row * 3 * H;
@@ -321,7 +324,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
 #pragma unroll
                     for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
                     if (ready) break;
-                    if (++spins > (1u << 22)) { dead = true; break; }
+                    if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
@@ -464,7 +467,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
 #pragma unroll
                     for (int d = 0; d < G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
                     if (ready) break;
-                    if (++spins > (1u << 22)) { dead = true; break; }
+                    if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_BWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
@@ -490,6 +493,24 @@ template <int H> static void launch_coop_bwd(int nb, dim3 grid, hipStream_t st, 
     else if (nb == 2) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
     else if (nb == 4) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
     else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
+}
+
+// does the cooperative kernel fit a CU, and the grid the chip?  (cached per instance: the occupancy query is not free)
+template <int H> static bool coop_fwd_fits(int nb, unsigned grid, int n_cus)
+{
+    static int ok[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};        // 0 unknown, 1 fits a CU, -1 does not
+    if (ok[nb] == 0)
+        ok[nb] = (nb == 1 ? coop_fits(gru_fwd_coop_kernel<H, 1>, 1, 1) : nb == 2 ? coop_fits(gru_fwd_coop_kernel<H, 2>, 1, 1)
+                  : nb == 4 ? coop_fits(gru_fwd_coop_kernel<H, 4>, 1, 1) : coop_fits(gru_fwd_coop_kernel<H, 8>, 1, 1)) ? 1 : -1;
+    return ok[nb] == 1 && (int)grid <= n_cus;
+}
+template <int H> static bool coop_bwd_fits(int nb, unsigned grid, int n_cus)
+{
+    static int ok[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok[nb] == 0)
+        ok[nb] = (nb == 1 ? coop_fits(gru_bwd_coop_kernel<H, 1>, 1, 1) : nb == 2 ? coop_fits(gru_bwd_coop_kernel<H, 2>, 1, 1)
+                  : nb == 4 ? coop_fits(gru_bwd_coop_kernel<H, 4>, 1, 1) : coop_fits(gru_bwd_coop_kernel<H, 8>, 1, 1)) ? 1 : -1;
+    return ok[nb] == 1 && (int)grid <= n_cus;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -569,11 +590,14 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         static const int n_cus = coop_cu_count();
         // the cooperative kernel needs every workgroup resident at once (1 per CU)
         int G = 0;
-        const int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        if (nb != 0 && !(H == 256 ? coop_fwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * G), n_cus) : coop_fwd_fits<512>(nb, (unsigned)(cdiv(N, nb) * G), n_cus)))
+            nb = 0;                             // not resident all at once: the streaming kernel has no such requirement
         if (nb != 0) {
             GruCoopArgs ca{};
             ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            ca.err = coop_error_word(); ca.fault = coop_fault_injection();
             CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * nb * H, st));
             ProfScope prof(PROF_GRU_FWD, st);
             const dim3 grid((unsigned)(ca.groups * G));
@@ -610,11 +634,14 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
         static const int n_cus = coop_cu_count();
         int G = 0;
-        const int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        if (nb != 0 && !(H == 256 ? coop_bwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * G), n_cus) : coop_bwd_fits<512>(nb, (unsigned)(cdiv(N, nb) * G), n_cus)))
+            nb = 0;
         if (nb != 0) {
             GruCoopArgs ca{};
             ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            ca.err = coop_error_word(); ca.fault = coop_fault_injection();
             CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * G * nb * H, st));
             ProfScope prof(PROF_GRU_BWD, st);
             const dim3 grid((unsigned)(ca.groups * G));
@@ -667,6 +694,7 @@ extern "C" size_t cpc_gru_scratch_bytes(int n, int t, int dim_in, int hidden, in
 extern "C" int cpc_gru_forward(const float *x, const float *const *params, const float *h0, float *out, float *h_last,
                                void *saved, void *scratch, int n, int t, int dim_in, int hidden, int layers, cpc_stream_t stream)
 {
+    CPC_TRY(cpc::coop_error_take("cpc_gru_forward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::gru_forward(x, params, h0, out, h_last, saved, scratch, n, t, dim_in, hidden, layers, static_cast<hipStream_t>(stream));
 }
 
@@ -674,6 +702,7 @@ extern "C" int cpc_gru_backward(const float *x, const float *const *params, cons
                                 float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                 cpc_stream_t stream)
 {
+    CPC_TRY(cpc::coop_error_take("cpc_gru_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::gru_backward(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                              static_cast<hipStream_t>(stream));
 }

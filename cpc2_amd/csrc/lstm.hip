@@ -236,6 +236,8 @@ struct LstmCoopArgs {
     LstmArgs g;
     gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
     int groups, xcd_map;
+    int *err;              // host-visible error word (coop.h), or nullptr
+    int fault;             // tests: member 0 of group 0 withholds its publish of step 1
 };
 
 template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_kernel(LstmCoopArgs ca)
@@ -321,8 +323,9 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
             // publish first (also for padding windows, so that every granule of the epoch gets written): the other
             // members wait for this store, nobody waits for the saved activations below
             COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
-            __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(ca.fault && group == 0 && member == 0 && t == 1))
+                __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine) {
                 const long row = (long)ns * T + t;
                 float *gs = a.gates + row * 4 * H;
@@ -350,7 +353,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
 #pragma unroll
                     for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
                     if (ready) break;
-                    if (++spins > (1u << 22)) { dead = true; break; }
+                    if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
@@ -496,7 +499,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
 #pragma unroll
                 for (int d = 0; d < G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
                 if (ready) break;
-                if (++spins > (1u << 22)) { dead = true; break; }
+                if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_BWD_WAIT); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -508,6 +511,22 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
     }
 }
 
+template <int H> static bool lstm_coop_fwd_fits(int nb, unsigned grid, int n_cus)
+{
+    static int ok[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};        // 0 unknown, 1 fits a CU, -1 does not
+    if (ok[nb] == 0)
+        ok[nb] = (nb == 1 ? coop_fits(lstm_fwd_coop_kernel<H, 1>, 1, 1) : nb == 2 ? coop_fits(lstm_fwd_coop_kernel<H, 2>, 1, 1)
+                  : nb == 4 ? coop_fits(lstm_fwd_coop_kernel<H, 4>, 1, 1) : coop_fits(lstm_fwd_coop_kernel<H, 8>, 1, 1)) ? 1 : -1;
+    return ok[nb] == 1 && (int)grid <= n_cus;
+}
+template <int H> static bool lstm_coop_bwd_fits(int nb, unsigned grid, int n_cus)
+{
+    static int ok[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok[nb] == 0)
+        ok[nb] = (nb == 1 ? coop_fits(lstm_bwd_coop_kernel<H, 1>, 1, 1) : nb == 2 ? coop_fits(lstm_bwd_coop_kernel<H, 2>, 1, 1)
+                  : nb == 4 ? coop_fits(lstm_bwd_coop_kernel<H, 4>, 1, 1) : coop_fits(lstm_bwd_coop_kernel<H, 8>, 1, 1)) ? 1 : -1;
+    return ok[nb] == 1 && (int)grid <= n_cus;
+}
 template <int H> static void launch_lstm_coop_fwd(int nb, dim3 grid, hipStream_t st, const LstmCoopArgs &ca)
 {
     if (nb == 1) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
@@ -615,11 +634,15 @@ static int lstm_forward(const float *x, const float *const *prm, const float *h0
         a.clast = c_last ? c_last + (size_t)l * N * H : nullptr;
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
         int members = 0;
-        const int nb = lstm_coop_windows(G, H, N, &members);
+        int nb = lstm_coop_windows(G, H, N, &members);
+        if (nb != 0 && !(H == 256 ? lstm_coop_fwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * members), coop_cu_count())
+                                  : lstm_coop_fwd_fits<512>(nb, (unsigned)(cdiv(N, nb) * members), coop_cu_count())))
+            nb = 0;                             // not resident all at once: the streaming kernel has no such requirement
         if (nb != 0) {
             LstmCoopArgs ca{};
             ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            ca.err = coop_error_word(); ca.fault = coop_fault_injection();
             CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(gu64_t) * (size_t)ca.groups * 2 * nb * H, st));
             ProfScope prof(PROF_GRU_FWD, st);
             const dim3 grid((unsigned)(ca.groups * members));
@@ -657,11 +680,15 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
         int members = 0;
-        const int nb = lstm_coop_windows(G, H, N, &members);
+        int nb = lstm_coop_windows(G, H, N, &members);
+        if (nb != 0 && !(H == 256 ? lstm_coop_bwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * members), coop_cu_count())
+                                  : lstm_coop_bwd_fits<512>(nb, (unsigned)(cdiv(N, nb) * members), coop_cu_count())))
+            nb = 0;
         if (nb != 0) {
             LstmCoopArgs ca{};
             ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
+            ca.err = coop_error_word(); ca.fault = coop_fault_injection();
             CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(gu64_t) * (size_t)ca.groups * 2 * members * nb * H, st));
             ProfScope prof(PROF_GRU_BWD, st);
             const dim3 grid((unsigned)(ca.groups * members));
@@ -715,6 +742,7 @@ extern "C" int cpc_lstm_forward(const float *x, const float *const *params, cons
                                 float *h_last, float *c_last, void *saved, void *scratch, int n, int t, int dim_in, int hidden,
                                 int layers, cpc_stream_t stream)
 {
+    CPC_TRY(cpc::coop_error_take("cpc_lstm_forward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_forward<4>(x, params, h0, c0, out, h_last, c_last, saved, scratch, n, t, dim_in, hidden, layers,
                                 static_cast<hipStream_t>(stream));
 }
@@ -723,6 +751,7 @@ extern "C" int cpc_lstm_backward(const float *x, const float *const *params, con
                                  float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                  cpc_stream_t stream)
 {
+    CPC_TRY(cpc::coop_error_take("cpc_lstm_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_backward<4>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                                  static_cast<hipStream_t>(stream));
 }
@@ -745,6 +774,7 @@ extern "C" int cpc_rnn_forward(const float *x, const float *const *params, const
                                void *saved, void *scratch, int n, int t, int dim_in, int hidden, int layers,
                                cpc_stream_t stream)
 {
+    CPC_TRY(cpc::coop_error_take("cpc_rnn_forward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_forward<1>(x, params, h0, nullptr, out, h_last, nullptr, saved, scratch, n, t, dim_in, hidden, layers,
                                 static_cast<hipStream_t>(stream));
 }
@@ -753,6 +783,7 @@ extern "C" int cpc_rnn_backward(const float *x, const float *const *params, cons
                                 float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                 cpc_stream_t stream)
 {
+    CPC_TRY(cpc::coop_error_take("cpc_rnn_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_backward<1>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                                  static_cast<hipStream_t>(stream));
 }

@@ -1,6 +1,7 @@
 // Small HBM-bound helpers: error state, column sums, weight re-layouts, channel-first ChannelNorm
 // (standalone module API), fused flat Adam.
 #include "common.h"
+#include "coop.h"
 
 #include <algorithm>
 #include <atomic>
@@ -45,6 +46,37 @@ ProfScope::~ProfScope()
     (void)hipEventRecord(b_, st_);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back({slot_, a_, b_});
+}
+
+// ---------------------------------------------------------------- asynchronous error word (coop.h)
+static int *g_err_host = nullptr, *g_err_dev = nullptr;
+static std::once_flag g_err_once;
+int *coop_error_word()
+{
+    std::call_once(g_err_once, [] {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_err_host = static_cast<int *>(h);
+        g_err_dev = static_cast<int *>(d);
+        *g_err_host = 0;
+    });
+    return g_err_dev;
+}
+int coop_error_take(const char *where)
+{
+    if (g_err_host == nullptr) return CPC_OK;
+    const int code = __atomic_exchange_n(g_err_host, 0, __ATOMIC_ACQ_REL);
+    if (code == 0) return CPC_OK;
+    set_error("%s: a cooperative recurrent kernel (%s pass) gave up waiting for the other workgroups of its group -- its "
+              "workgroups were not all resident at once (another kernel on the device?); its outputs are NaN.  "
+              "CPC_GRU_STREAM=1 selects the non-cooperative kernels", where, code == COOP_ERR_FWD_WAIT ? "forward" : "backward");
+    return CPC_ERR_HIP;
+}
+int coop_fault_injection()
+{
+    const char *v = getenv("CPC_COOP_FAULT");       // read every time: tests switch it on and off
+    return v != nullptr && v[0] == '1';
 }
 
 // ---------------------------------------------------------------- column sums
@@ -383,4 +415,10 @@ extern "C" int cpc_adam_step(float *p, const float *g, float *m, float *v, long 
                        lr_c1, rsqrt_c2, beta1, beta2, eps, grad_scale);
     CPC_CHECK_LAUNCH("adam_kernel");
     return CPC_OK;
+}
+
+extern "C" int cpc_async_error_check(cpc_stream_t stream)
+{
+    CPC_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return cpc::coop_error_take("cpc_async_error_check");
 }

@@ -256,6 +256,13 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     return allLosses.sum(), allLosses, allAcc
 
 
+def _check_async(device):
+    """Raise if a cooperative recurrent kernel timed out since the last check (it then produced NaN): cpc2_hip.h,
+    cpc_async_error_check.  Called where the loop synchronises with the device anyway."""
+    from . import _lib
+    _lib.check(_lib.load().cpc_async_error_check(_lib.stream_ptr(torch.device(device))), "async error check")
+
+
 def trainStep(dataLoader, cpcModel, cpcCriterion, optimizer, scheduler, loggingStep, dp=None, device=None):
     """train.py:72-142.  `dataLoader` yields (sequence [b,2,1,L], label [b][, signal_quality])."""
     cpcModel.train()
@@ -287,9 +294,11 @@ def trainStep(dataLoader, cpcModel, cpcCriterion, optimizer, scheduler, loggingS
                 print(f"Update {step + 1}\nelapsed: {elapsed:.1f} s")
                 print(f"{1000.0 * elapsed / loggingStep:.1f} ms per batch, {1000.0 * elapsed / n_examples:.1f} ms / example")
                 print("locLoss_train", (sum_loss / it).cpu().numpy())
+                _check_async(device)                      # the copy above synchronised anyway
                 start_time, n_examples = time.perf_counter(), 0
     if scheduler is not None:
         scheduler.step()
+    _check_async(device)
     if it > 0:
         logs["locLoss_train"] = (sum_loss / it).cpu().numpy()
         logs["locAcc_train"] = (sum_acc / it).cpu().numpy()
@@ -315,6 +324,7 @@ def valStep(dataLoader, cpcModel, cpcCriterion, device=None):
         sum_loss = ls if sum_loss is None else sum_loss + ls
         sum_acc = ac if sum_acc is None else sum_acc + ac
     logs = {"iter": it}
+    _check_async(device)
     if it > 0:
         logs["locLoss_val"] = (sum_loss / it).cpu().numpy()
         logs["locAcc_val"] = (sum_acc / it).cpu().numpy()

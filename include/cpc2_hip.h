@@ -50,6 +50,13 @@ const char *cpc_last_error(void);
  * (the split-in-kernel products), "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd" ("gru_*"
  * times whichever recurrent kernel runs: GRU, LSTM or RNN).  on = 1: every class; on = 2: "gemm_planes_nt" only, on = 3:
  * "gemm_nt" only (the events cost about 0.1 ms per step when every class is timed); 0 (default): off. */
+/* Asynchronous errors of the cooperative recurrent kernels (GRU / LSTM at hidden 256 / 512: workgroups that exchange
+ * the hidden state through L2 and need to be resident all at once).  Every wait inside them is bounded; a wave whose wait
+ * runs out poisons its outputs with NaN AND records a code in a host-visible word.  cpc_gru_* / cpc_lstm_* / cpc_rnn_*
+ * return CPC_ERR_HIP (message in cpc_last_error) at their NEXT call when the word is set; cpc_async_error_check
+ * synchronises `stream`, then reports and clears it.  CPC_COOP_FAULT=1 in the environment (tests) makes one member
+ * withhold one publish so that its group times out. */
+int cpc_async_error_check(cpc_stream_t stream);
 int cpc_prof_enable(int on);
 int cpc_prof_read(const char *name, double *total_ms, long *count);
 
