@@ -226,7 +226,9 @@ def main():
     from cpc2_amd.train import DataParallelContext, cpcStep
     lib = _lib.load()
     model, crit, opt = build(cfg, device)
-    dp = DataParallelContext(opt)
+    # N > 1: the criterion / context-network gradient slices are all-reduced under the encoder's backward (train.py)
+    dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()),
+                             overlap=not os.environ.get("CPC_BENCH_NO_OVERLAP"))
     crit.seed(1234 + rank)                                  # per-rank negative stream
     crit.sampler.prefetch = True                            # host draws step i+1's MT19937 words during step i
     g = torch.Generator().manual_seed(1000 + rank)          # per-rank shard of the synthetic utterances
@@ -234,7 +236,7 @@ def main():
     label = torch.zeros(args.batch, dtype=torch.long, device=device)
 
     def step():
-        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=args.dedup)
+        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=args.dedup, dp=dp)
         tot.backward()
         dp.reduce_and_step()
         opt.zero_grad()

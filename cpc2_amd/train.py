@@ -116,11 +116,14 @@ class FlatAdam(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
-    def _gather_stray_grads(self):
+    def _gather_stray_grads(self, ranges=None):
         """direct mode: a gradient that autograd did NOT adopt from flat_grad (accumulated or produced by a
-        torch op) lives in its own tensor: copy it home before the fused update."""
+        torch op) lives in its own tensor: copy it home before the fused update.  ranges: only the parameters inside
+        these [lo, hi) pieces of the flat buffer (the others have been all-reduced already)."""
         base = self.flat_grad.data_ptr()
         for p, off in zip(self.params, self.offsets):
+            if ranges is not None and not any(lo <= off < hi for lo, hi in ranges):
+                continue
             if p.grad is not None and p.grad.data_ptr() != base + 4 * off:
                 self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
 
@@ -216,25 +219,89 @@ def buildScheduler(optimizer, schedulerStep=-1, schedulerRamp=None, epochs_done=
 
 
 class DataParallelContext:
-    """One process per GPU (train.py:291-295, 523-527 with --distributed).  Replaces the two DDP
-    wrappers by: one broadcast of the flat parameter buffer from rank 0 at start, and one all-reduce
-    (SUM) of the flat gradient buffer per step whose 1/world_size is folded into the Adam kernel."""
+    """One process per GPU (train.py:291-295, 523-527 with --distributed).  Replaces the two DDP wrappers by: one
+    broadcast of the flat parameter buffer from rank 0 at start, and all-reduces (SUM) of the flat gradient buffer whose
+    1/world_size is folded into the Adam kernel.
 
-    def __init__(self, optimizer):
+    Overlap (the reference gets it from DDP's buckets, train.py:523-527): with `early_params` -- the parameters whose
+    gradients are complete before the encoder's backward starts: the criterion's and the context network's -- their slices
+    of the flat gradient are reduced ASYNCHRONOUSLY from an autograd hook on the encoder's output (`attach`, called by
+    cpcStep), i.e. while the encoder's backward kernels run; `reduce_and_step` then reduces the encoder's slice, waits
+    for the early ones and updates.  Without early_params (or overlap=False): one blocking all-reduce of the whole buffer."""
+
+    def __init__(self, optimizer, early_params=None, overlap=True):
         self.opt = optimizer
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
+        self.early, self.late, self._pending, self._fired = [], [], [], False
         if self.active:
             dist.broadcast(self.opt.flat, src=0)
+            if early_params and overlap and hasattr(optimizer, "offsets"):
+                self._split(early_params)
+
+    def _split(self, early_params):
+        """[lo, hi) ranges of the flat buffer: early (merged runs of the early parameters) and the rest."""
+        ids = {id(p) for p in early_params}
+        total = self.opt.flat.numel()
+        marks = sorted((off, off + p.numel()) for p, off in zip(self.opt.params, self.opt.offsets) if id(p) in ids)
+        for lo, hi in marks:
+            if self.early and self.early[-1][1] == lo:
+                self.early[-1] = (self.early[-1][0], hi)
+            else:
+                self.early.append((lo, hi))
+        pos = 0
+        for lo, hi in self.early:
+            if lo > pos:
+                self.late.append((pos, lo))
+            pos = hi
+        if pos < total:
+            self.late.append((pos, total))
+
+    def attach(self, encoder_output):
+        """Register the hook that starts the early reductions when the gradient of `encoder_output` is ready (everything
+        downstream of the encoder has then written its parameter gradients)."""
+        if not (self.active and self.early and encoder_output.requires_grad):
+            return
+        self._fired = False
+
+        def start(_grad):
+            if not self._fired:                 # once per backward pass
+                self._fired = True
+                if getattr(self.opt, "direct_grads", False):
+                    self.opt._gather_stray_grads(self.early)     # a gradient autograd did not write in place (accumulation)
+                self._pending = [dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+                                 for lo, hi in self.early]
+        encoder_output.register_hook(start)
 
     def reduce_and_step(self):
         if self.active:
+            if self._fired and self._pending:
+                if getattr(self.opt, "direct_grads", False):
+                    self.opt._gather_stray_grads(self.late)      # (the early slices hold SUMS by now)
+                for lo, hi in self.late:
+                    dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM)
+                for work in self._pending:
+                    work.wait()
+                # the optimiser must not take a stray early gradient for the reduced one again
+                stray = getattr(self.opt, "direct_grads", False)
+                if stray:
+                    self.opt.direct_grads = False
+                try:
+                    self.opt.step(grad_scale=1.0 / self.world)
+                finally:
+                    if stray:
+                        self.opt.direct_grads = True
+                self._pending, self._fired = [], False
+                return
+            if getattr(self.opt, "direct_grads", False):
+                self.opt._gather_stray_grads()
             dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM)
+            self._pending, self._fired = [], False
         self.opt.step(grad_scale=1.0 / self.world)
 
 
 # --------------------------------------------------------------------------- the step
-def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False):
+def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False, dp=None):
     """train.py:95-108: model on cat([past, future]); context from the past half, targets from the
     future half; returns (totLoss, allLosses [1,K], allAcc [1,K]).
 
@@ -244,11 +311,15 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     b = past.size(0)
     if dedup and (future is past or (future.data_ptr() == past.data_ptr() and future.shape == past.shape)):
         c_feature, encoded_data, label = cpcModel(past, label)
+        if dp is not None:
+            dp.attach(encoded_data)
         allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
         return allLosses.sum(), allLosses, allAcc
     combined = torch.cat([past, future], dim=0)
     label = torch.cat([label, label])
     c_feature, encoded_data, label = cpcModel(combined, label)
+    if dp is not None:
+        dp.attach(encoded_data)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
     c_feature = c_feature[:b, :, :]
     encoded_data = encoded_data[b:, :, :]
     label = label[:b]
@@ -280,7 +351,7 @@ def trainStep(dataLoader, cpcModel, cpcCriterion, optimizer, scheduler, loggingS
         signal_quality = signal_quality[0].to(device, non_blocking=True) if len(signal_quality) else None
         past, future = sequence[:, 0, ...], sequence[:, 1, ...]
         n_examples += past.size(0)
-        totLoss, allLosses, allAcc = cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality)
+        totLoss, allLosses, allAcc = cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality, dp=dp)
         totLoss.backward()
         dp.reduce_and_step()
         optimizer.zero_grad()

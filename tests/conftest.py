@@ -21,3 +21,64 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+# ---- multi-process GPU jobs --------------------------------------------------------------------------------------
+# tests/test_dp_gpu.py compares a 2-rank data-parallel run of the real model with a single process doing the same work,
+# and checks an RCCL process group of one rank.  Every rank is its own python process on cuda:0; they are started HERE,
+# when the session starts -- before this process has made any GPU call -- and the tests only collect their results.
+_DP = {}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    import tempfile
+    markexpr = session.config.getoption("markexpr", "") or ""
+    if "not gpu" in markexpr or os.environ.get("CPC_SKIP_DP_JOBS"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:      # (counting devices does not initialise the GPU)
+            return
+    except Exception:
+        return
+    tmp = tempfile.mkdtemp(prefix="cpc_dp_")
+    job = os.path.join(ROOT, "tests", "dp_job.py")
+    port, port1 = str(_free_port()), str(_free_port())
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = {}
+    specs = {"rank0": ("ranks", 0, 2, port), "rank1": ("ranks", 1, 2, port), "single": ("single", 0, 1, port),
+             "nccl": ("nccl", 0, 1, port1)}
+    for name, (mode, rank, world, prt) in specs.items():
+        out = os.path.join(tmp, name + ".pt")
+        log = open(os.path.join(tmp, name + ".log"), "w")
+        procs[name] = (subprocess.Popen([sys.executable, job, mode, str(rank), str(world), prt, out], stdout=log,
+                                        stderr=subprocess.STDOUT, env=env, cwd=ROOT), out, log.name)
+    _DP.update(procs)
+
+
+@pytest.fixture(scope="session")
+def dp_jobs():
+    """name -> loaded result of tests/dp_job.py (waits for the processes started at session start)."""
+    import torch
+    if not _DP:
+        pytest.skip("data-parallel jobs were not started (no GPU, or -m 'not gpu')")
+    results = {}
+    for name, (proc, out, log) in _DP.items():
+        try:
+            rc = proc.wait(timeout=420)
+        except Exception:
+            proc.kill()
+            raise AssertionError(f"dp job {name} did not finish:\n" + open(log).read()[-3000:])
+        assert rc == 0, f"dp job {name} failed ({rc}):\n" + open(log).read()[-3000:]
+        results[name] = torch.load(out)
+    return results
