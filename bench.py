@@ -191,39 +191,12 @@ def cpu_baseline(cfg, seconds_budget):
                       f"{dt:.2f} s/step, fp32 torch-CPU"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
-    ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--no-prof", action="store_true", help="skip the in-situ kernel timing")
-    ap.add_argument("--dedup", action="store_true",
-                    help="one encoder/AR pass when past is future (identical results; NOT the reference's 2b-window step)")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # one process per GPU; CPC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
-    # distributed code path on a one-GPU box (ranks then share the device)
-    backend = os.environ.get("CPC_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    # CPC_BENCH_FORCE_DIST=1: go through the process-group code path (RCCL init, broadcast, all-reduce) with one rank too
-    use_dist = world > 1 or bool(os.environ.get("CPC_BENCH_FORCE_DIST") and "MASTER_ADDR" in os.environ)
-    if use_dist:
-        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
-
+def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_seconds):
+    """Build CONFIGS[cfg_name], run `warmup` untimed and `steps` timed steps (barrier + synchronize on both sides, MAX over
+    ranks) and return the result record (rank 0: the dict that is printed; other ranks: None)."""
     from cpc2_amd import _lib
     from cpc2_amd.train import DataParallelContext, cpcStep
+    cfg = CONFIGS[cfg_name]
     lib = _lib.load()
     model, crit, opt = build(cfg, device)
     # N > 1: the criterion / context-network gradient slices are all-reduced under the encoder's backward (train.py)
@@ -242,8 +215,8 @@ def main():
         opt.zero_grad()
         return losses
 
-    log(f"rank {rank}: model built, starting {args.warmup} warm-up steps")
-    for i in range(args.warmup):
+    log(f"rank {rank}: {cfg_name}: model built, starting {warmup} warm-up steps")
+    for i in range(warmup):
         losses = step()
         if i == 0:
             torch.cuda.synchronize()
@@ -253,19 +226,20 @@ def main():
     if use_dist:
         dist.barrier()
     prof = not args.no_prof
+    roof = "gemm_planes_nt" if cfg["hidden"] % 256 == 0 else "gemm_nt"
     if prof:
-        roof = "gemm_planes_nt" if cfg["hidden"] % 256 == 0 else "gemm_nt"
         lib.cpc_prof_enable(2 if roof == "gemm_planes_nt" else 3)   # the roofline kernel only inside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         losses = step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     lib.cpc_prof_enable(0)
-    log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
+    _lib.check(lib.cpc_async_error_check(_lib.stream_ptr(device)), "async error check")
+    log(f"{cfg_name}: timed region done: {1e3 * elapsed / steps:.2f} ms/step")
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -283,7 +257,7 @@ def main():
                                  "avg_launch_us": round(1e3 * tot.value / cnt.value, 2)}
 
     if prof:
-        read_classes((roof,), args.steps)                  # measured over the timed region
+        read_classes((roof,), steps)                       # measured over the timed region
         # the other classes: a few extra steps after the clock has stopped (timing every class costs ~0.1 ms per step)
         extra = 5
         lib.cpc_prof_enable(1)
@@ -295,58 +269,109 @@ def main():
         lib.cpc_prof_read(roof.encode(), ctypes.byref(tot), ctypes.byref(cnt))   # discard: already taken from the timed region
         read_classes(tuple(c for c in ("gemm_planes_nt", "gemm_planes_tn", "gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd",
                                        "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd") if c != roof), extra)
+    if rank != 0:
+        return None
+    ms = 1e3 * elapsed / steps
+    value = world * args.batch * SECONDS_PER_WINDOW * steps / elapsed
+    out = {
+        "metric": "audio-seconds/sec CPC training (1.28 s @16 kHz, 128 neg)",
+        "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"CPC-{cfg_name} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
+                               f"{cfg['npred']}, {cfg['nneg']} negatives, {('multi-head ' if cfg.get('multihead') else '') + cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
+                               f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
+                                                         if args.dedup else
+                                                         "reference trainStep semantics (encoder+AR on 2b windows), ")
+                               + "fwd+bwd+allreduce+Adam",
+                   "windows_per_gpu": args.batch, "global_batch": world * args.batch,
+                   "parallelism": f"dp{world}", "final_losses": final_loss,
+                   "inputs": "x = 0.05 randn, generator seed 1000 + rank; criterion MT19937 stream seed 1234 + rank; model "
+                             "init torch.manual_seed(0) on every rank (SURVEY 8d's recipe with per-rank shards)"},
+    }
+    default_workload = args.batch == 64 and not args.dedup
+    if prof and roof in kernels:
+        planes = roof == "gemm_planes_nt"
+        flops, launches = (planes_nt_algorithmic_flops if planes else gemm_nt_algorithmic_flops)(args.batch, cfg, args.dedup)
+        k = kernels[roof]
+        achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
+        kname = "gemm_planes_kernel<0, false>" if planes else "gemm_nt_x6_kernel"
+        out["roofline"] = {"bound": "mfma",
+                           "kernel": kname + (" (conv1-4 forward and backward-data on pre-split bf16 planes)" if planes else
+                                              " (conv1-4 forward and backward-data, context / predictor projections)"),
+                           "achieved": round(achieved, 2), "peak": GEMM_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / GEMM_PEAK_TFLOPS, 4),
+                           "peak_note": "algorithmic f32 flops; peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per "
+                                        "f32 product (f32-accurate bf16x6 split); the f32 MFMA's own peak is "
+                                        f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s",
+                           # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes), default workload only
+                           "traffic": measured_traffic(kname + ":" + cfg_name) if default_workload else None,
+                           "algorithmic_gflop_per_launch": round(flops / max(k["launches_per_step"], 1.0) / 1e9, 3),
+                           "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
+    if "infonce_fwd" in kernels and cfg.get("rnn", "linear") == "linear":
+        # north_star's one explicit kernel target: the [context x negatives] similarity matmul, >= 60 % of the f32 MFMA peak
+        k = kernels["infonce_fwd"]
+        sim = similarity_algorithmic_flops(args.batch, cfg)
+        ach = sim / (k["ms_per_step"] * 1e-3) / 1e12
+        out["roofline_similarity"] = {"bound": "mfma", "kernel": "infonce_fwd_kernel (gather + similarity + cross-entropy fused)",
+                                      "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                                      "algorithmic_gflop_per_launch": round(sim / 1e9, 3), "avg_launch_us": k["avg_launch_us"],
+                                      "traffic": measured_traffic("infonce_fwd_kernel:" + cfg_name) if default_workload else None}
+    out["kernels"] = kernels
+    if cpu_seconds > 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg, cpu_seconds)
+    del model, crit, opt, dp, x
+    torch.cuda.empty_cache()
+    return out
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
+    ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="skip the in-situ kernel timing")
+    ap.add_argument("--dedup", action="store_true",
+                    help="one encoder/AR pass when past is future (identical results; NOT the reference's 2b-window step)")
+    ap.add_argument("--also", default=None,
+                    help="comma-separated configs measured AFTER the headline's timed region and reported inside the same JSON "
+                         "line under \"other_configs\" (default at one GPU with the small config: large,transformer = BASELINE "
+                         "configs[4] per GPU and configs[3]; '' = none)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # one process per GPU; CPC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
+    # distributed code path on a one-GPU box (ranks then share the device)
+    backend = os.environ.get("CPC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    # CPC_BENCH_FORCE_DIST=1: go through the process-group code path (RCCL init, broadcast, all-reduce) with one rank too
+    use_dist = world > 1 or bool(os.environ.get("CPC_BENCH_FORCE_DIST") and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
+
+    out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
+    also = args.also
+    if also is None:
+        also = "large,transformer" if (world == 1 and args.config == "small" and not args.no_prof) else ""
+    others = []
+    for name in [n for n in also.split(",") if n]:
+        rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
+        if rec is not None:
+            others.append(rec)
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        value = world * args.batch * SECONDS_PER_WINDOW * args.steps / elapsed
-        out = {
-            "metric": "audio-seconds/sec CPC training (1.28 s @16 kHz, 128 neg)",
-            "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"CPC-{args.config} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
-                                   f"{cfg['npred']}, {cfg['nneg']} negatives, {('multi-head ' if cfg.get('multihead') else '') + cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
-                                   f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
-                                                             if args.dedup else
-                                                             "reference trainStep semantics (encoder+AR on 2b windows), ")
-                                   + "fwd+bwd+allreduce+Adam",
-                       "windows_per_gpu": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "final_losses": final_loss,
-                       "inputs": "x = 0.05 randn, generator seed 1000 + rank; criterion MT19937 stream seed 1234 + rank; model "
-                                 "init torch.manual_seed(0) on every rank (SURVEY 8d's recipe with per-rank shards)"},
-        }
-        default_workload = args.batch == 64 and not args.dedup
-        if prof and roof in kernels:
-            planes = roof == "gemm_planes_nt"
-            flops, launches = (planes_nt_algorithmic_flops if planes else gemm_nt_algorithmic_flops)(args.batch, cfg, args.dedup)
-            k = kernels[roof]
-            achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
-            kname = "gemm_planes_kernel<0, false>" if planes else "gemm_nt_x6_kernel"
-            out["roofline"] = {"bound": "mfma",
-                               "kernel": kname + (" (conv1-4 forward and backward-data on pre-split bf16 planes)" if planes else
-                                                  " (conv1-4 forward and backward-data, context / predictor projections)"),
-                               "achieved": round(achieved, 2), "peak": GEMM_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / GEMM_PEAK_TFLOPS, 4),
-                               "peak_note": "algorithmic f32 flops; peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per "
-                                            "f32 product (f32-accurate bf16x6 split); the f32 MFMA's own peak is "
-                                            f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s",
-                               # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes), default workload only
-                               "traffic": measured_traffic(kname + ":" + args.config) if default_workload else None,
-                               "algorithmic_gflop_per_launch": round(flops / max(k["launches_per_step"], 1.0) / 1e9, 3),
-                               "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"]}
-        if "infonce_fwd" in kernels and cfg.get("rnn", "linear") == "linear":
-            # north_star's one explicit kernel target: the [context x negatives] similarity matmul, >= 60 % of the f32 MFMA peak
-            k = kernels["infonce_fwd"]
-            sim = similarity_algorithmic_flops(args.batch, cfg)
-            ach = sim / (k["ms_per_step"] * 1e-3) / 1e12
-            out["roofline_similarity"] = {"bound": "mfma", "kernel": "infonce_fwd_kernel (gather + similarity + cross-entropy fused)",
-                                          "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                                          "algorithmic_gflop_per_launch": round(sim / 1e9, 3), "avg_launch_us": k["avg_launch_us"],
-                                          "traffic": measured_traffic("infonce_fwd_kernel:" + args.config) if default_workload else None}
-        out["kernels"] = kernels
-        if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        if others:
+            out["other_configs"] = others
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

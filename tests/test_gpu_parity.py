@@ -1393,3 +1393,59 @@ def test_cooperative_recurrence_timeout_is_reported(monkeypatch, mode):
     again = ar(x)
     _lib.check(lib.cpc_async_error_check(stream))
     assert torch.equal(again, good)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs at their real shapes
+def _full_step_vs_oracle(hidden, layers, nneg, x, steps, lr, seed, tol_loss, tol_param):
+    """`steps` Adam steps of the HIP path and of the fp32 CPU oracle on the same windows (reference semantics: 2b windows
+    through encoder + GRU): loss per prediction step within tol_loss relative at every step, parameters after the last
+    step within tol_param of their scale."""
+    k = 12
+    mp = synth.encoder_params(hidden, 31)
+    mp.update(synth.gru_params(hidden, hidden, layers, 32))
+    cp = synth.predictor_params(k, hidden, hidden, 33)
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, layers))
+    model.load_state_dict(mp)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, hidden, hidden, nneg, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(cp)
+    model, crit = model.to(DEV), crit.to(DEV)
+    opt = buildOptimizer(model, crit, lr=lr)
+    crit.seed(seed)
+    xd = x.to(DEV)
+    label = torch.zeros(x.shape[0], dtype=torch.long, device=DEV)
+    curve = []
+    for _ in range(steps):
+        tot, losses, _ = cpcStep(xd, xd, label, model, crit)
+        tot.backward()
+        opt.step()
+        opt.zero_grad()
+        curve.append(losses.detach().cpu())
+    ref_curve, ref_params = O.train_steps(x, x, mp, cp, seed, steps, k, nneg, n_layers_gru=layers, lr=lr)
+    for i in range(steps):
+        err = float(((curve[i].view(-1) - ref_curve[i]).abs() / ref_curve[i].abs()).max())
+        assert err <= tol_loss, f"step {i}: InfoNCE loss differs from the oracle by {err:.2e} relative"
+    got = {n: p.detach().cpu() for n, p in list(crit.state_dict().items()) + list(model.state_dict().items())}
+    # Adam moves every weight by about lr per step whatever the size of its gradient, so an element whose gradient is
+    # rounding noise may legitimately end up 2 lr steps away: the bound below catches a missing or mis-scaled update,
+    # the loss curve above is the tight check (step i + 1 sees step i's update)
+    for n, ref in ref_params.items():
+        d = float((got[n] - ref).abs().max())
+        assert d <= 2.5 * lr * steps + tol_param * float(ref.abs().max()), f"{n}: {d:.2e}"
+        moved = float((got[n] - (mp[n] if n in mp else cp[n])).abs().max())
+        assert moved > 0.2 * lr, f"{n} was not updated"
+
+
+def test_config_c5_cpc_large_full_step_vs_oracle():
+    """BASELINE configs[4] per GPU at its real shapes -- hiddenEncoder = hiddenGar = 512, nLevelsGRU = 2, 256 negatives,
+    nPredicts 12, 20480-sample windows -- at b = 2 (4 windows through the encoder): two steps against the oracle."""
+    _full_step_vs_oracle(512, 2, 256, synth.audio_windows(2, 20480, 34), steps=2, lr=2e-4, seed=77, tol_loss=1e-3, tol_param=2e-3)
+
+
+def test_config_c1_cpc_small_on_reference_test_data_vs_oracle():
+    """BASELINE configs[0] at its real shapes: CPC-small (hidden 256, GRU, 12 predictions, 128 negatives) on windows of the
+    reference's cpc/test_data fixture, batchSizeGPU = 8, three Adam steps against the CPU oracle."""
+    import random
+    random.seed(0)
+    data = _feeder(DEV)
+    seq, _label = next(iter(data.getDataLoader(8, "sequential", False)))
+    _full_step_vs_oracle(256, 1, 128, seq[:, 0].cpu(), steps=3, lr=2e-4, seed=1234, tol_loss=1e-3, tol_param=2e-3)
