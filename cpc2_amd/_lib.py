@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpc2_hip.so")
+LIB_PATH = os.environ.get("CPC2_HIP_LIB") or os.path.join(_HERE, "libcpc2_hip.so")     # (override: probe builds under tools/)
 
 c_float_p = ctypes.c_void_p      # raw device / host addresses (tensor.data_ptr())
 c_ptr = ctypes.c_void_p

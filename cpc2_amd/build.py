@@ -22,7 +22,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "..", "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rowcfg.h"), os.path.join(CSRC, "coop.h"), os.path.join(HERE, "..", "include", "cpc2_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rowcfg.h"), os.path.join(CSRC, "coop.h"), os.path.join(CSRC, "ldsdma.h"), os.path.join(HERE, "..", "include", "cpc2_hip.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + headers):
         return LIB

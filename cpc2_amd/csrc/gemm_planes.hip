@@ -25,6 +25,7 @@
 //   row block 3 is multiplied while those reads and the new requests are under way.
 // All LDS traffic is issued from inline asm: hipcc drains vmcnt to 0 before any LDS read it can see behind an LDS-DMA.
 #include "common.h"
+#include "ldsdma.h"
 
 #include <algorithm>
 
@@ -33,8 +34,7 @@ namespace cpc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;
-typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // one MFMA operand (8 bf16) as four dwords: hipcc handles
-                                                                // a bf16x8 value that crosses a branch element by element
+// (frag_t of ldsdma.h: one MFMA operand (8 bf16) as four dwords: hipcc handles a bf16x8 value that crosses a branch element by element)
 
 constexpr int PT_BM = 256, PT_BN = 256, PT_BK = 16;
 constexpr int PT_PIECE = 1024;                    // bytes: 32 rows x 16 k x bf16
@@ -78,20 +78,6 @@ __device__ __forceinline__ long chunk0(const PlanesSide &o, int ks)
     const int j = (jj >> 1) + ((jj & 1) << o.sshift);
     const int smask = (1 << o.sshift) - 1;
     return (long)((c << o.sshift) + (j & smask)) * o.rts + (j >> o.sshift);
-}
-
-// one LDS-DMA piece: lane l writes 16 bytes at lds_dst + 16 l, read from sbase + voff (bytes)
-__device__ __forceinline__ void glds16(unsigned lds_dst, unsigned voff, const void *sbase)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %1\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %3\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_dst), "v"(voff), "s"(sbase)
-                 : "memory");
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

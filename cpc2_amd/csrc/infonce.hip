@@ -12,11 +12,13 @@
 // column k of that tile -- computed by the same MFMA chain as the negatives, so a negative that happens
 // to be the positive frame ties EXACTLY, as in the reference) followed by the Nneg gathered negatives.
 #include "common.h"
+#include "ldsdma.h"
 
 #include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace cpc {
 
@@ -35,7 +37,9 @@ struct NceArgs {
     long p_stride;
     int p_rows;
     const float *z;        // [b*T][H]
-    const int32_t *ext;    // [b][W][Nneg]  TIME-MAJOR index layout (the negatives of one (b,t) are contiguous)
+    const int32_t *ext;    // [b][W][Nneg]  TIME-MAJOR index layout (the negatives of one (b,t) are contiguous); inside the
+                           // library: sorted by z-row block (nce_block_sort_kernel), slot g holds the caller's negative perm[g]
+    const unsigned short *perm;   // [b][W][Nneg]: the caller's negative number of slot g (logits keep the caller's order)
     const float *weights;  // [b*W] or null
     float *logits;         // [b*W][K][Nneg+1]
     float *lse;            // [b*W][K]
@@ -49,11 +53,42 @@ struct NceArgs {
     float *vbuf;           // [b*W][K + Nneg][H] or null: every candidate's dz contribution stored once (see below)
     float *ds_buf;         // [b*W][17][lw]: dS and the candidate rows, handed from infonce_bwd_kernel to the dz kernels
     float inv_count;       // 1 / (b*W)
+    unsigned long long *stamps;   // diagnostic build (CPC_NCE_STAMP=1): per wave, s_memtime at five points of the forward kernel
 };
+
+// The gather table z (b*T rows) is larger than one XCD's L2 (8.4 MB against 4 MB at the benchmark shape), and a (b,t)'s
+// negatives are spread uniformly over it: every wave walking ITS negatives in the order they were drawn makes the chip's
+// working set the whole table, and about half of the gathered rows miss L2.  Sorted by z-row BLOCK (blocks of ~2 MB), all
+// waves -- they start together and do the same amount of work per candidate -- are in the same block at the same time:
+// the working set is a block or two.  One wave per (b,t): stable counting sort of its Nneg indices by block, and the
+// permutation (the logits keep the caller's candidate order; losses and gradients do not depend on the order).
+__global__ __launch_bounds__(64) void nce_block_sort_kernel(const int32_t *ext, int32_t *sorted, unsigned short *perm, int Nneg,
+                                                            int rows_per_block, int nblk)
+{
+    const long base = (long)blockIdx.x * Nneg;
+    const int lane = threadIdx.x;
+    int pos = 0;
+    for (int blk = 0; blk < nblk; ++blk)
+        for (int c = 0; c < Nneg; c += 64) {
+            const int j = c + lane;
+            const int row = j < Nneg ? ext[base + j] : -1;
+            const bool mine = j < Nneg && min(row / rows_per_block, nblk - 1) == blk;
+            const unsigned long long m = __ballot(mine);
+            if (mine) {
+                const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
+                sorted[base + at] = row;
+                perm[base + at] = (unsigned short)j;
+            }
+            pos += __popcll(m);
+        }
+}
 
 // z row of candidate g of (bb, t): g < 16 -> positive tile (row t+1+g, only g < K), else negative g-16
 __device__ __forceinline__ long nce_row(const NceArgs &a, int bb, int t, int g)
 {
+#if defined(NCE_DBG) && (NCE_DBG & 1)
+    return (g < NCE_POS || g - NCE_POS < a.Nneg) ? (long)(g & 15) : -1;       // probe: every candidate from 16 hot rows
+#endif
     if (g < NCE_POS) return (g < a.K && t + 1 + g < a.T) ? (long)bb * a.T + t + 1 + g : -1;
     const int j = g - NCE_POS;
     return j < a.Nneg ? (long)a.ext[((long)bb * a.W + t) * a.Nneg + j] : -1;
@@ -73,6 +108,8 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
     const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     const float inv_h = 1.f / H;
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    if (a.stamps) st0 = __builtin_amdgcn_s_memtime();
     float4 areg[KK];
     {
         const float *prow = a.Pk[r < a.K ? r : 0] + ((long)bb * a.p_rows + t) * a.p_stride + 4 * q;
@@ -84,21 +121,46 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
     float pos[4] = {0.f, 0.f, 0.f, 0.f};
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f};
 
-    long row = nce_row(a, bb, t, r);
+    // the wave's negative rows (and their numbers in the caller's order) go to LDS first, in one coalesced round trip: a
+    // tile's row loads then issue at once instead of behind an index load of their own (two dependent L2 round trips per
+    // tile were the kernel's critical path)
+    extern __shared__ __attribute__((aligned(16))) int fwd_lds[];
+    int *lrow = fwd_lds;                                                             // [Nneg]
+    unsigned short *lperm = reinterpret_cast<unsigned short *>(fwd_lds + a.Nneg);    // [Nneg]
+    for (int j = lane; j < a.Nneg; j += 64) {
+        lrow[j] = a.ext[(long)bt * a.Nneg + j];
+        lperm[j] = a.perm != nullptr ? a.perm[(long)bt * a.Nneg + j] : (unsigned short)j;
+    }
+    __syncthreads();                           // one wave
+    auto cand_row = [&](int g) -> long {       // z row of candidate g: the positive tile, then the negatives
+#if defined(NCE_DBG) && (NCE_DBG & 1)
+        return (g < NCE_POS || g - NCE_POS < a.Nneg) ? (long)(g & 15) : -1;
+#endif
+        if (g < NCE_POS) return (g < a.K && t + 1 + g < a.T) ? (long)bb * a.T + t + 1 + g : -1;
+        return g - NCE_POS < a.Nneg ? (long)lrow[g - NCE_POS] : -1;
+    };
+
+    // (rows of padding candidates are clamped to row 0, not zeroed: their columns are never used, and an unconditional
+    // load keeps the loop free of branches -- hipcc then waits for the CURRENT tile's loads only, not for the prefetch)
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
+    long row = max(cand_row(r), 0L);
     float4 bcur[KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-        bcur[kk] = row >= 0 ? *reinterpret_cast<const float4 *>(a.z + row * H + 4 * q + 16 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kk = 0; kk < KK; ++kk) bcur[kk] = *reinterpret_cast<const float4 *>(a.z + row * H + 4 * q + 16 * kk);
 
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st2 = __builtin_amdgcn_s_memtime(); }
     for (int tile = 0; tile < ntiles; ++tile) {
         // prefetch the next tile's rows while this one is multiplied
         float4 bnext[KK];
-        const long nrow = (tile + 1 < ntiles) ? nce_row(a, bb, t, 16 * (tile + 1) + r) : -1;
+        const long nrow = max(cand_row(16 * (tile + 1) + r), 0L);        // (past the last tile: row 0, unused)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-            bnext[kk] = nrow >= 0 ? *reinterpret_cast<const float4 *>(a.z + nrow * H + 4 * q + 16 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kk = 0; kk < KK; ++kk) bnext[kk] = *reinterpret_cast<const float4 *>(a.z + nrow * H + 4 * q + 16 * kk);
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#if defined(NCE_DBG) && (NCE_DBG & 2)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) acc[kk & 3] += bcur[kk].x + bcur[kk].y + bcur[kk].z + bcur[kk].w;   // probe: no MFMA
+#else
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].x, bcur[kk].x, acc, 0, 0, 0);
@@ -106,28 +168,34 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].z, bcur[kk].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kk].w, bcur[kk].w, acc, 0, 0, 0);
         }
+#endif
+        // the prefetched rows are taken over HERE, before this tile's logits are stored: vmcnt counts stores too, and a
+        // wait for the rows placed behind the stores would sit out a store round trip per tile
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bcur[kk] = bnext[kk];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tile == 0) {
             // positive of step k = column k of this tile: lane 16q + (4q+e) of row group q holds it
 #pragma unroll
             for (int e = 0; e < 4; ++e) pos[e] = __shfl(acc[e], 16 * q + 4 * q + e, 64) * inv_h;
         } else {
-            const int j = 16 * (tile - 1) + r;              // negative index of this lane's column
+            const int j = 16 * (tile - 1) + r;              // negative slot of this lane's column
             if (j < a.Nneg) {
+                const int jo = lperm[j];                    // the caller's number of it
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = 4 * q + e;
                     const float x = acc[e] * inv_h;
-                    if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + j] = x;
+                    if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + jo] = x;
                     const float mn = fmaxf(m[e], x);
                     s[e] = s[e] * expf(m[e] - mn) + expf(x - mn);    // m = -inf: s = 0, exp(-inf) = 0
                     m[e] = mn;
                 }
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bcur[kk] = bnext[kk];
     }
 
+    if (a.stamps) st3 = __builtin_amdgcn_s_memtime();
     // merge (m, s) over the 16 lanes of the row group; lanes that saw no candidate carry (-inf, 0)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -154,6 +222,206 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
                 a.lse[(long)bt * a.K + k] = lse;
                 a.lossp[(long)bt * a.K + k] = wgt * (lse - pos[e]);
                 a.hit[(long)bt * a.K + k] = pos[e] >= m[e] ? 1.f : 0.f;       // first-index-wins argmax
+            }
+        }
+    }
+    if (a.stamps && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *o = a.stamps + (long)bt * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memtime(); o[5] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// The same forward pass for H = 256 / 512 as a STREAM through LDS.  Lanes that each pull 16-byte pieces of "their" row (the
+// kernel above) make every load instruction touch 16 half-used cache lines, and a wave that starts by loading its own P
+// rows idles its SIMD for microseconds; measured, that kernel spends a third of its time multiplying.  Here:
+//   * one global_load_lds_dwordx4 moves one KiB of whole row pieces (KC = 128 floats of two rows) into LDS, the rows chosen
+//     per half wave; an ELEMENT of the stream = 16 rows x KC floats = 8 such pieces, a piece 32 bytes past a KiB multiple
+//     from the previous one (fragment reads -- lane (n, q): 16 bytes at row n, floats 4q + 16kk -- at most 2-way conflicts);
+//   * persistent waves, TWO per SIMD (an LDS-DMA instruction holds a wave's issue port for ~100 cycles: one wave requests
+//     while the other multiplies): a wave walks (b,t) = blockIdx, + gridDim, ... and its stream is P(b,t) [the K prediction
+//     rows, read from LDS into the A-operand registers], the candidate tiles, P of the NEXT (b,t) with its index list, ...:
+//     element e + 1 is requested before element e is used (s_waitcnt vmcnt(n_{e+1}): everything older than the newest
+//     request -- the logits stored meanwhile included -- has landed), two LDS slots per wave;
+//   * nothing else loads: no prologue, no staging registers.
+constexpr int NCE_KC = 128;                                  // floats of a row per element
+constexpr int NCE_PIECE = 1024 + 32;                         // bytes between pieces in LDS
+constexpr int NCE_PP = 16 * NCE_KC * 4 / 1024;               // pieces per element (8)
+constexpr int NCE_SLOT = NCE_PP * NCE_PIECE;
+constexpr int NCE_LIST = 1024 + 512;                         // bytes per index list in LDS: rows (int), numbers (ushort), <= 256
+template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel(NceArgs a, int n_bt)
+{
+    static_assert(H % NCE_KC == 0 && NCE_KC == 128, "two rows per piece");
+    constexpr int HS = H / NCE_KC;                           // elements per candidate tile (and per P)
+    constexpr int FR = NCE_KC / 16;                          // fragments (16 bytes per lane) per element
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const float inv_h = 1.f / H;
+    extern __shared__ __attribute__((aligned(1024))) char dma_lds[];
+    const unsigned lds0 = lds_addr(dma_lds);
+    const char *lists = dma_lds + 2 * NCE_SLOT;                                // [2][NCE_LIST]
+    const int ntiles = 1 + (a.Nneg + 15) / 16;
+    unsigned wslot = 0;                                                        // slot the next request fills
+    unsigned rslot = 0;                                                        // slot of the element to use next
+    const int up = lane >> 5;                                                  // which of a piece's two rows this lane moves
+    const unsigned vcol = (lane & 31) * 16;
+
+    // ---- requests: NCE_PP LDS-DMA instructions each (+ 2 for an index list)
+    auto req_rows = [&](int mine, int half) {              // lane r knows row r of the tile; K slice `half`
+        const unsigned dst = lds0 + wslot;
+#pragma unroll
+        for (int i = 0; i < NCE_PP; ++i) {
+            const int r0 = __builtin_amdgcn_readlane(mine, 2 * i), r1 = __builtin_amdgcn_readlane(mine, 2 * i + 1);
+            const unsigned vo = (unsigned)(up ? r1 : r0) * (unsigned)(H * 4) + (unsigned)(half * NCE_KC * 4) + vcol;
+            glds16(dst + i * NCE_PIECE, vo, a.z);
+        }
+        wslot ^= NCE_SLOT;
+    };
+    auto req_p = [&](int bt, int half) {                   // the K prediction rows of (b,t) (rows >= K: row 0, unused)
+        const int bb = bt / a.W, t = bt - bb * a.W;
+        const unsigned dst = lds0 + wslot;
+        const long off = ((long)bb * a.p_rows + t) * a.p_stride + half * NCE_KC;
+#pragma unroll
+        for (int i = 0; i < NCE_PP; ++i) {
+            const float *p0 = a.Pk[2 * i < a.K ? 2 * i : 0] + off, *p1 = a.Pk[2 * i + 1 < a.K ? 2 * i + 1 : 0] + off;
+            glds16_addr(dst + i * NCE_PIECE, reinterpret_cast<const char *>(up ? p1 : p0) + vcol);   // (the K predictions may be K tensors)
+        }
+        wslot ^= NCE_SLOT;
+    };
+    auto req_list = [&](int bt, int par) {                 // rows and numbers of (b,t)'s negatives
+        const unsigned dst = lds0 + 2 * NCE_SLOT + par * NCE_LIST;   // (the rows piece reads up to 1 KiB past a short list: inside `saved`)
+        glds16(dst, lane * 16, reinterpret_cast<const char *>(a.ext) + (long)bt * a.Nneg * 4);
+        if (lane < 32) glds16(dst + 1024, lane * 16, reinterpret_cast<const char *>(a.perm) + (long)bt * a.Nneg * 2);
+    };
+    auto wait_newest = [&](int n) {                        // everything older than the newest n DMA instructions has landed
+        if (n == NCE_PP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == NCE_PP + 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(NCE_PP == 8, "the waits above are written for 8 pieces");
+    // lane (n = r, q): row n = piece n / 2, row n % 2 of it; floats 4q + 16kk
+    const unsigned fbase = lds0 + (r >> 1) * NCE_PIECE + (r & 1) * (NCE_KC * 4) + q * 16;
+    auto read_frags = [&](frag_t (&f)[FR]) {
+        const unsigned fa = fbase + rslot;
+        f[0] = lds_read16<0>(fa);     f[1] = lds_read16<64>(fa);    f[2] = lds_read16<128>(fa);   f[3] = lds_read16<192>(fa);
+        f[4] = lds_read16<256>(fa);   f[5] = lds_read16<320>(fa);   f[6] = lds_read16<384>(fa);   f[7] = lds_read16<448>(fa);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+                     :
+                     : "memory");
+        rslot ^= NCE_SLOT;
+    };
+
+    float4 areg[HS * FR];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int bt = blockIdx.x, par = 0;
+    if (bt >= n_bt) return;
+    req_p(bt, 0);
+    req_list(bt, 0);
+    for (; bt < n_bt; bt += gridDim.x, par ^= 1) {
+        const int bb = bt / a.W, t = bt - bb * a.W;
+        const int bt_next = bt + gridDim.x;
+        // ---- the P elements (the first one travelled with the index list): into the A-operand registers
+#pragma unroll
+        for (int half = 0; half < HS; ++half) {
+            if (half + 1 < HS) req_p(bt, half + 1);
+            else req_rows(r < a.K ? bb * a.T + t + 1 + r : 0, 0);           // tile 0 = the positives z[b][t+1 ..]: no list needed
+            wait_newest(NCE_PP);
+            frag_t f[FR];
+            read_frags(f);
+#pragma unroll
+            for (int kk = 0; kk < FR; ++kk) areg[half * FR + kk] = __builtin_bit_cast(float4, f[kk]);
+        }
+        // lists[par] has landed (it is older than the P elements' successors)
+        const int *lrow = reinterpret_cast<const int *>(lists + par * NCE_LIST);
+        const unsigned short *lperm = reinterpret_cast<const unsigned short *>(lists + par * NCE_LIST + 1024);
+        float pos[4] = {0.f, 0.f, 0.f, 0.f};
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+            for (int half = 0; half < HS; ++half) {
+                // request the next element of the stream, then take this one
+                int newest = NCE_PP;
+                if (half + 1 < HS) {
+                    const int g = 16 * tile + r;
+                    req_rows(g < NCE_POS ? (g < a.K ? bb * a.T + t + 1 + g : 0) : (g - NCE_POS < a.Nneg ? lrow[g - NCE_POS] : 0), half + 1);
+                } else if (tile + 1 < ntiles) {
+                    const int j = 16 * tile + r;                            // negative slot of candidate 16 (tile + 1) + r
+                    req_rows(j < a.Nneg ? lrow[j] : 0, 0);                  // (padding candidates: row 0, columns never used)
+                } else if (bt_next < n_bt) {
+                    req_p(bt_next, 0);
+                    req_list(bt_next, par ^ 1);
+                    newest = NCE_PP + 2;
+                } else {
+                    newest = 0;
+                }
+                wait_newest(newest);
+                frag_t bf[FR];
+                read_frags(bf);
+#pragma unroll
+                for (int kk = 0; kk < FR; kk += 2) {
+                    const float4 p0 = areg[half * FR + kk], p1 = areg[half * FR + kk + 1];
+                    const f32x4 b0 = __builtin_bit_cast(f32x4, bf[kk]), b1 = __builtin_bit_cast(f32x4, bf[kk + 1]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0.x, b0[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1.x, b1[0], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0.y, b0[1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1.y, b1[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0.z, b0[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1.z, b1[2], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0.w, b0[3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1.w, b1[3], acc1, 0, 0, 0);
+                }
+            }
+            // ---- a candidate tile is complete
+            f32x4 acc = acc0 + acc1;
+            acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1 = acc0;
+            if (tile == 0) {
+                // positive of step k = column k of this tile: lane 16q + (4q+e) of row group q holds it
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pos[e] = __shfl(acc[e], 16 * q + 4 * q + e, 64) * inv_h;
+            } else {
+                const int j = 16 * (tile - 1) + r;              // negative slot of this lane's column
+                if (j < a.Nneg) {
+                    const int jo = lperm[j];                    // the caller's number of it
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * q + e;
+                        const float x = acc[e] * inv_h;
+                        if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + jo] = x;
+                        const float mn = fmaxf(m[e], x);
+                        sm[e] = sm[e] * expf(m[e] - mn) + expf(x - mn);  // m = -inf: s = 0, exp(-inf) = 0
+                        m[e] = mn;
+                    }
+                }
+            }
+        }
+        // merge (m, s) over the 16 lanes of the row group; lanes that saw no candidate carry (-inf, 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float m2 = __shfl_xor(m[e], off, 64), s2 = __shfl_xor(sm[e], off, 64);
+                const float mn = fmaxf(m[e], m2);
+                const float f1 = (m[e] == -INFINITY) ? 0.f : expf(m[e] - mn);
+                const float f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+                sm[e] = sm[e] * f1 + s2 * f2;
+                m[e] = mn;
+            }
+        }
+        if (r == 0) {
+            const float wgt = a.weights != nullptr ? a.weights[bt] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * q + e;
+                if (k < a.K) {
+                    const float mx = fmaxf(m[e], pos[e]);
+                    const float se = sm[e] * expf(m[e] - mx) + expf(pos[e] - mx);
+                    const float lse = mx + logf(se);
+                    a.logits[((long)bt * a.K + k) * (a.Nneg + 1)] = pos[e];
+                    a.lse[(long)bt * a.K + k] = lse;
+                    a.lossp[(long)bt * a.K + k] = wgt * (lse - pos[e]);
+                    a.hit[(long)bt * a.K + k] = pos[e] >= m[e] ? 1.f : 0.f;       // first-index-wins argmax
+                }
             }
         }
     }
@@ -226,7 +494,7 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
                 if (g < NCE_POS) {
                     if (g == k) v = coef * (expf(lg[0] - l) - 1.f);
                 } else if (g - NCE_POS < a.Nneg) {
-                    v = coef * expf(lg[1 + g - NCE_POS] - l);
+                    v = coef * expf(lg[1 + (a.perm != nullptr ? (int)a.perm[bt * a.Nneg + g - NCE_POS] : g - NCE_POS)] - l);
                 }
             }
             dS[k * a.lw + g] = v;
@@ -507,6 +775,9 @@ __global__ void negidx_expand_kernel(const uint32_t *raw, int32_t *ext, int b, i
 struct NceLayout {
     int b, T, K, W, Har, Henc, Nneg, lw;
     float *P, *logits, *lse;            // saved
+    int32_t *ext_sorted;                // saved: the negatives of every (b,t) sorted by z-row block
+    unsigned short *perm;               // saved: slot -> the caller's negative number
+    int nblk, rows_per_block;
     size_t saved_bytes;
     float *lossp, *hit, *dP, *wt, *tn;  // scratch
     float *vbuf;                        // scratch: [b*W][K + Nneg][Henc] contribution rows of the dz product
@@ -529,6 +800,13 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.P = sv.take<float>((size_t)b * T * K * Henc);
     l.logits = sv.take<float>((size_t)b * l.W * K * (Nneg + 1));
     l.lse = sv.take<float>((size_t)b * l.W * K);
+    l.ext_sorted = sv.take<int32_t>((size_t)b * l.W * Nneg);
+    l.perm = sv.take<unsigned short>((size_t)b * l.W * Nneg + 1024);     // (+ slack: the streaming kernel reads whole KiB pieces)
+    // blocks of about 2 MB of z rows (an XCD's L2 holds 4 MB); CPC_NCE_NOSORT=1: one block = the drawn order
+    static const bool nosort = getenv("CPC_NCE_NOSORT") != nullptr;
+    const size_t zbytes = sizeof(float) * (size_t)b * T * Henc;
+    l.nblk = nosort ? 1 : (int)std::min<size_t>(16, std::max<size_t>(1, (zbytes + (1u << 21) - 1) >> 21));
+    l.rows_per_block = (int)cdiv((long)b * T, l.nblk);
     l.saved_bytes = sv.used();
     Carver sc(scratch);
     l.lossp = sc.take<float>((size_t)b * l.W * K);
@@ -543,7 +821,7 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.vbuf = sc.take<float>((size_t)b * l.W * (K + Nneg) * Henc);
     l.ds_buf = sc.take<float>((size_t)b * l.W * (NCE_ROWS + 1) * l.lw);
     l.scratch_bytes = sc.used();
-    l.lds_fwd = 0;
+    l.lds_fwd = align_up(sizeof(int) * (size_t)Nneg + sizeof(unsigned short) * (size_t)Nneg, 16);
     l.lds_bwd = sizeof(float) * (size_t)NCE_ROWS * l.lw + sizeof(int) * (size_t)l.lw;
     CPC_REQUIRE(l.lds_bwd <= 64 * 1024, "infonce: n_neg=%d needs %zu B of LDS (> 64 KiB)", Nneg, l.lds_bwd);
     return CPC_OK;
@@ -568,22 +846,74 @@ template <typename Kern> static int allow_lds(Kern kern, size_t bytes)
 
 static void nce_common(NceArgs &a, const NceLayout &l, const float *z, const int32_t *ext, const float *weights)
 {
-    a.z = z; a.ext = ext; a.weights = weights; a.logits = l.logits; a.lse = l.lse; a.lossp = l.lossp; a.hit = l.hit;
+    (void)ext;                                  // the kernels walk the block-sorted copy (forward: nce_sort_negatives)
+    a.z = z; a.ext = l.ext_sorted; a.perm = l.perm; a.weights = weights; a.logits = l.logits; a.lse = l.lse; a.lossp = l.lossp; a.hit = l.hit;
     a.b = l.b; a.T = l.T; a.W = l.W; a.K = l.K; a.Nneg = l.Nneg; a.lw = l.lw; a.inv_count = 1.f / ((float)l.b * l.W);
+}
+
+static int nce_sort_negatives(const NceLayout &l, const int32_t *ext, hipStream_t st)
+{
+    CPC_REQUIRE(l.Nneg <= 65535, "infonce: at most 65535 negatives (got %d)", l.Nneg);
+    hipLaunchKernelGGL(nce_block_sort_kernel, dim3((unsigned)(l.b * l.W)), dim3(64), 0, st, ext, l.ext_sorted, l.perm, l.Nneg,
+                       l.rows_per_block, l.nblk);
+    CPC_CHECK_LAUNCH("nce_block_sort_kernel");
+    return CPC_OK;
 }
 
 static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *acc, hipStream_t st)
 {
+    static const bool stamp = getenv("CPC_NCE_STAMP") != nullptr;
+    static unsigned long long *stamps = nullptr;
+    const long nw = (long)l.b * l.W;
+    if (stamp && nw <= 65536) {
+        if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 65536 * 8 * sizeof(unsigned long long)));
+        a.stamps = stamps;
+    }
     int status = CPC_OK;
     {
         ProfScope prof(PROF_NCE_FWD, st);
-        NCE_DISPATCH(l.Henc, {
-            status = allow_lds(infonce_fwd_kernel<HH>, l.lds_fwd);
-            if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_fwd, st, a);
-        });
+        static const bool no_dma = getenv("CPC_NCE_NO_DMA") != nullptr;           // A/B switch: the register-gather kernel
+        if (!no_dma && (l.Henc == 256 || l.Henc == 512) && a.stamps == nullptr && l.Nneg % 8 == 0 && l.Nneg <= 256 && a.perm != nullptr) {
+            // persistent waves, two per SIMD: 8 workgroups of one wave per CU (LDS: two 8.25 KiB slots + two index lists each)
+            const size_t lds = 2 * NCE_SLOT + 2 * NCE_LIST;
+            static int n_cus = 0;
+            if (n_cus == 0) {
+                int dev = 0;
+                CPC_CHECK_HIP(hipGetDevice(&dev));
+                CPC_CHECK_HIP(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+            }
+            const int n_bt = l.b * l.W;
+            const unsigned grid = (unsigned)std::min(n_bt, 8 * n_cus);
+            if (l.Henc == 256) {
+                status = allow_lds(infonce_fwd_dma_kernel<256>, lds);
+                if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_dma_kernel<256>, dim3(grid), dim3(64), lds, st, a, n_bt);
+            } else {
+                status = allow_lds(infonce_fwd_dma_kernel<512>, lds);
+                if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_dma_kernel<512>, dim3(grid), dim3(64), lds, st, a, n_bt);
+            }
+        } else {
+            NCE_DISPATCH(l.Henc, {
+                status = allow_lds(infonce_fwd_kernel<HH>, l.lds_fwd);
+                if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_fwd, st, a);
+            });
+        }
     }
     CPC_TRY(status);
     CPC_CHECK_LAUNCH("infonce_fwd_kernel");
+    if (a.stamps != nullptr) {
+        static std::vector<unsigned long long> h(65536 * 8);
+        CPC_CHECK_HIP(hipStreamSynchronize(st));
+        CPC_CHECK_HIP(hipMemcpy(h.data(), stamps, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double p = 0, f = 0, lp = 0, e = 0;
+        unsigned long long r0 = ~0ull, r1 = 0;
+        for (long i = 0; i < nw; ++i) {
+            p += (double)(h[i * 8 + 1] - h[i * 8]); f += (double)(h[i * 8 + 2] - h[i * 8 + 1]); lp += (double)(h[i * 8 + 3] - h[i * 8 + 2]);
+            e += (double)(h[i * 8 + 4] - h[i * 8 + 3]);
+            r0 = std::min(r0, h[i * 8 + 5]); r1 = std::max(r1, h[i * 8 + 5]);
+        }
+        fprintf(stderr, "infonce_fwd stamps (cycles per wave): P loads %.0f, first tile rows %.0f, tile loop %.0f, epilogue %.0f; last - first wave exit %.1f us\n",
+                p / nw, f / nw, lp / nw, e / nw, (double)(r1 - r0) * 0.01);
+    }
     hipLaunchKernelGGL(infonce_reduce_kernel, dim3(2 * l.K), dim3(256), 0, st, l.lossp, l.hit, (long)l.b * l.W, l.K, a.inv_count, losses, acc);
     CPC_CHECK_LAUNCH("infonce_reduce_kernel");
     return CPC_OK;
@@ -669,6 +999,7 @@ static int infonce_forward(const float *c, const float *z, const float *wpred, c
     RowMap none{};
     // all K predictors in one GEMM: P[(b,t)][k*Henc + e] = sum_a c[b,t,a] * W_k[e][a]     (criterion.py:163)
     CPC_TRY(gemm_nt(c, Har, wpred, Har, l.P, (long)K * Henc, nullptr, (long)b * T, K * Henc, Har, none, st));
+    CPC_TRY(nce_sort_negatives(l, ext, st));
     NceArgs a{};
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) a.Pk[k] = l.P + (size_t)k * Henc;
@@ -704,6 +1035,7 @@ static int infonce_forward_pred(const float *const *pred, const float *z, const 
 {
     NceLayout l;
     CPC_TRY(nce_layout(l, b, T, K, Henc, Henc, Nneg, saved, scratch));
+    CPC_TRY(nce_sort_negatives(l, ext, st));
     NceArgs a{};
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) a.Pk[k] = pred[k];
