@@ -160,6 +160,7 @@ template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_plane
     int n0, ks0, nst;
     unsigned a_vo, b_vo;                                                // LDS-DMA: byte offset of this lane's 16 bytes
     long rbeg = 0;
+    unsigned slab_z = blockIdx.z;
     if constexpr (!TN) {
         long mt = blockIdx.x / p.tiles_n;
         int nt = (int)(blockIdx.x % p.tiles_n);
@@ -182,10 +183,22 @@ template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_plane
         b_vo = (unsigned)(32 * (bseg * p.B.seg_q + (nb - bseg * p.B.segv)) + 16 * h);
     } else {
         // blockIdx.x: column tile (j), .y: row tile (i), .z: slab of rchunk reduction rows
-        m0 = (long)blockIdx.y * PT_BM;
-        n0 = (int)blockIdx.x * PT_BN;
+        unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+        if (p.xcd_remap) {
+            // workgroups go to the 8 XCDs round robin in dispatch order (x fastest): ALL tiles of a slab on ONE XCD, so that
+            // the slab's rows of both operands are fetched into one L2 instead of eight (the column tiles of a conv weight
+            // gradient are its taps: they read the same dU rows, and taps j, j + s the same signal rows)
+            const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const unsigned tiles = gridDim.x * gridDim.y, i = lin >> 3, tile = i % tiles;
+            bz = (i / tiles) * 8 + (lin & 7);
+            by = tile / gridDim.x;
+            bx = tile % gridDim.x;
+        }
+        m0 = (long)by * PT_BM;
+        n0 = (int)bx * PT_BN;
         ks0 = 0;
-        rbeg = (long)blockIdx.z * p.rchunk;
+        rbeg = (long)bz * p.rchunk;
+        slab_z = bz;
         nst = (int)((min(p.R, rbeg + p.rchunk) - rbeg) / PT_BK);        // even, >= 2
         // wave w fills the 32 columns (two chunks) 32 w .. 32 w + 31 of both tiles; lane -> (4-row group, chunk, row, half)
         const int rowp = 4 * (lane >> 4) + ((lane >> 1) & 3), ch = (lane >> 3) & 1, half = lane & 1;
@@ -322,7 +335,7 @@ template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_plane
     for (int j = 0; j < 2; ++j) bias_v[j] = (!TN && p.bias != nullptr && blockIdx.y == 0) ? p.bias[nw + j * 32 + r32] : 0.f;
     const int jrow = (p.map.enabled && p.map.col_rows > 0) ? nw / p.map.col_rows : 0;
     const long rv = p.map.enabled ? p.map.rv : (1L << 62);
-    float *const out = TN ? p.slabs + (long)blockIdx.z * p.M * p.N : p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.slab_rows * p.N : p.C;
+    float *const out = TN ? p.slabs + (long)slab_z * p.M * p.N : p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.slab_rows * p.N : p.C;
     const long ldo = (TN || p.slabs != nullptr) ? p.N : p.ldc;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -534,7 +547,12 @@ static int tn_planes_splits(int M, int N, long R, long *chunk_out)
     const long Rp = cdiv(R, 32) * 32;
     long S = std::max<long>(1, (256 + tiles / 2) / tiles);            // one workgroup per CU, one round
     S = std::min(S, std::max<long>(1, Rp / 128));
-    const long chunk = cdiv(cdiv(Rp, S), 32) * 32;
+    long chunk = cdiv(cdiv(Rp, S), 32) * 32;
+    // a slab count that is a multiple of 8 lets all tiles of a slab share an XCD (gemm_planes_kernel, xcd_remap): look for
+    // one among slightly larger chunks
+    if (S >= 8 && tiles > 1)
+        for (long c = chunk; c <= chunk + 32 * 16; c += 32)
+            if (cdiv(Rp, c) % 8 == 0) { chunk = c; break; }
     *chunk_out = chunk;
     return (int)cdiv(Rp, chunk);
 }
@@ -576,6 +594,8 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     a.rchunk = chunk;
     a.M = M; a.N = N; a.K = 0; a.slabs = static_cast<float *>(scratch);
     a.dbg = 0;
+    static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
+    a.xcd_remap = (!no_remap && S % 8 == 0 && (M / PT_BM) * (N / PT_BN) > 1) ? 1 : 0;
     {
         ProfScope prof(PROF_PLANES_TN, st);
         hipLaunchKernelGGL((gemm_planes_kernel<0, true>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
