@@ -636,6 +636,197 @@ template <int H> __global__ __launch_bounds__(64) void infonce_dz_store_kernel(N
     }
 }
 
+// Backward at encoder width 256 / 512 with stored contributions: both halves above in ONE workgroup per (b,t), H/128 waves
+// that each own 128 of the H channels -- half the accumulators and operands of the one-wave form, so more waves per SIMD
+// stay resident and the candidate-row gathers of some overlap the 1 GB of contribution-row stores of others.
+//   phase 0  dS[16][lw] and the candidates' z rows into LDS.  ONE round of global loads: the index lists and the K logits
+//            rows are requested together (the rows land in LDS in the caller's order and are picked up through perm there);
+//            under load a dependent global load costs microseconds
+//   phase 1  dP[k][d] (as infonce_bwd_kernel, d in this wave's 128 channels), the rows of the next 16 candidates
+//            requested before the current 16 are multiplied
+//   phase 2  V[cand][d] = sum_k dS[k][cand] * P_k[d]  16x16x4: M = d, so a lane holds four consecutive channels of one
+//            candidate; 16 candidates x 64 channels go through a wave-private LDS tile and leave as 256-byte row pieces,
+//            16 bytes per lane (the one-dword-per-lane form of infonce_dz_store_kernel stored at 3.9 TB/s).  The
+//            contribution buffer keeps 16 rows for the positive slots, so no store is conditional (rows of unused slots
+//            are written as zeros and never read).
+// NKK = ceil(K / 4).  Needs Nneg % 16 == 0, lw <= 320 and K * (Nneg + 1) floats within the staging tiles.
+constexpr int NCE_SROW = 68;               // staging tile row: 64 channels + 4 floats
+template <int H, int NKK> __global__ __launch_bounds__(H / 2) void infonce_bwd_fused_kernel(NceArgs a)
+{
+    constexpr int NW = H / 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *dS = smem;                                              // [16][lw]
+    int *rowidx = reinterpret_cast<int *>(dS + NCE_ROWS * a.lw);   // [lw]
+    float *stage0 = reinterpret_cast<float *>(rowidx + a.lw);      // [NW][16][NCE_SROW]; phase 0: the K logits rows
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    float *stage = stage0 + wave * 16 * NCE_SROW;
+
+    const int bb = blockIdx.x / a.p_rows, t = blockIdx.x - bb * a.p_rows;
+    if (t >= a.W) {            // only reached when p_rows == T: zero the unused rows of the GEMM-shaped dP
+        for (int k = 0; k < a.K; ++k) {
+            float *row = a.dPk[k] + ((long)bb * a.p_rows + t) * a.p_stride;
+            for (int i = threadIdx.x; i < H / 4; i += 64 * NW) reinterpret_cast<float4 *>(row)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const long bt = (long)bb * a.W + t;
+    const int ncand = NCE_POS + a.Nneg;
+    const int npad = a.lw - 4;                                     // multiple of 32 >= ncand
+    const float inv_h = 1.f / H;
+    const float wgt = (a.weights != nullptr ? a.weights[bt] : 1.f) * a.inv_count;
+    unsigned long long *stamp = a.stamps != nullptr && threadIdx.x == 0 ? a.stamps + bt * 8 : nullptr;
+    if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+
+    // ---- phase 0 -------------------------------------------------------------------------------
+    // (loads are unconditional, from clamped addresses, and selected afterwards: a load under a lane condition becomes a
+    //  branch with its own wait)
+    constexpr int GI = 5;                                          // candidate slots per lane: lw <= 320
+    constexpr int KW = NCE_ROWS / NW;                              // prediction steps per wave: k = wave + NW * kk
+    const int lrow = a.Nneg + 1;
+    int gi[GI];                                                    // where candidate g = lane + 64 i sits in a logits row
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        const int j = lane + 64 * i - NCE_POS;
+        const int pj = 1 + (int)a.perm[bt * a.Nneg + min(max(j, 0), a.Nneg - 1)];
+        gi[i] = j >= 0 && j < a.Nneg ? pj : 0;                     // (slot k < 16, the positive of step k: element 0)
+    }
+    float coef[KW], lsek[KW];
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+        const int kc = min(wave + NW * kk, a.K - 1);
+        coef[kk] = a.dloss[kc] * wgt * inv_h;
+        lsek[kk] = a.lse[bt * a.K + kc];
+    }
+    {
+        const float *lg = a.logits + bt * a.K * lrow;              // K rows, contiguous
+        const int n = a.K * lrow;
+        constexpr int NT = 16 * NCE_SROW / 64;                    // the staging tiles hold NT floats per thread (host: n fits)
+        float tmp[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tmp[i] = lg[min((int)threadIdx.x + 64 * NW * i, n - 1)];
+        for (int g = threadIdx.x; g < a.lw; g += 64 * NW) {
+            const int j = min(max(g - NCE_POS, 0), a.Nneg - 1);
+            const int neg = a.ext[bt * a.Nneg + j];
+            const int pos = (g < a.K && t + 1 + g < a.T) ? bb * a.T + t + 1 + g : -1;
+            rowidx[g] = g < NCE_POS ? pos : (g < ncand ? neg : -1);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if ((int)threadIdx.x + 64 * NW * i < n) stage0[threadIdx.x + 64 * NW * i] = tmp[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+        const int k = wave + NW * kk, kc = min(k, a.K - 1);
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int g = lane + 64 * i;
+            const float e = expf(stage0[kc * lrow + gi[i]] - lsek[kk]);
+            float v = g >= NCE_POS ? (g < ncand ? coef[kk] * e : 0.f) : (g == k ? coef[kk] * (e - 1.f) : 0.f);
+            if (k >= a.K) v = 0.f;
+            if (g < a.lw) dS[k * a.lw + g] = v;
+        }
+    }
+    __syncthreads();
+    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+
+    // ---- phase 1: dP -----------------------------------------------------------------------------
+    const int d0 = 128 * wave;
+    {
+        f32x4 dp[2][4];
+#pragma unroll
+        for (int T4 = 0; T4 < 2; ++T4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[T4][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 av[2][4][2];
+        float bv4[2][4];
+        auto request = [&](int buf, int s0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = 4 * (s0 + u) + q;
+                const int row = rowidx[g];
+                bv4[buf][u] = dS[r * a.lw + g];
+                const float *src = a.z + (long)(row >= 0 ? row : 0) * H + d0 + 4 * r;      // (row 0 for the padding: dS is 0 there)
+                av[buf][u][0] = *reinterpret_cast<const float4 *>(src);
+                av[buf][u][1] = *reinterpret_cast<const float4 *>(src + 64);
+            }
+        };
+        auto multiply = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int T4 = 0; T4 < 2; ++T4) {
+                    dp[T4][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][u][T4].x, bv4[buf][u], dp[T4][0], 0, 0, 0);
+                    dp[T4][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][u][T4].y, bv4[buf][u], dp[T4][1], 0, 0, 0);
+                    dp[T4][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][u][T4].z, bv4[buf][u], dp[T4][2], 0, 0, 0);
+                    dp[T4][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][u][T4].w, bv4[buf][u], dp[T4][3], 0, 0, 0);
+                }
+        };
+        const int nb = npad / 16;                                  // even (npad is a multiple of 32)
+        request(0, 0);
+        for (int ib = 0; ib < nb; ib += 2) {
+            request(1, 4 * (ib + 1));
+            multiply(0);
+            if (ib + 2 < nb) request(0, 4 * (ib + 2));
+            multiply(1);
+        }
+        // dp[T4][e][reg] = dP[k = r][d = d0 + 64*T4 + 4*(4q + reg) + e]
+        if (r < a.K) {
+            float *dprow = a.dPk[r] + ((long)bb * a.p_rows + t) * a.p_stride + d0;
+#pragma unroll
+            for (int T4 = 0; T4 < 2; ++T4)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    *reinterpret_cast<float4 *>(dprow + 64 * T4 + 16 * q + 4 * reg) =
+                        make_float4(dp[T4][0][reg], dp[T4][1][reg], dp[T4][2][reg], dp[T4][3][reg]);
+        }
+    }
+
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+    // ---- phase 2: contribution rows ------------------------------------------------------------------
+    const long prow_off = ((long)bb * a.p_rows + t) * a.p_stride + d0;
+    float pa[8][NKK];                                              // A: P_{4kk + q}[d0 + 16*tile + r]
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int k = 4 * kk + q;
+        const float *pk = a.Pk[min(k, a.K - 1)] + prow_off + r;
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            const float v = pk[16 * tile];
+            pa[tile][kk] = k < a.K ? v : 0.f;
+        }
+    }
+    // row `cand` of the (b,t)'s NCE_POS + Nneg contribution rows; this lane: rows 4j + q of a tile, its 16-byte piece r
+    float *vb = a.vbuf + (bt * (long)ncand + q) * H + d0 + 4 * r;
+    for (int c0 = 0; c0 < ncand; c0 += 16) {
+        float bv[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) bv[kk] = dS[(4 * kk + q) * a.lw + c0 + r];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * half + tl][kk], bv[kk], acc[tl], 0, 0, 0);
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) *reinterpret_cast<f32x4 *>(stage + r * NCE_SROW + 16 * tl + 4 * q) = acc[tl];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4 *>(stage + (4 * j + q) * NCE_SROW + 4 * r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(vb + (long)(c0 + 4 * j) * H + 64 * half) = v[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (stamp) { stamp[3] = __builtin_amdgcn_s_memtime(); stamp[4] = __builtin_amdgcn_s_memrealtime(); }
+}
+
 // ---- reference lists: which (b, t, negative) triples point at z row r (counting sort of ext by value) -------------
 __global__ void nce_hist_kernel(const int32_t *ext, long n, int *counts)
 {
@@ -699,7 +890,7 @@ __global__ __launch_bounds__(256) void nce_sort_kernel(const int *offsets, int *
 // come from (bb, t' - 1 - k), the negatives from the row's reference list.  One wave per row, 16 bytes per lane.
 template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel(const float *vbuf, const int *offsets,
                                                                                    const int *entries, float *dz, int b, int T,
-                                                                                   int W, int K, int Nneg)
+                                                                                   int W, int K, int Nneg, int pos_rows)
 {
     constexpr int C4 = H / 4;                        // float4 per row
     constexpr int PER = (C4 + 63) / 64;              // per lane
@@ -707,7 +898,7 @@ template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel
     const int r = blockIdx.x * 4 + wave;
     if (r >= b * T) return;
     const int bb = r / T, tp = r - bb * T;
-    const int vrows = K + Nneg;
+    const int vrows = pos_rows + Nneg;              // pos_rows = K (one-wave store kernel) or 16 (fused kernel)
     const float4 *v4 = reinterpret_cast<const float4 *>(vbuf);
     float4 acc[PER];
 #pragma unroll
@@ -721,18 +912,16 @@ template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel
             }
         }
     };
-    for (int k = 0; k < K; ++k) {
-        const int t = tp - 1 - k;
-        if (t >= 0 && t < W) add_row(((long)bb * W + t) * vrows + k);
-    }
+    // newest rows first: the lists are sorted by (b,t) and the contribution rows were written in that order, so the tail of
+    // every list is what the memory-side cache (256 MB of the 1.1 GB) still holds when this kernel starts
     const int beg = offsets[r], end = offsets[r + 1];
-    int e = beg;
-    for (; e + 8 <= end; e += 8) {                   // eight rows in flight
+    int e = end;
+    for (; e - 8 >= beg; e -= 8) {                   // eight rows in flight
         long src[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int o = entries[e + i];
-            src[i] = (long)(o / Nneg) * vrows + K + o % Nneg;
+            const int o = entries[e - 1 - i];
+            src[i] = (long)(o / Nneg) * vrows + pos_rows + o % Nneg;
         }
         float4 v[8][PER];
 #pragma unroll
@@ -745,9 +934,13 @@ template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel
 #pragma unroll
             for (int c = 0; c < PER; ++c) { acc[c].x += v[i][c].x; acc[c].y += v[i][c].y; acc[c].z += v[i][c].z; acc[c].w += v[i][c].w; }
     }
-    for (; e < end; ++e) {
-        const int o = entries[e];
-        add_row((long)(o / Nneg) * vrows + K + o % Nneg);
+    for (; e > beg; --e) {
+        const int o = entries[e - 1];
+        add_row((long)(o / Nneg) * vrows + pos_rows + o % Nneg);
+    }
+    for (int k = 0; k < K; ++k) {
+        const int t = tp - 1 - k;
+        if (t >= 0 && t < W) add_row(((long)bb * W + t) * vrows + k);
     }
 #pragma unroll
     for (int c = 0; c < PER; ++c)
@@ -784,7 +977,7 @@ struct NceLayout {
     float *ds_buf;                      // scratch: [b*W][17][lw]
     int *counts, *offsets, *entries;    // scratch: reference lists (counts doubles as the fill cursor)
     size_t tn_bytes, scratch_bytes;
-    size_t lds_fwd, lds_bwd;
+    size_t lds_fwd, lds_bwd, lds_bwd_fused;
 };
 
 static bool nce_supported(int H) { return H == 32 || H == 64 || H == 128 || H == 256 || H == 512; }
@@ -818,12 +1011,13 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.counts = sc.take<int>((size_t)b * T);
     l.offsets = sc.take<int>((size_t)b * T + 1);
     l.entries = sc.take<int>((size_t)b * l.W * Nneg);
-    l.vbuf = sc.take<float>((size_t)b * l.W * (K + Nneg) * Henc);
+    l.vbuf = sc.take<float>((size_t)b * l.W * (NCE_POS + Nneg) * Henc);
     l.ds_buf = sc.take<float>((size_t)b * l.W * (NCE_ROWS + 1) * l.lw);
     l.scratch_bytes = sc.used();
     l.lds_fwd = align_up(sizeof(int) * (size_t)Nneg + sizeof(unsigned short) * (size_t)Nneg, 16);
     l.lds_bwd = sizeof(float) * (size_t)NCE_ROWS * l.lw + sizeof(int) * (size_t)l.lw;
     CPC_REQUIRE(l.lds_bwd <= 64 * 1024, "infonce: n_neg=%d needs %zu B of LDS (> 64 KiB)", Nneg, l.lds_bwd);
+    l.lds_bwd_fused = l.lds_bwd + sizeof(float) * (size_t)(Henc / 128) * 16 * NCE_SROW;
     return CPC_OK;
 }
 
@@ -954,6 +1148,12 @@ static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t
     a.dz = dz;
     a.vbuf = atomic_dz ? nullptr : l.vbuf;
     a.ds_buf = l.ds_buf;
+    static const bool stamp = getenv("CPC_NCE_STAMP") != nullptr;
+    if (stamp && (long)l.b * l.W <= 65536) {
+        static unsigned long long *stamps = nullptr;
+        if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 65536 * 8 * sizeof(unsigned long long)));
+        a.stamps = stamps;
+    }
     ProfScope prof(PROF_NCE_BWD, st);
     NceSide *side = nullptr;
     if (atomic_dz) {
@@ -973,18 +1173,53 @@ static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t
         CPC_CHECK_HIP(hipEventRecord(side->join, side->stream));
     }
     int status = CPC_OK;
-    NCE_DISPATCH(l.Henc, {
-        status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
-        if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(l.b * a.p_rows)), dim3(64), l.lds_bwd, st, a);
-    });
+    static const bool no_fused = getenv("CPC_NCE_NO_FUSED_BWD") != nullptr;       // A/B switch: the two one-wave kernels
+    const bool fused = !atomic_dz && !no_fused && (l.Henc == 256 || l.Henc == 512) && a.perm != nullptr && l.lw <= 320 &&
+                       l.Nneg % 16 == 0 && (size_t)l.K * (l.Nneg + 1) <= (size_t)(l.Henc / 128) * 16 * NCE_SROW;
+    if (fused) {
+        const unsigned grid = (unsigned)(l.b * a.p_rows);
+#define NCE_FUSED(HH, NKK)                                                                                                  \
+    {                                                                                                                       \
+        status = allow_lds(infonce_bwd_fused_kernel<HH, NKK>, l.lds_bwd_fused);                                             \
+        if (status == CPC_OK) hipLaunchKernelGGL((infonce_bwd_fused_kernel<HH, NKK>), dim3(grid), dim3(HH / 2), l.lds_bwd_fused, st, a); \
+    }
+        const int nkk = (l.K + 3) / 4;
+        if (l.Henc == 256) {
+            if (nkk == 1) NCE_FUSED(256, 1) else if (nkk == 2) NCE_FUSED(256, 2) else if (nkk == 3) NCE_FUSED(256, 3) else NCE_FUSED(256, 4)
+        } else {
+            if (nkk == 1) NCE_FUSED(512, 1) else if (nkk == 2) NCE_FUSED(512, 2) else if (nkk == 3) NCE_FUSED(512, 3) else NCE_FUSED(512, 4)
+        }
+#undef NCE_FUSED
+    } else {
+        NCE_DISPATCH(l.Henc, {
+            status = allow_lds(infonce_bwd_kernel<HH>, l.lds_bwd);
+            if (status == CPC_OK) hipLaunchKernelGGL(infonce_bwd_kernel<HH>, dim3((unsigned)(l.b * a.p_rows)), dim3(64), l.lds_bwd, st, a);
+        });
+    }
     CPC_TRY(status);
     CPC_CHECK_LAUNCH("infonce_bwd_kernel");
+    if (fused && a.stamps != nullptr) {
+        const long nw = (long)l.b * l.W;
+        std::vector<unsigned long long> h(nw * 8);
+        CPC_CHECK_HIP(hipStreamSynchronize(st));
+        CPC_CHECK_HIP(hipMemcpy(h.data(), a.stamps, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double p0 = 0, p1 = 0, p2 = 0;
+        unsigned long long r0 = ~0ull, r1 = 0;
+        for (long i = 0; i < nw; ++i) {
+            p0 += (double)(h[i * 8 + 1] - h[i * 8]); p1 += (double)(h[i * 8 + 2] - h[i * 8 + 1]); p2 += (double)(h[i * 8 + 3] - h[i * 8 + 2]);
+            r0 = std::min(r0, h[i * 8 + 4]); r1 = std::max(r1, h[i * 8 + 4]);
+        }
+        fprintf(stderr, "infonce_bwd_fused stamps (cycles per workgroup): dS %.0f, dP %.0f, contribution rows %.0f; last - first exit %.1f us\n",
+                p0 / nw, p1 / nw, p2 / nw, (double)(r1 - r0) * 0.01);
+    }
     if (!atomic_dz) {
-        NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_store_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_bwd, st, a));
-        CPC_CHECK_LAUNCH("infonce_dz_store_kernel");
+        if (!fused) {
+            NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_store_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_bwd, st, a));
+            CPC_CHECK_LAUNCH("infonce_dz_store_kernel");
+        }
         CPC_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
         NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_gather_kernel<HH>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, l.vbuf,
-                                                 l.offsets, l.entries, dz, l.b, l.T, l.W, l.K, l.Nneg));
+                                                 l.offsets, l.entries, dz, l.b, l.T, l.W, l.K, l.Nneg, fused ? NCE_POS : l.K));
         CPC_CHECK_LAUNCH("infonce_dz_gather_kernel");
     }
     return CPC_OK;

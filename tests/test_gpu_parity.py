@@ -154,6 +154,129 @@ def test_gemm_split_accuracy(kind, shape, data):
     assert split_max <= 16 * 2.0 ** -24
 
 
+def _to_planes(lib, x, stride_log2=0):
+    """x[rows][cols] (f32, device) -> its three bf16 planes in 16-channel chunks (cpc_split_planes); rows padded to the stride."""
+    rows, cols = x.shape
+    s = 1 << stride_log2
+    assert rows % s == 0
+    rts = rows // s
+    plane = (cols // 16) * s * rts * 16
+    out = torch.zeros(3 * plane, dtype=torch.int16, device=x.device)
+    _lib.check(lib.cpc_split_planes(_lib.ptr(x), cols, rows, cols, _lib.ptr(out), plane, stride_log2, rts, _lib.stream_ptr(x.device)))
+    return out, plane, rts
+
+
+@pytest.mark.parametrize("taps,stride,n_win,frames,cols,data", [(8, 4, 5, 130, 256, "relu"), (4, 2, 3, 257, 512, "randn"),
+                                                               (1, 1, 1, 1000, 256, "wide"), (8, 4, 40, 128, 256, "tiny")])
+def test_plane_fed_gemm_nt_accuracy(taps, stride, n_win, frames, cols, data):
+    """cpc_gemm_nt_planes (operands stored as the three bf16 terms of every f32, six MFMA products): a strided Conv1d over a
+    channel-last signal as ONE product.  Its error against fp64 must be an f32 GEMM's: no worse than the f32-MFMA
+    kernel's (cpc_gemm_nt, mode 1) on the same overlapping rows, and a few f32 roundings of sum |a||b|."""
+    lib = _lib.load()
+    H = 256
+    g = torch.Generator().manual_seed(taps * 1000 + frames)
+    R = stride * (frames + 2) if taps > 1 else frames             # signal rows per window
+    rows = n_win * R + 2 * stride
+    y = torch.randn(rows, H, generator=g)
+    if data == "relu":
+        y = y.clamp_min(0)
+    if data == "wide":
+        y = y * torch.exp2(torch.randint(-20, 21, y.shape, generator=g).float())
+    w = torch.randn(cols, taps * H, generator=g) / (taps * H) ** 0.5
+    if data == "tiny":
+        y, w = y * 1e-9, w * 1e-7
+    bias = torch.randn(cols, generator=g) * float(y.abs().max() * w.abs().max())
+    yd, wd, bd = y.to(DEV), w.to(DEV), bias.to(DEV)
+    sl = stride.bit_length() - 1
+    K = taps * H
+    yp, ya, rts = _to_planes(lib, yd, sl)
+    order = [(jj >> 1) + (jj & 1) * stride for jj in range(taps)] if taps > 1 else [0]
+    wk = wd.view(cols, taps, H // 16, 16)[:, order].permute(0, 2, 1, 3).reshape(cols, K).contiguous()
+    wp, wa, _ = _to_planes(lib, wk)
+    # the planes add up to the operand EXACTLY (three bf16 terms hold 24 bits) unless a term falls under the bf16 range
+    rec = sum(yp[i * ya:(i + 1) * ya].view(torch.bfloat16).double() for i in range(3)).view(H // 16, stride, rts, 16)
+    rec = rec.permute(2, 1, 0, 3).reshape(rows, H)
+    if data != "tiny":
+        assert torch.equal(rec.cpu(), y.double())
+    M = n_win * frames
+    c = torch.empty(M, cols, device=DEV)
+    _lib.check(lib.cpc_gemm_nt_planes(_lib.ptr(yp), ya, taps.bit_length() - 1, sl, rts, frames, R // stride, _lib.ptr(wp), wa,
+                                      _lib.ptr(c), cols, _lib.ptr(bd), M, cols, K, _lib.stream_ptr(c.device)))
+    # the same product by the f32-MFMA kernel: virtual rows of stride * H floats, window n starts at row n * R / stride
+    virt = n_win * (R // stride)
+    prev = lib.cpc_gemm_set_mode(1)
+    try:
+        cv = torch.empty(virt, cols, device=DEV)
+        _lib.check(lib.cpc_gemm_nt(_lib.ptr(yd), stride * H, _lib.ptr(wd), K, _lib.ptr(cv), cols, _lib.ptr(bd), virt, cols, K,
+                                   _lib.stream_ptr(c.device)))
+    finally:
+        lib.cpc_gemm_set_mode(prev)
+    emax = {"planes": 0.0, "f32": 0.0}
+    esq = {"planes": 0.0, "f32": 0.0}
+    for n in range(n_win):
+        a = torch.as_strided(y, (frames, K), (stride * H, 1), n * R * H).double()
+        ref = a @ w.double().t() + bias.double()
+        mag = (a.abs() @ w.double().abs().t() + bias.double().abs()).clamp_min(1e-300)
+        for name, got in (("planes", c[n * frames:(n + 1) * frames]), ("f32", cv[n * (R // stride):n * (R // stride) + frames])):
+            e = (got.cpu().double() - ref).abs() / mag
+            emax[name] = max(emax[name], float(e.max()))
+            esq[name] += float(e.pow(2).mean()) / n_win
+    assert esq["planes"] ** 0.5 <= 1.25 * esq["f32"] ** 0.5 + 1e-10, (esq, emax)
+    assert emax["planes"] <= 1.5 * emax["f32"] + 1e-9, (esq, emax)
+    assert emax["planes"] <= 16 * 2.0 ** -24
+
+
+@pytest.mark.parametrize("stride,taps,n_rows,data", [(4, 8, 5 * 132, "relu"), (1, 1, 3000, "randn"), (2, 4, 64, "tiny")])
+def test_plane_fed_gemm_tn_accuracy(stride, taps, n_rows, data):
+    """cpc_gemm_tn_planes: the weight gradient of a strided Conv1d, dW[co][j * H + ci] = sum_m dU[m + 1][co] * Y[m * s + j][ci],
+    from the stored planes of dU and Y -- vs fp64 and vs the f32-MFMA kernel (cpc_gemm_tn, mode 1), and bitwise
+    repeatable (the row slabs are summed in a fixed order)."""
+    lib = _lib.load()
+    H = 256
+    g = torch.Generator().manual_seed(stride * 100 + n_rows)
+    K = taps * H
+    rows = ((n_rows + 63) // 64 * 64 + 2) * stride + taps          # (the kernel reads whole 32-row slabs: finite rows behind R)
+    rows = (rows + stride - 1) // stride * stride
+    y = torch.randn(rows, H, generator=g)
+    if data == "relu":
+        y = y.clamp_min(0)
+    rowsd = (n_rows + 2 + 63) // 32 * 32
+    du = torch.randn(rowsd, H, generator=g) * 0.1
+    du[n_rows + 1:] = 0
+    if data == "tiny":
+        y, du = y * 1e-7, du * 1e-9
+    yd, dud = y.to(DEV), du.to(DEV)
+    sl = stride.bit_length() - 1
+    yp, ya, rts = _to_planes(lib, yd, sl)
+    dup, da, _ = _to_planes(lib, dud)
+    st = _lib.stream_ptr(yd.device)
+    nb = lib.cpc_gemm_tn_planes_scratch_bytes(H, K, n_rows)
+    sc = torch.empty(max(nb, 1), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(H, K, device=DEV)
+        _lib.check(lib.cpc_gemm_tn_planes(_lib.ptr(dup), da, 0, rowsd, 1, H, _lib.ptr(yp), ya, sl, rts, 0, H, _lib.ptr(dw), K, H, K,
+                                          n_rows, _lib.ptr(sc), nb, st))
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    a = torch.as_strided(y, (n_rows, K), (stride * H, 1), 0).double()
+    d = du[1:1 + n_rows].double()
+    ref, mag = d.t() @ a, (d.abs().t() @ a.abs()).clamp_min(1e-300)
+    prev = lib.cpc_gemm_set_mode(1)
+    try:
+        nb2 = lib.cpc_gemm_tn_scratch_bytes(H, K, n_rows)
+        sc2 = torch.empty(max(nb2, 1), dtype=torch.uint8, device=DEV)
+        dw2 = torch.empty(H, K, device=DEV)
+        _lib.check(lib.cpc_gemm_tn(_lib.ptr(dud[1:]), H, _lib.ptr(yd), stride * H, _lib.ptr(dw2), K, H, K, n_rows, _lib.ptr(sc2), nb2, st))
+    finally:
+        lib.cpc_gemm_set_mode(prev)
+    e_pl = (outs[0].double() - ref).abs() / mag
+    e_32 = (dw2.cpu().double() - ref).abs() / mag
+    assert float(e_pl.pow(2).mean().sqrt()) <= 1.25 * float(e_32.pow(2).mean().sqrt()) + 1e-10
+    assert float(e_pl.max()) <= 1.5 * float(e_32.max()) + 1e-9
+    assert float(e_pl.max()) <= 16 * 2.0 ** -24
+
+
 def test_gemm_split_specials():
     """inf / nan operands poison exactly the outputs they feed; zeros and denormal-range values are harmless."""
     lib = _lib.load()
@@ -421,6 +544,19 @@ def test_criterion_full_shape_vs_reference_golden(golden):
         w = crit.wPrediction.predictors[i].weight.grad
         assert abs(float(w.double().abs().sum()) - float(g[f"dW{i}_abs"])) <= 1e-4 * float(g[f"dW{i}_abs"])
         assert_close(w[:4, :8], t(g[f"dW{i}_head"]), 2e-4, f"dW{i} head")
+    # EVERY element of every gradient: the fp64 oracle on the same inputs and negatives (tests/test_oracle_golden.py pins
+    # the oracle at this very case to the reference's heads, tails and sums)
+    p64 = {n: v.double().requires_grad_(True) for n, v in synth.predictor_params(12, 256, 256, seed=60, scale=4.0).items()}
+    c64 = synth.features((8, 128, 256), 61).double().requires_grad_(True)
+    z64 = synth.features((8, 128, 256), 62, relu=True).double().requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(1234), 8, 128, 116, 128)
+    ref_losses, _ = O.criterion_forward(c64, z64, O.predictor_list(p64, 12), ext, 128)
+    ref_losses.sum().backward()
+    assert_close(losses, ref_losses, 1e-5, "losses vs oracle")
+    assert_close(c.grad, c64.grad, 1e-4, "dc, all elements")
+    assert_close(z.grad, z64.grad, 1e-4, "dz, all elements")
+    for i in range(12):
+        assert_close(crit.wPrediction.predictors[i].weight.grad, p64[f"wPrediction.predictors.{i}.weight"].grad, 2e-4, f"dW{i}, all elements")
 
 
 @pytest.mark.parametrize("b,t_len,har,henc,k,nn", [(1, 14, 32, 32, 1, 1), (3, 20, 32, 64, 5, 3), (2, 40, 64, 32, 16, 17),
