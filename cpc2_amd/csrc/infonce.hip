@@ -13,6 +13,7 @@
 // to be the positive frame ties EXACTLY, as in the reference) followed by the Nneg gathered negatives.
 #include "common.h"
 #include "ldsdma.h"
+#include "rowcfg.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -255,7 +256,7 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
     constexpr int HS = H / NCE_KC;                           // elements per candidate tile (and per P)
     constexpr int FR = NCE_KC / 16;                          // fragments (16 bytes per lane) per element
     const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
-    const float inv_h = 1.f / H;
+    const float inv_h = 1.f / H, sc2 = 1.4426950408889634f / H;
     extern __shared__ __attribute__((aligned(1024))) char dma_lds[];
     const unsigned lds0 = lds_addr(dma_lds);
     const char *lists = dma_lds + 2 * NCE_SLOT;                                // [2][NCE_LIST]
@@ -334,8 +335,14 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
         // lists[par] has landed (it is older than the P elements' successors)
         const int *lrow = reinterpret_cast<const int *>(lists + par * NCE_LIST);
         const unsigned short *lperm = reinterpret_cast<const unsigned short *>(lists + par * NCE_LIST + 1024);
-        float pos[4] = {0.f, 0.f, 0.f, 0.f};
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+        // Cross-entropy in base 2 on the raw accumulators (v_exp_f32 / v_log_f32 are single instructions, the natural-base
+        // library forms ~15 each): score x = acc / H, x2 = x log2(e).
+        float posacc[4] = {0.f, 0.f, 0.f, 0.f};              // raw accumulators of the positives
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};       // base 2: running max, sum
+        float macc[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};                                    // raw running max (argmax)
+        // logits row of step k = 4q + e: lrow0 + e * lstep, past the positive's slot (rows >= K are never stored)
+        float *const lrow0 = a.logits + ((long)bt * a.K + 4 * q) * (a.Nneg + 1) + 1;
+        const int lstep = a.Nneg + 1;
         for (int tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
             for (int half = 0; half < HS; ++half) {
@@ -378,49 +385,49 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
             if (tile == 0) {
                 // positive of step k = column k of this tile: lane 16q + (4q+e) of row group q holds it
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pos[e] = __shfl(acc[e], 16 * q + 4 * q + e, 64) * inv_h;
+                for (int e = 0; e < 4; ++e) posacc[e] = __shfl(acc[e], 16 * q + 4 * q + e, 64);
             } else {
                 const int j = 16 * (tile - 1) + r;              // negative slot of this lane's column
                 if (j < a.Nneg) {
                     const int jo = lperm[j];                    // the caller's number of it
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int k = 4 * q + e;
-                        const float x = acc[e] * inv_h;
-                        if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + jo] = x;
-                        const float mn = fmaxf(m[e], x);
-                        sm[e] = sm[e] * expf(m[e] - mn) + expf(x - mn);  // m = -inf: s = 0, exp(-inf) = 0
+                        if (4 * q + e < a.K) lrow0[e * lstep + jo] = acc[e] * inv_h;
+                        const float x2 = acc[e] * sc2;
+                        const float mn = fmaxf(m[e], x2);
+                        sm[e] = sm[e] * __builtin_amdgcn_exp2f(m[e] - mn) + __builtin_amdgcn_exp2f(x2 - mn);   // m = -inf: 0 * 0 + ..
                         m[e] = mn;
+                        macc[e] = fmaxf(macc[e], acc[e]);
                     }
                 }
             }
         }
-        // merge (m, s) over the 16 lanes of the row group; lanes that saw no candidate carry (-inf, 0)
+        // merge over the 16 lanes of a row group (data-parallel primitives): the max first, ONE rescale, then the sum.
+        // Lanes that saw no candidate carry (-inf, 0).
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const float m2 = __shfl_xor(m[e], off, 64), s2 = __shfl_xor(sm[e], off, 64);
-                const float mn = fmaxf(m[e], m2);
-                const float f1 = (m[e] == -INFINITY) ? 0.f : expf(m[e] - mn);
-                const float f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
-                sm[e] = sm[e] * f1 + s2 * f2;
-                m[e] = mn;
-            }
+            float mx = m[e], ma = macc[e];
+            mx = fmaxf(mx, row_dpp<0xB1>(mx)); mx = fmaxf(mx, row_dpp<0x4E>(mx)); mx = fmaxf(mx, row_dpp<0x141>(mx)); mx = fmaxf(mx, row_dpp<0x140>(mx));
+            ma = fmaxf(ma, row_dpp<0xB1>(ma)); ma = fmaxf(ma, row_dpp<0x4E>(ma)); ma = fmaxf(ma, row_dpp<0x141>(ma)); ma = fmaxf(ma, row_dpp<0x140>(ma));
+            float sv = m[e] == -INFINITY ? 0.f : sm[e] * __builtin_amdgcn_exp2f(m[e] - mx);
+            sv += row_dpp<0xB1>(sv); sv += row_dpp<0x4E>(sv); sv += row_dpp<0x141>(sv); sv += row_dpp<0x140>(sv);
+            m[e] = mx; sm[e] = sv; macc[e] = ma;
         }
         if (r == 0) {
-            const float wgt = a.weights != nullptr ? a.weights[bt] : 1.f;
+            typedef const __attribute__((address_space(4))) float *const_float_p;        // (a scalar load: a vector load here would
+            const float wgt = a.weights != nullptr ? ((const_float_p)(unsigned long long)a.weights)[bt] : 1.f;   //  count in vmcnt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = 4 * q + e;
                 if (k < a.K) {
-                    const float mx = fmaxf(m[e], pos[e]);
-                    const float se = sm[e] * expf(m[e] - mx) + expf(pos[e] - mx);
-                    const float lse = mx + logf(se);
-                    a.logits[((long)bt * a.K + k) * (a.Nneg + 1)] = pos[e];
+                    const float pos = posacc[e] * inv_h, pos2 = posacc[e] * sc2;
+                    const float mx = fmaxf(m[e], pos2);
+                    const float se = sm[e] * __builtin_amdgcn_exp2f(m[e] - mx) + __builtin_amdgcn_exp2f(pos2 - mx);
+                    const float lse = (mx + __builtin_amdgcn_logf(se)) * 0.693147180559945f;
+                    lrow0[e * lstep - 1] = pos;
                     a.lse[(long)bt * a.K + k] = lse;
-                    a.lossp[(long)bt * a.K + k] = wgt * (lse - pos[e]);
-                    a.hit[(long)bt * a.K + k] = pos[e] >= m[e] ? 1.f : 0.f;       // first-index-wins argmax
+                    a.lossp[(long)bt * a.K + k] = wgt * (lse - pos);
+                    a.hit[(long)bt * a.K + k] = posacc[e] >= macc[e] ? 1.f : 0.f;  // first-index-wins argmax (raw: exact ties tie)
                 }
             }
         }
