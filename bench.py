@@ -313,11 +313,13 @@ def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_se
         k = kernels["infonce_fwd"]
         sim = similarity_algorithmic_flops(args.batch, cfg)
         ach = sim / (k["ms_per_step"] * 1e-3) / 1e12
-        out["roofline_similarity"] = {"bound": "mfma", "kernel": "infonce_fwd_kernel (gather + similarity + cross-entropy fused)",
+        hid = cfg["hidden"]
+        sim_kernel = f"infonce_fwd_dma_kernel<{hid}>" if hid in (256, 512) else f"infonce_fwd_kernel<{hid}>"
+        out["roofline_similarity"] = {"bound": "mfma", "kernel": sim_kernel + " (gather + similarity + cross-entropy fused)",
                                       "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                                       "algorithmic_gflop_per_launch": round(sim / 1e9, 3), "avg_launch_us": k["avg_launch_us"],
-                                      "traffic": measured_traffic("infonce_fwd_kernel:" + cfg_name) if default_workload else None}
+                                      "traffic": measured_traffic(sim_kernel + ":" + cfg_name) if default_workload else None}
     out["kernels"] = kernels
     if cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, cpu_seconds)

@@ -650,7 +650,7 @@ template <int H> __global__ __launch_bounds__(64) void infonce_dz_store_kernel(N
 //            rows are requested together (the rows land in LDS in the caller's order and are picked up through perm there);
 //            under load a dependent global load costs microseconds
 //   phase 1  dP[k][d] (as infonce_bwd_kernel, d in this wave's 128 channels), the rows of the next 16 candidates
-//            requested before the current 16 are multiplied
+//            requested before the current 16 are multiplied; phase 2 runs INSIDE phase 1's loop, group by group
 //   phase 2  V[cand][d] = sum_k dS[k][cand] * P_k[d]  16x16x4: M = d, so a lane holds four consecutive channels of one
 //            candidate; 16 candidates x 64 channels go through a wave-private LDS tile and leave as 256-byte row pieces,
 //            16 bytes per lane (the one-dword-per-lane form of infonce_dz_store_kernel stored at 3.9 TB/s).  The
@@ -737,8 +737,49 @@ template <int H, int NKK> __global__ __launch_bounds__(H / 2) void infonce_bwd_f
     __syncthreads();
     if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
 
-    // ---- phase 1: dP -----------------------------------------------------------------------------
+    // ---- phases 1 and 2, one loop over groups of 16 candidates: the rows of group i + 1 are requested, the contribution rows
+    // of group i are formed and stored (no gathered row needed), THEN the gathered rows of group i are multiplied into dP --
+    // the gather's latency passes under the stores and the two kinds of traffic overlap inside a wave.
     const int d0 = 128 * wave;
+    const long prow_off = ((long)bb * a.p_rows + t) * a.p_stride + d0;
+    float pa[8][NKK];                                              // phase 2's A: P_{4kk + q}[d0 + 16*tile + r]
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int k = 4 * kk + q;
+        const float *pk = a.Pk[min(k, a.K - 1)] + prow_off + r;
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            const float v = pk[16 * tile];
+            pa[tile][kk] = k < a.K ? v : 0.f;
+        }
+    }
+    // row `cand` of the (b,t)'s NCE_POS + Nneg contribution rows; this lane: rows 4j + q of a tile, its 16-byte piece r
+    float *vb = a.vbuf + (bt * (long)ncand + q) * H + d0 + 4 * r;
+    // (a macro, not a lambda: inside a lambda the staging tile's address space is lost and its arrays go to scratch memory)
+#define NCE_ROWS_GROUP(C0)                                                                                                     \
+    {                                                                                                                          \
+        const int c0_ = (C0);                                                                                                  \
+        float bv[NKK];                                                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk) bv[kk] = dS[(4 * kk + q) * a.lw + c0_ + r];                        \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                               \
+            f32x4 acc[4];                                                                                                      \
+            _Pragma("unroll") for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};                            \
+            _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk)                                                                 \
+                _Pragma("unroll") for (int tl = 0; tl < 4; ++tl)                                                               \
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * half + tl][kk], bv[kk], acc[tl], 0, 0, 0);           \
+            _Pragma("unroll") for (int tl = 0; tl < 4; ++tl)                                                                   \
+                *reinterpret_cast<f32x4 *>(stage + r * NCE_SROW + 16 * tl + 4 * q) = acc[tl];                                  \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                             \
+            __builtin_amdgcn_wave_barrier();                                                                                   \
+            float4 v[4];                                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+                v[j] = *reinterpret_cast<const float4 *>(stage + (4 * j + q) * NCE_SROW + 4 * r);                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+                *reinterpret_cast<float4 *>(vb + (long)(c0_ + 4 * j) * H + 64 * half) = v[j];                                  \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                             \
+            __builtin_amdgcn_wave_barrier();                                                                                   \
+        }                                                                                                                      \
+    }
     {
         f32x4 dp[2][4];
 #pragma unroll
@@ -769,12 +810,16 @@ template <int H, int NKK> __global__ __launch_bounds__(H / 2) void infonce_bwd_f
                     dp[T4][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][u][T4].w, bv4[buf][u], dp[T4][3], 0, 0, 0);
                 }
         };
-        const int nb = npad / 16;                                  // even (npad is a multiple of 32)
+        // (measured: with ONE row buffer and three waves per SIMD the kernel takes the same 378 us -- it moves 1.2 GB of stores and
+        //  0.6 GB of L2 misses at the fabric's ~4.8 TB/s either way)
+        const int nb = npad / 16;                                  // even (npad is a multiple of 32); ncand / 16 or one more
         request(0, 0);
         for (int ib = 0; ib < nb; ib += 2) {
             request(1, 4 * (ib + 1));
+            NCE_ROWS_GROUP(16 * ib)
             multiply(0);
             if (ib + 2 < nb) request(0, 4 * (ib + 2));
+            if (16 * (ib + 1) < ncand) NCE_ROWS_GROUP(16 * (ib + 1))
             multiply(1);
         }
         // dp[T4][e][reg] = dP[k = r][d = d0 + 64*T4 + 4*(4q + reg) + e]
@@ -788,49 +833,8 @@ template <int H, int NKK> __global__ __launch_bounds__(H / 2) void infonce_bwd_f
                         make_float4(dp[T4][0][reg], dp[T4][1][reg], dp[T4][2][reg], dp[T4][3][reg]);
         }
     }
-
+#undef NCE_ROWS_GROUP
     if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
-    // ---- phase 2: contribution rows ------------------------------------------------------------------
-    const long prow_off = ((long)bb * a.p_rows + t) * a.p_stride + d0;
-    float pa[8][NKK];                                              // A: P_{4kk + q}[d0 + 16*tile + r]
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-        const int k = 4 * kk + q;
-        const float *pk = a.Pk[min(k, a.K - 1)] + prow_off + r;
-#pragma unroll
-        for (int tile = 0; tile < 8; ++tile) {
-            const float v = pk[16 * tile];
-            pa[tile][kk] = k < a.K ? v : 0.f;
-        }
-    }
-    // row `cand` of the (b,t)'s NCE_POS + Nneg contribution rows; this lane: rows 4j + q of a tile, its 16-byte piece r
-    float *vb = a.vbuf + (bt * (long)ncand + q) * H + d0 + 4 * r;
-    for (int c0 = 0; c0 < ncand; c0 += 16) {
-        float bv[NKK];
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) bv[kk] = dS[(4 * kk + q) * a.lw + c0 + r];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 acc[4];
-#pragma unroll
-            for (int tl = 0; tl < 4; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-                for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * half + tl][kk], bv[kk], acc[tl], 0, 0, 0);
-#pragma unroll
-            for (int tl = 0; tl < 4; ++tl) *reinterpret_cast<f32x4 *>(stage + r * NCE_SROW + 16 * tl + 4 * q) = acc[tl];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4 *>(stage + (4 * j + q) * NCE_SROW + 4 * r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(vb + (long)(c0 + 4 * j) * H + 64 * half) = v[j];
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
     if (stamp) { stamp[3] = __builtin_amdgcn_s_memtime(); stamp[4] = __builtin_amdgcn_s_memrealtime(); }
 }
 
