@@ -53,16 +53,33 @@ def pytest_sessionstart(session):
         return
     tmp = tempfile.mkdtemp(prefix="cpc_dp_")
     job = os.path.join(ROOT, "tests", "dp_job.py")
-    port, port1 = str(_free_port()), str(_free_port())
+    port, port1, port2 = str(_free_port()), str(_free_port()), str(_free_port())
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = {}
-    specs = {"rank0": ("ranks", 0, 2, port), "rank1": ("ranks", 1, 2, port), "single": ("single", 0, 1, port),
-             "nccl": ("nccl", 0, 1, port1)}
-    for name, (mode, rank, world, prt) in specs.items():
-        out = os.path.join(tmp, name + ".pt")
-        log = open(os.path.join(tmp, name + ".log"), "w")
-        procs[name] = (subprocess.Popen([sys.executable, job, mode, str(rank), str(world), prt, out], stdout=log,
-                                        stderr=subprocess.STDOUT, env=env, cwd=ROOT), out, log.name)
+    # two groups, one after the other (a GPU box allows six processes on its card at once, this session included): the ranks of
+    # a group are started together by a launcher process that never touches the GPU itself
+    groups = [{"rank0": ("ranks", 0, 2, port), "rank1": ("ranks", 1, 2, port), "single": ("single", 0, 1, port),
+               "nccl": ("nccl", 0, 1, port1)},
+              {"ddp0": ("ddp", 0, 2, port2), "ddp1": ("ddp", 1, 2, port2)}]
+    plan = []
+    for group in groups:
+        cmds = []
+        for name, (mode, rank, world, prt) in group.items():
+            out = os.path.join(tmp, name + ".pt")
+            log = os.path.join(tmp, name + ".log")
+            cmds.append(([sys.executable, job, mode, str(rank), str(world), prt, out], log, os.path.join(tmp, name + ".rc")))
+            procs[name] = (None, out, log)
+        plan.append(cmds)
+    launcher = ("import subprocess, sys, json\n"
+                "plan = json.loads(sys.argv[1])\n"
+                "for cmds in plan:\n"
+                "    ps = [(subprocess.Popen(c, stdout=open(l, 'w'), stderr=subprocess.STDOUT), rc) for c, l, rc in cmds]\n"
+                "    for p, rc in ps:\n"
+                "        open(rc, 'w').write(str(p.wait()))\n")
+    import json
+    proc = subprocess.Popen([sys.executable, "-c", launcher, json.dumps(plan)], env=env, cwd=ROOT)
+    for name in procs:
+        procs[name] = (proc, procs[name][1], procs[name][2])
     _DP.update(procs)
 
 
@@ -73,12 +90,15 @@ def dp_jobs():
     if not _DP:
         pytest.skip("data-parallel jobs were not started (no GPU, or -m 'not gpu')")
     results = {}
-    for name, (proc, out, log) in _DP.items():
-        try:
-            rc = proc.wait(timeout=420)
-        except Exception:
-            proc.kill()
-            raise AssertionError(f"dp job {name} did not finish:\n" + open(log).read()[-3000:])
+    launcher = next(iter(_DP.values()))[0]
+    try:
+        launcher.wait(timeout=600)
+    except Exception:
+        launcher.kill()
+        raise AssertionError("the data-parallel jobs did not finish:\n" + "\n".join(open(l).read()[-1500:] for _p, _o, l in _DP.values()))
+    for name, (_proc, out, log) in _DP.items():
+        rc_path = out[:-3] + ".rc"
+        rc = int(open(rc_path).read()) if os.path.exists(rc_path) else -1
         assert rc == 0, f"dp job {name} failed ({rc}):\n" + open(log).read()[-3000:]
         results[name] = torch.load(out)
     return results

@@ -8,6 +8,9 @@ mode "ranks":  `world` processes share cuda:0, backend gloo; rank r trains on IT
 mode "single": one process does the same 2 steps on the union, shard by shard (two micro-batches whose gradients add up,
                Adam with grad_scale 1/2): SURVEY 8(e)'s equivalence.
 mode "nccl":   world_size 1 over RCCL: init, broadcast, overlapped + blocking all-reduce through DataParallelContext.
+mode "ddp":    the reference's own arrangement (cpc/train.py:523-527): model and criterion wrapped in
+               torch.nn.parallel.DistributedDataParallel (gloo, two ranks on cuda:0), FlatAdam as the optimiser -- DDP's
+               buckets average the gradients that the fused backward kernels wrote into the flat buffer.
 """
 import os
 import sys
@@ -68,6 +71,25 @@ if mode in ("ranks", "nccl"):
         tot.backward()
         dp2.reduce_and_step()
         opt.zero_grad()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+elif mode == "ddp":
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank != 0:
+        opt.flat.mul_(1.5)                     # DDP's constructor broadcasts rank 0's parameters (into the flat buffer's views)
+    ddp_model = DDP(model, device_ids=[0], find_unused_parameters=True)
+    ddp_crit = DDP(crit, device_ids=[0], find_unused_parameters=True)
+    crit.seed(1234 + rank)
+    x = shard(rank)
+    for _ in range(STEPS):
+        tot, ls, _acc = cpcStep(x, x, label, ddp_model, ddp_crit)
+        tot.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(ls.detach().cpu())
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

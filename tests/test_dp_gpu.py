@@ -28,3 +28,16 @@ def test_rccl_process_group_of_one_rank(dp_jobs):
     assert res["step_count"] == 3 and torch.isfinite(res["flat"]).all() and torch.isfinite(res["losses"]).all()
     # world 1: the same trajectory as rank 0's first two steps would have alone -- just check the steps moved the weights
     assert float(res["losses"][0].mean()) > 0
+
+
+def test_reference_style_ddp_wrapping_with_flat_adam(dp_jobs):
+    """cpc/train.py:523-527 as is: DistributedDataParallel around model and criterion, FlatAdam stepping the flat buffer
+    the fused backward kernels write their gradients into.  Same update as the single process with two micro-batches."""
+    d0, d1, single = dp_jobs["ddp0"], dp_jobs["ddp1"], dp_jobs["single"]
+    assert d0["step_count"] == d1["step_count"] == 2
+    assert torch.equal(d0["flat"], d1["flat"])
+    err = float((d0["flat"] - single["flat"]).abs().max())
+    scale = float(single["flat"].abs().max())
+    assert err <= 2e-6 * scale, (err, scale)
+    both = torch.stack([d0["losses"], d1["losses"]], dim=1).reshape(single["losses"].shape)
+    assert torch.allclose(both, single["losses"], rtol=2e-5, atol=1e-6)
