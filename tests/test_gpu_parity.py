@@ -576,7 +576,11 @@ def test_criterion_full_shape_vs_reference_golden(golden):
 
 
 @pytest.mark.parametrize("b,t_len,har,henc,k,nn", [(1, 14, 32, 32, 1, 1), (3, 20, 32, 64, 5, 3), (2, 40, 64, 32, 16, 17),
-                                                   (5, 33, 128, 128, 7, 129), (2, 64, 32, 512, 12, 40), (9, 17, 24, 32, 3, 250)])
+                                                   (5, 33, 128, 128, 7, 129), (2, 64, 32, 512, 12, 40), (9, 17, 24, 32, 3, 250),
+                                                   # hidden 256 / 512: the streaming forward kernel and the one-kernel backward, every
+                                                   # prediction-step count class (1-4, 5-8, 9-12, 13-16), few and many candidate tiles
+                                                   (2, 24, 64, 256, 3, 16), (3, 30, 32, 256, 7, 48), (2, 40, 96, 256, 16, 32),
+                                                   (1, 20, 32, 512, 1, 16), (2, 36, 64, 512, 14, 256), (2, 28, 32, 256, 12, 24)])
 def test_criterion_odd_shapes_vs_oracle_fp64(b, t_len, har, henc, k, nn):
     """Shapes off every tile size of the criterion kernels (candidate tiles of 16 / 32, 16 prediction rows, lane groups):
     one window, one step, one negative, more negatives than a tile, all supported encoder widths -- vs the fp64 oracle."""
@@ -599,6 +603,49 @@ def test_criterion_odd_shapes_vs_oracle_fp64(b, t_len, har, henc, k, nn):
     assert_close(zd.grad, z64.grad, 1e-4, "dz")
     for i in range(k):
         assert_close(crit.wPrediction.predictors[i].weight.grad, p64[f"wPrediction.predictors.{i}.weight"].grad, 2e-4, f"dW{i}")
+
+
+@pytest.mark.parametrize("variant", ["skip", "reverse", "quality"])
+@pytest.mark.parametrize("henc", [256, 512])
+def test_criterion_variants_at_hidden_256_512_vs_oracle_fp64(variant, henc):
+    """n_skipped, mode='reverse' and the signal-quality weights on the kernels that only hidden 256 / 512 use (the streaming
+    forward kernel, the one-kernel backward); the reference-made goldens of these variants are at hidden 32."""
+    b, t_len, har, k, nn = 3, 40, 64, 12, 32
+    kw, okw = {}, {}
+    if variant == "skip":
+        kw["n_skipped"] = okw["n_skipped"] = 2
+    if variant == "reverse":
+        kw["mode"] = okw["mode"] = "reverse"
+    if variant == "quality":
+        kw.update(growth_rate=2.0, inflection_point_x=0.1)
+    crit = make_criterion(k, har, henc, nn, 300, scale=3.0, **kw)
+    cp = synth.predictor_params(k, har, henc, seed=300, scale=3.0)
+    c = synth.features((b, t_len, har), 301)
+    z = synth.features((b, t_len, henc), 302, relu=True)
+    quality = torch.rand(b, 9, generator=torch.Generator().manual_seed(5)) if variant == "quality" else None
+    if quality is not None:
+        okw["weights"] = O.quality_weights(quality.double(), 2.0, 0.1, t_len - k)
+    cd, zd = c.to(DEV).requires_grad_(True), z.to(DEV).requires_grad_(True)
+    crit.seed(78)
+    losses, acc = crit(cd, zd, None, None if quality is None else quality.to(DEV))
+    losses.sum().backward()
+    p64 = {n: v.double().requires_grad_(True) for n, v in cp.items()}
+    c64, z64 = c.double().requires_grad_(True), z.double().requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(78), b, t_len, t_len - k, nn)
+    ref_losses, ref_acc = O.criterion_forward(c64, z64, O.predictor_list(p64, k), ext, nn, **okw)
+    ref_losses.sum().backward()
+    assert losses.shape == ref_losses.shape
+    assert_close(losses, ref_losses, 1e-5, "losses")
+    assert torch.allclose(acc.cpu().double(), ref_acc, atol=2.5 / (b * (t_len - k)))
+    assert_close(cd.grad, c64.grad, 1e-4, "dc")
+    assert_close(zd.grad, z64.grad, 1e-4, "dz")
+    for i in range(k):
+        ref = p64[f"wPrediction.predictors.{i}.weight"].grad
+        got = crit.wPrediction.predictors[i].weight.grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert got is None or float(got.abs().max()) == 0.0
+        else:
+            assert_close(got, ref, 2e-4, f"dW{i}")
 
 
 def test_criterion_transformer_predictors_vs_reference_golden(golden):
