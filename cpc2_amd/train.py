@@ -234,19 +234,8 @@ class DataParallelContext:
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
         self.early, self.late, self._pending, self._fired = [], [], [], False
-        # gloo (the rehearsal backend: ranks sharing one GPU) reduces device tensors through a staging copy of its own; with
-        # two ranks on one MI355X one 4 KiB page of the summed buffer came out wrong in ~15 % of runs (torch's own DDP over
-        # gloo shows the same; the kernels are bitwise repeatable, also in two independent processes at once).  With the
-        # staging done explicitly here it was 0 of 30 runs.  RCCL ("nccl") reduces on the device and does not come here.
-        self._host_staged = (self.active and dist.get_backend() == "gloo" and getattr(self.opt, "flat", None) is not None
-                             and self.opt.flat.is_cuda)
         if self.active:
-            if self._host_staged:
-                host = self.opt.flat.cpu()
-                dist.broadcast(host, src=0)
-                self.opt.flat.copy_(host)
-            else:
-                dist.broadcast(self.opt.flat, src=0)
+            dist.broadcast(self.opt.flat, src=0)
             if early_params and overlap and hasattr(optimizer, "offsets"):
                 self._split(early_params)
 
@@ -280,7 +269,8 @@ class DataParallelContext:
                 self._fired = True
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.early)     # a gradient autograd did not write in place (accumulation)
-                self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
+                self._pending = [dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+                                 for lo, hi in self.early]
         encoder_output.register_hook(start)
 
     def reduce_and_step(self):
@@ -289,10 +279,9 @@ class DataParallelContext:
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.late)      # (the early slices hold SUMS by now)
                 for lo, hi in self.late:
-                    self._all_reduce(lo, hi)
+                    dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM)
                 for work in self._pending:
-                    if work is not None:
-                        work.wait()
+                    work.wait()
                 # the optimiser must not take a stray early gradient for the reduced one again
                 stray = getattr(self.opt, "direct_grads", False)
                 if stray:
@@ -306,19 +295,9 @@ class DataParallelContext:
                 return
             if getattr(self.opt, "direct_grads", False):
                 self.opt._gather_stray_grads()
-            self._all_reduce(0, self.opt.flat_grad.numel())
+            dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM)
             self._pending, self._fired = [], False
         self.opt.step(grad_scale=1.0 / self.world)
-
-    def _all_reduce(self, lo, hi, async_op=False):
-        """SUM over the ranks of flat_grad[lo:hi], in place; the handle of an asynchronous reduction, else None."""
-        view = self.opt.flat_grad[lo:hi]
-        if self._host_staged:                   # (synchronous: the rehearsal path does not overlap)
-            host = view.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            view.copy_(host)
-            return None
-        return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
 # --------------------------------------------------------------------------- the step

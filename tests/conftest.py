@@ -56,7 +56,7 @@ def pytest_sessionstart(session):
     port, port1, port2 = str(_free_port()), str(_free_port()), str(_free_port())
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = {}
-    # two groups, one after the other (a GPU box allows six processes on its card at once, this session included): the ranks of
+    # groups, one after the other (a GPU box allows six processes on its card at once, this session included): the ranks of
     # a group are started together by a launcher process that never touches the GPU itself
     groups = [{"rank0": ("ranks", 0, 2, port), "rank1": ("ranks", 1, 2, port), "single": ("single", 0, 1, port),
                "nccl": ("nccl", 0, 1, port1)},
@@ -102,3 +102,4 @@ def dp_jobs():
         assert rc == 0, f"dp job {name} failed ({rc}):\n" + open(log).read()[-3000:]
         results[name] = torch.load(out)
     return results
+

@@ -54,7 +54,7 @@ if mode in ("ranks", "nccl"):
     dist.init_process_group("nccl" if mode == "nccl" else "gloo", rank=rank, world_size=world)
     if rank != 0:
         opt.flat.mul_(1.5)                     # the broadcast must bring rank 0's parameters
-    overlap = not os.environ.get("CPC_DP_JOB_NO_OVERLAP")
+    overlap = not os.environ.get("CPC_DP_JOB_NO_OVERLAP")        # (diagnostics, tools/scratch/dp_diag.py: one blocking all-reduce)
     dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()), overlap=overlap)
     assert not overlap or (dp.early and dp.late), (dp.early, dp.late)
     crit.seed(1234 + rank)
@@ -63,7 +63,7 @@ if mode in ("ranks", "nccl"):
         tot, ls, _acc = cpcStep(x, x, label, model, crit, dp=dp)
         tot.backward()
         assert not overlap or (dp._fired and len(dp._pending) == len(dp.early))       # the early slices are on their way
-        if os.environ.get("CPC_DP_JOB_DUMP") and not losses:                          # (diagnostic: this rank's own gradient, step 1)
+        if os.environ.get("CPC_DP_JOB_DUMP") and not losses:                          # (diagnostics: this rank's own gradient, step 1)
             torch.cuda.synchronize()
             torch.save(opt.flat_grad.detach().cpu(), out + ".grad")
         dp.reduce_and_step()
@@ -86,19 +86,6 @@ elif mode == "ddp":
         opt.flat.mul_(1.5)                     # DDP's constructor broadcasts rank 0's parameters (into the flat buffer's views)
     ddp_model = DDP(model, device_ids=[0], find_unused_parameters=True)
     ddp_crit = DDP(crit, device_ids=[0], find_unused_parameters=True)
-
-    def staged_allreduce(_state, bucket):
-        """DDP's bucket reduction with an explicit host copy: ProcessGroupGloo's own staging of device tensors was seen to
-        lose a 4 KiB page now and then with two ranks on one GPU (cpc2_amd/train.py:DataParallelContext)."""
-        buf = bucket.buffer()
-        host = buf.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        buf.copy_(host / world)
-        fut = torch.futures.Future()
-        fut.set_result(buf)
-        return fut
-    ddp_model.register_comm_hook(None, staged_allreduce)
-    ddp_crit.register_comm_hook(None, staged_allreduce)
     crit.seed(1234 + rank)
     x = shard(rank)
     for _ in range(STEPS):
@@ -122,9 +109,6 @@ else:
             x = shard(r)
             tot, ls, _acc = cpcStep(x, x, label, model, crit)
             tot.backward()
-            if os.environ.get("CPC_DP_JOB_DUMP") and len(losses) < SHARDS:            # (diagnostic: shard r's gradient, step 1)
-                torch.cuda.synchronize()
-                torch.save(opt.flat_grad.detach().cpu(), out + f".grad{r}")
             losses.append(ls.detach().cpu())
         opt.step(grad_scale=1.0 / SHARDS)
         opt.zero_grad()
