@@ -709,6 +709,38 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_x6_kernel(GemmTNArgs p)
 __global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k)
 {
     const long total = (long)M * N;
+    if (N % 4 == 0 && conv_cin % 4 == 0 && reinterpret_cast<uintptr_t>(slab) % 16 == 0) {
+        // four outputs per thread, 16-byte loads, four slabs in flight (a latency-bound pass); slab order fixed
+        const long total4 = total / 4;
+        const float4 *s4 = reinterpret_cast<const float4 *>(slab);
+        for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 4 <= S; z += 4) {
+                const float4 v0 = s4[(long)z * total4 + i4], v1 = s4[(long)(z + 1) * total4 + i4];
+                const float4 v2 = s4[(long)(z + 2) * total4 + i4], v3 = s4[(long)(z + 3) * total4 + i4];
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; z < S; ++z) {
+                const float4 v = s4[(long)z * total4 + i4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            const long idx = i4 * 4;
+            const int i = (int)(idx / N), j = (int)(idx - (long)i * N);
+            if (conv_cin > 0) {                             // conv_cin % 4 == 0: the four elements share the tap
+                const int jj = j / conv_cin, ci = j - jj * conv_cin;
+                float *dst = C + (long)i * conv_cin * conv_k + (long)ci * conv_k + jj;
+                dst[0] = acc.x; dst[conv_k] = acc.y; dst[2 * conv_k] = acc.z; dst[3 * conv_k] = acc.w;
+            } else {
+                float *dst = C + (long)i * ldc + j;
+                dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
+            }
+        }
+        return;
+    }
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < S; ++z) s += slab[(long)z * total + idx];
