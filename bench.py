@@ -321,11 +321,57 @@ def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_se
                                       "algorithmic_gflop_per_launch": round(sim / 1e9, 3), "avg_launch_us": k["avg_launch_us"],
                                       "traffic": measured_traffic(sim_kernel + ":" + cfg_name) if default_workload else None}
     out["kernels"] = kernels
+    out["_gradient_bytes"] = 4 * opt.flat_grad.numel()
     if cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, cpu_seconds)
     del model, crit, opt, dp, x
     torch.cuda.empty_cache()
     return out
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """Start `n` copies of this command, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in
+    their environment, rendezvous on 127.0.0.1 at a free port), wait for them and return the worst exit code.  Rank 0
+    prints the JSON line on the stdout the children inherit.  The parent never initialises the GPU
+    (torch.cuda.device_count() does not)."""
+    import subprocess
+    backend = os.environ.get("CPC_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < n and "--rendezvous-only" not in sys.argv:
+        print(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible and RCCL needs one per rank "
+              "(CPC_BENCH_BACKEND=gloo rehearses the N-rank path with ranks sharing a GPU)", file=sys.stderr)
+        return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    log(f"launcher: started {n} ranks (backend {backend}, port {port}), pids {[p.pid for p in procs]}")
+    worst = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                log(f"launcher: rank process {p.pid} exited with {rc}; stopping the others")
+                for q in pending:              # exactly the processes started above
+                    q.kill()
+        time.sleep(0.05)
+    return worst if worst >= 0 else 1
 
 
 def main():
@@ -343,14 +389,31 @@ def main():
                     help="comma-separated configs measured AFTER the headline's timed region and reported inside the same JSON "
                          "line under \"other_configs\" (default at one GPU with the small config: large,transformer = BASELINE "
                          "configs[4] per GPU and configs[3]; '' = none)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, all-reduce one CPU number over gloo, print it and exit (launcher self-test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher (no GPU call has been made in this process) and run
+        # one rank per GPU as child processes -- the entry the reference takes through init_distributed_mode
+        # (cpc/distributed_training/distributed_mode.py:75-86,129-142)
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (unset WORLD_SIZE to let bench.py "
+                         "start the ranks itself)")
+    if args.rendezvous_only:
+        # the launcher + rendezvous alone, on CPU tensors over gloo (tests/test_bench_launcher.py; no GPU needed)
+        dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "rank_sum": float(t.item()), "master": os.environ["MASTER_ADDR"]}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # one process per GPU; CPC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
     # distributed code path on a one-GPU box (ranks then share the device)
     backend = os.environ.get("CPC_BENCH_BACKEND", "nccl")
@@ -358,11 +421,23 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # CPC_BENCH_FORCE_DIST=1: go through the process-group code path (RCCL init, broadcast, all-reduce) with one rank too
-    use_dist = world > 1 or bool(os.environ.get("CPC_BENCH_FORCE_DIST") and "MASTER_ADDR" in os.environ)
+    use_dist = world > 1 or bool(os.environ.get("CPC_BENCH_FORCE_DIST"))
     if use_dist:
+        if "MASTER_ADDR" not in os.environ:                 # (one forced rank started by hand)
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
 
     out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
+    if out is not None:
+        comm = {"world": world, "process_group": backend if use_dist else None}
+        if use_dist and backend == "nccl":
+            comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            comm["env"] = {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE",
+                                                          "HSA_ENABLE_IPC_MODE_LEGACY")}
+        comm["gradient_bytes"] = out.pop("_gradient_bytes", None)
+        comm["overlap"] = "criterion + context-network slices reduced under the encoder's backward" if (
+            use_dist and not os.environ.get("CPC_BENCH_NO_OVERLAP")) else "one blocking all-reduce" if use_dist else None
+        out["comm"] = comm
     also = args.also
     if also is None:
         also = "large,transformer" if (world == 1 and args.config == "small" and not args.no_prof) else ""
