@@ -166,7 +166,6 @@ def buildOptimizer(cpcModel, cpcCriterion, lr=2e-4, beta1=0.9, beta2=0.999, epsi
     return FlatAdam(g_params, lr=lr, betas=(beta1, beta2), eps=epsilon)
 
 
-# --------------------------------------------------------------------------- data parallel
 # --------------------------------------------------------------------------- learning-rate schedule
 def ramp_scheduling_function(n_epoch_ramp, epoch, square_ramp=False):
     """cpc/utils/misc.py:77-83: linear (or squared) warm-up factor over the first n_epoch_ramp epochs."""
@@ -218,6 +217,7 @@ def buildScheduler(optimizer, schedulerStep=-1, schedulerRamp=None, epochs_done=
     return scheduler
 
 
+# --------------------------------------------------------------------------- data parallel
 class DataParallelContext:
     """One process per GPU (train.py:291-295, 523-527 with --distributed).  Replaces the two DDP wrappers by: one
     broadcast of the flat parameter buffer from rank 0 at start, and all-reduces (SUM) of the flat gradient buffer whose
@@ -227,10 +227,20 @@ class DataParallelContext:
     gradients are complete before the encoder's backward starts: the criterion's and the context network's -- their slices
     of the flat gradient are reduced ASYNCHRONOUSLY from an autograd hook on the encoder's output (`attach`, called by
     cpcStep), i.e. while the encoder's backward kernels run; `reduce_and_step` then reduces the encoder's slice, waits
-    for the early ones and updates.  Without early_params (or overlap=False): one blocking all-reduce of the whole buffer."""
+    for the early ones and updates.  Without early_params (or overlap=False): one blocking all-reduce of the whole buffer.
+    `DataParallelContext.for_modules(optimizer, cpcModel, cpcCriterion)` takes the early parameters from the modules.
 
-    def __init__(self, optimizer, early_params=None, overlap=True):
+    ONE backward pass per optimisation step: the hook reduces the early slices at the end of the first backward pass
+    after `attach`; a second backward pass before `reduce_and_step` (gradient accumulation) would add onto sums.  `attach`
+    raises if it is called again before `reduce_and_step` has consumed a fired hook.
+
+    `trace`: None, or a callable(kind, lo, hi, view) invoked on the compute stream right before every all-reduce
+    ("pre": view = flat_grad[lo:hi] as this rank computed it) and after the last one of a step ("post": the whole
+    buffer of sums) -- the equivalence tests clone what they see there (tests/dp_job.py)."""
+
+    def __init__(self, optimizer, early_params=None, overlap=True, trace=None):
         self.opt = optimizer
+        self.trace = trace
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
         self.early, self.late, self._pending, self._fired = [], [], [], False
@@ -238,6 +248,14 @@ class DataParallelContext:
             dist.broadcast(self.opt.flat, src=0)
             if early_params and overlap and hasattr(optimizer, "offsets"):
                 self._split(early_params)
+
+    @classmethod
+    def for_modules(cls, optimizer, cpcModel, cpcCriterion, overlap=True, trace=None):
+        """The context the training loop uses: the criterion's and the context network's parameters reduce early."""
+        inner = getattr(cpcModel, "module", cpcModel)
+        crit = getattr(cpcCriterion, "module", cpcCriterion)
+        early = list(crit.parameters()) + (list(inner.gAR.parameters()) if hasattr(inner, "gAR") else [])
+        return cls(optimizer, early_params=early, overlap=overlap, trace=trace)
 
     def _split(self, early_params):
         """[lo, hi) ranges of the flat buffer: early (merged runs of the early parameters) and the rest."""
@@ -257,20 +275,28 @@ class DataParallelContext:
         if pos < total:
             self.late.append((pos, total))
 
+    def _all_reduce(self, lo, hi, async_op=False):
+        """SUM over the ranks of flat_grad[lo:hi], in place, enqueued behind everything the current stream holds."""
+        view = self.opt.flat_grad[lo:hi]
+        if self.trace is not None:
+            self.trace("pre", lo, hi, view)
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
+
     def attach(self, encoder_output):
         """Register the hook that starts the early reductions when the gradient of `encoder_output` is ready (everything
         downstream of the encoder has then written its parameter gradients)."""
         if not (self.active and self.early and encoder_output.requires_grad):
             return
-        self._fired = False
+        if self._fired:
+            raise RuntimeError("DataParallelContext: a backward pass has already reduced the early gradient slices of this "
+                               "step; call reduce_and_step() before the next forward pass (one backward pass per step)")
 
         def start(_grad):
             if not self._fired:                 # once per backward pass
                 self._fired = True
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.early)     # a gradient autograd did not write in place (accumulation)
-                self._pending = [dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-                                 for lo, hi in self.early]
+                self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
         encoder_output.register_hook(start)
 
     def reduce_and_step(self):
@@ -279,9 +305,11 @@ class DataParallelContext:
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.late)      # (the early slices hold SUMS by now)
                 for lo, hi in self.late:
-                    dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM)
+                    self._all_reduce(lo, hi)
                 for work in self._pending:
                     work.wait()
+                if self.trace is not None:
+                    self.trace("post", 0, self.opt.flat_grad.numel(), self.opt.flat_grad)
                 # the optimiser must not take a stray early gradient for the reduced one again
                 stray = getattr(self.opt, "direct_grads", False)
                 if stray:
@@ -295,7 +323,9 @@ class DataParallelContext:
                 return
             if getattr(self.opt, "direct_grads", False):
                 self.opt._gather_stray_grads()
-            dist.all_reduce(self.opt.flat_grad, op=dist.ReduceOp.SUM)
+            self._all_reduce(0, self.opt.flat_grad.numel())
+            if self.trace is not None:
+                self.trace("post", 0, self.opt.flat_grad.numel(), self.opt.flat_grad)
             self._pending, self._fired = [], False
         self.opt.step(grad_scale=1.0 / self.world)
 
@@ -339,7 +369,7 @@ def trainStep(dataLoader, cpcModel, cpcCriterion, optimizer, scheduler, loggingS
     cpcModel.train()
     cpcCriterion.train()
     device = device or next(cpcModel.parameters()).device
-    dp = dp or DataParallelContext(optimizer)
+    dp = dp or DataParallelContext.for_modules(optimizer, cpcModel, cpcCriterion)      # (run() builds it once and passes it)
     start_time = time.perf_counter()
     n_examples, it = 0, 0
     sum_loss = sum_acc = None
@@ -411,7 +441,9 @@ def run(trainDataset, valDataset, batchSize, samplingMode, cpcModel, cpcCriterio
     validation accuracy beat bestAcc -- which is never raised from 0 (train.py:207,237-238)."""
     import json
     from . import feature_loader as fl
-    dp = dp or DataParallelContext(optimizer)
+    # built ONCE (its constructor broadcasts rank 0's parameters): the criterion's and the context network's gradient
+    # slices are reduced under the encoder's backward, as bench.py measures it
+    dp = dp or DataParallelContext.for_modules(optimizer, cpcModel, cpcCriterion)
     print(f"Running {nEpoch} epochs")
     best_acc, best_state = 0, None
     t_start = time.perf_counter()

@@ -39,11 +39,37 @@ def _free_port():
     return port
 
 
+DP_TESTS = ("test_two_ranks_equal_one_process_with_two_micro_batches", "test_rccl_process_group_of_one_rank",
+            "test_reference_style_ddp_wrapping_with_flat_adam")
+
+
+def _dp_tests_selected(config):
+    """Will this session run anything of tests/test_dp_gpu.py?  (Decided from the command line alone: the jobs must be
+    started before collection imports anything that could touch the GPU.)"""
+    markexpr = config.getoption("markexpr", "") or ""
+    if "not gpu" in markexpr or os.environ.get("CPC_SKIP_DP_JOBS"):
+        return False
+    files = [a.split("::")[0] for a in config.args]
+    if files and not any(os.path.isdir(f) or os.path.basename(f) == "test_dp_gpu.py" for f in files):
+        return False
+    explicit = [a.split("::", 1)[1] for a in config.args if "::" in a and os.path.basename(a.split("::")[0]) == "test_dp_gpu.py"]
+    if any("::" in a for a in config.args) and not explicit and not any(os.path.isdir(f) for f in files):
+        return False
+    keyword = config.getoption("keyword", "") or ""
+    if keyword:
+        try:
+            from _pytest.mark.expression import Expression
+            expr = Expression.compile(keyword)
+            return any(expr.evaluate(lambda word, name=name: word in name or word in "test_dp_gpu.py") for name in DP_TESTS)
+        except Exception:
+            return True
+    return True
+
+
 def pytest_sessionstart(session):
     import subprocess
     import tempfile
-    markexpr = session.config.getoption("markexpr", "") or ""
-    if "not gpu" in markexpr or os.environ.get("CPC_SKIP_DP_JOBS"):
+    if not _dp_tests_selected(session.config):
         return
     try:
         import torch
@@ -77,7 +103,8 @@ def pytest_sessionstart(session):
                 "    for p, rc in ps:\n"
                 "        open(rc, 'w').write(str(p.wait()))\n")
     import json
-    proc = subprocess.Popen([sys.executable, "-c", launcher, json.dumps(plan)], env=env, cwd=ROOT)
+    # its own session (= process group): a time-out can then stop the launcher AND the rank processes it started
+    proc = subprocess.Popen([sys.executable, "-c", launcher, json.dumps(plan)], env=env, cwd=ROOT, start_new_session=True)
     for name in procs:
         procs[name] = (proc, procs[name][1], procs[name][2])
     _DP.update(procs)
@@ -86,6 +113,7 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def dp_jobs():
     """name -> loaded result of tests/dp_job.py (waits for the processes started at session start)."""
+    import signal
     import torch
     if not _DP:
         pytest.skip("data-parallel jobs were not started (no GPU, or -m 'not gpu')")
@@ -94,12 +122,22 @@ def dp_jobs():
     try:
         launcher.wait(timeout=600)
     except Exception:
-        launcher.kill()
+        try:
+            os.killpg(launcher.pid, signal.SIGKILL)         # exactly the process group created above: launcher + its ranks
+        except OSError:
+            pass
+        launcher.wait()
         raise AssertionError("the data-parallel jobs did not finish:\n" + "\n".join(open(l).read()[-1500:] for _p, _o, l in _DP.values()))
     for name, (_proc, out, log) in _DP.items():
         rc_path = out[:-3] + ".rc"
         rc = int(open(rc_path).read()) if os.path.exists(rc_path) else -1
         assert rc == 0, f"dp job {name} failed ({rc}):\n" + open(log).read()[-3000:]
         results[name] = torch.load(out)
+    keep = os.environ.get("CPC_DP_KEEP")                    # diagnostics: keep the records (e.g. under gpurun_out/)
+    if keep:
+        import shutil
+        os.makedirs(keep, exist_ok=True)
+        for name, (_proc, out, log) in _DP.items():
+            shutil.copy(out, keep)
+            shutil.copy(log, keep)
     return results
-

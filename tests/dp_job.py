@@ -11,6 +11,11 @@ mode "nccl":   world_size 1 over RCCL: init, broadcast, overlapped + blocking al
 mode "ddp":    the reference's own arrangement (cpc/train.py:523-527): model and criterion wrapped in
                torch.nn.parallel.DistributedDataParallel (gloo, two ranks on cuda:0), FlatAdam as the optimiser -- DDP's
                buckets average the gradients that the fused backward kernels wrote into the flat buffer.
+
+Self-diagnosing (round-2 review): every rank keeps, per step, an ON-STREAM clone of its own gradient taken right before each
+all-reduce (DataParallelContext.trace, no device-wide synchronisation anywhere near it) and of the buffer of sums after the
+last one; the single process keeps its accumulated gradient per step.  Every record travels with a checksum computed on the
+device, so a bad device-to-host copy of the record itself cannot pass for a finding.  tests/test_dp_gpu.py compares them.
 """
 import os
 import sys
@@ -46,31 +51,63 @@ def shard(r):
     return synth.audio_windows(B, 20480, 100 + r).to(DEV)
 
 
+def checksum(t):
+    """64-bit sum of the fp32 bit patterns, computed on the device."""
+    return int(t.contiguous().view(torch.int32).sum(dtype=torch.int64).item())
+
+
+class Tape:
+    """Per step: `pre` (this rank's gradient, assembled from the slices seen right before each all-reduce) and `post` (the
+    sums), as on-stream device copies."""
+
+    def __init__(self, n):
+        self.n, self.pre, self.post = n, [], []
+
+    def begin(self):
+        self.pre.append(torch.full((self.n,), float("nan"), device=DEV))
+        self.post.append(None)
+
+    def __call__(self, kind, lo, hi, view):
+        if kind == "pre":
+            self.pre[-1][lo:hi].copy_(view)
+        else:
+            self.post[-1] = view.clone()
+
+    def export(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, seq in (("pre", self.pre), ("post", self.post)):
+            out[name] = torch.stack([t.cpu() for t in seq])
+            out[name + "_sum"] = [checksum(t) for t in seq]
+        return out
+
+
 label = torch.zeros(B, dtype=torch.long, device=DEV)
 model, crit, opt = build()
+names = [(off, n) for off, (n, _p) in zip(opt.offsets, list(crit.named_parameters()) + list(model.named_parameters()))]
+tape = Tape(opt.flat_grad.numel())
 losses = []
 if mode in ("ranks", "nccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("nccl" if mode == "nccl" else "gloo", rank=rank, world_size=world)
     if rank != 0:
         opt.flat.mul_(1.5)                     # the broadcast must bring rank 0's parameters
-    overlap = not os.environ.get("CPC_DP_JOB_NO_OVERLAP")        # (diagnostics, tools/scratch/dp_diag.py: one blocking all-reduce)
-    dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()), overlap=overlap)
+    overlap = not os.environ.get("CPC_DP_JOB_NO_OVERLAP")        # (diagnostics: one blocking all-reduce)
+    dp = DataParallelContext.for_modules(opt, model, crit, overlap=overlap, trace=tape)
     assert not overlap or (dp.early and dp.late), (dp.early, dp.late)
     crit.seed(1234 + rank)
     x = shard(rank)
     for _ in range(STEPS):
+        tape.begin()
         tot, ls, _acc = cpcStep(x, x, label, model, crit, dp=dp)
         tot.backward()
         assert not overlap or (dp._fired and len(dp._pending) == len(dp.early))       # the early slices are on their way
-        if os.environ.get("CPC_DP_JOB_DUMP") and not losses:                          # (diagnostics: this rank's own gradient, step 1)
-            torch.cuda.synchronize()
-            torch.save(opt.flat_grad.detach().cpu(), out + ".grad")
         dp.reduce_and_step()
         opt.zero_grad()
         losses.append(ls.detach().cpu())
     if mode == "nccl":                          # and the blocking form
-        dp2 = DataParallelContext(opt, overlap=False)
+        dp2 = DataParallelContext(opt, overlap=False, trace=tape)
+        tape.begin()
         tot, ls, _acc = cpcStep(x, x, label, model, crit)
         tot.backward()
         dp2.reduce_and_step()
@@ -79,6 +116,7 @@ if mode in ("ranks", "nccl"):
     dist.barrier()
     dist.destroy_process_group()
 elif mode == "ddp":
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     from torch.nn.parallel import DistributedDataParallel as DDP
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -86,11 +124,26 @@ elif mode == "ddp":
         opt.flat.mul_(1.5)                     # DDP's constructor broadcasts rank 0's parameters (into the flat buffer's views)
     ddp_model = DDP(model, device_ids=[0], find_unused_parameters=True)
     ddp_crit = DDP(crit, device_ids=[0], find_unused_parameters=True)
+    home = {id(p): off for p, off in zip(opt.params, opt.offsets)}
+
+    def tap_then_allreduce(_state, bucket):
+        # what DDP does by default (divide by the world size, all-reduce the bucket), after an on-stream copy of this rank's
+        # gradients as the bucket holds them
+        for g, p in zip(bucket.gradients(), bucket.parameters()):
+            off = home[id(p)]
+            tape.pre[-1][off:off + p.numel()].copy_(g.reshape(-1))
+        return default_hooks.allreduce_hook(None, bucket)
+
+    ddp_model.register_comm_hook(None, tap_then_allreduce)
+    ddp_crit.register_comm_hook(None, tap_then_allreduce)
     crit.seed(1234 + rank)
     x = shard(rank)
     for _ in range(STEPS):
+        tape.begin()
         tot, ls, _acc = cpcStep(x, x, label, ddp_model, ddp_crit)
         tot.backward()
+        opt._gather_stray_grads()
+        tape("post", 0, opt.flat_grad.numel(), opt.flat_grad)         # DDP's averages, back in the parameters' gradients
         opt.step()
         opt.zero_grad()
         losses.append(ls.detach().cpu())
@@ -104,14 +157,21 @@ else:
         smp.seed(1234 + r)
         samplers.append(smp)
     for _ in range(STEPS):
+        tape.begin()
         for r in range(SHARDS):
             crit.sampler = samplers[r]
             x = shard(r)
             tot, ls, _acc = cpcStep(x, x, label, model, crit)
             tot.backward()
             losses.append(ls.detach().cpu())
+        opt._gather_stray_grads()
+        tape("pre", 0, opt.flat_grad.numel(), opt.flat_grad)          # the accumulated gradient of both shards
+        tape("post", 0, opt.flat_grad.numel(), opt.flat_grad)
         opt.step(grad_scale=1.0 / SHARDS)
         opt.zero_grad()
     torch.cuda.synchronize()
-torch.save({"flat": opt.flat.detach().cpu(), "losses": torch.stack(losses), "step_count": opt.step_count}, out)
+result = {"flat": opt.flat.detach().cpu(), "flat_sum": checksum(opt.flat), "losses": torch.stack(losses),
+          "step_count": opt.step_count, "names": names, "mode": mode}
+result.update(tape.export())
+torch.save(result, out)
 print("dp_job done", mode, rank, flush=True)
