@@ -10,6 +10,13 @@ LIB = os.path.join(HERE, "libcpc2_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["gemm_f32.hip", "gemm_planes.hip", "rowops.hip", "encoder.hip", "gru.hip", "lstm.hip", "infonce.hip", "transformer.hip", "negidx.cpp", "flac.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
+# Device code is built WITHOUT the packed-f32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  Round 3 found
+# (profiles/r03_dp_rootcause.md; tools/load_determinism_probe.py reproduces it) that kernels which hipcc
+# had packed -- conv0_bwd_kernel first of all -- returned slightly different sums from one launch to the next, on the same
+# inputs in the same registers, whenever ANOTHER process ran short kernels on the same MI355X: 10-39 % of launches with the
+# instructions, 0 of 1 260 without, at no measurable cost (5.42 against 5.43-5.64 ms per step; the guide lists packed f32
+# beside MFMAs as an anti-lever anyway).  The host pass does not know the feature and says so: that line is filtered.
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _newer(target, deps):
@@ -22,7 +29,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "..", "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rowcfg.h"), os.path.join(CSRC, "coop.h"), os.path.join(CSRC, "ldsdma.h"), os.path.join(HERE, "..", "include", "cpc2_hip.h")]
+    headers = [os.path.abspath(__file__), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rowcfg.h"), os.path.join(CSRC, "coop.h"), os.path.join(CSRC, "ldsdma.h"), os.path.join(HERE, "..", "include", "cpc2_hip.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + headers):
         return LIB
@@ -31,10 +38,15 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if not force and _newer(obj, [src] + headers):
             return obj
-        cmd = [HIPCC] + FLAGS + (["--offload-arch=gfx950"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + (DEVICE_FLAGS if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        noise = [ln for ln in res.stdout.splitlines() if ln.strip() and "is not a recognized feature for this target" not in ln]
+        if noise:
+            print("\n".join(noise), flush=True)
+        if res.returncode != 0:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as pool:

@@ -40,6 +40,11 @@ struct Conv0Args {
     const float *dy;       // [N][L1][H]
     float *part;           // [slots][13][H]
     int tiles_per_sample, n_tiles;
+#ifdef CPC_C0_DBG
+    unsigned *dbg;         // [blocks][8]: wrapping sums of the bit patterns a block LOADED (parameters, dy rows, statistics, xs);
+                           // waves whose HW_ID changed between entry and exit (context switch), wave 0's run time in 10 ns
+                           // ticks and its HW_ID at entry / exit
+#endif
 };
 
 template <int H> __device__ __forceinline__ void conv0_load_segment(float *xs, const Conv0Args &a, int n, int t0)
@@ -170,6 +175,26 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
             dbacc[v][e] = dgacc[v][e] = dbeacc[v][e] = 0.f;
         }
 
+#ifdef CPC_C0_DBG
+    __shared__ unsigned dbg_s[8];
+    if (threadIdx.x < 8) dbg_s[threadIdx.x] = 0u;
+    const unsigned hwid0 = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+    unsigned dbg_dy = 0u, dbg_st = 0u;
+    {
+        unsigned pp = 0u;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < C0_K; ++j) pp += __float_as_uint(wreg[v][e][j]);
+                pp += __float_as_uint(breg[v][e]) + __float_as_uint(gam[v][e]) + __float_as_uint(bet[v][e]);
+            }
+        __syncthreads();
+        atomicAdd(&dbg_s[0], pp);
+    }
+#endif
     constexpr int ROWS_PER_PASS = 4 * RPW;
     // the dy row and the statistics of pass it+1 are requested before pass it is worked on: with two or three
     // waves per SIMD nothing else hides the HBM round trip of a load that is consumed right away
@@ -190,6 +215,8 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
         __syncthreads();
         conv0_load_segment<H>(xs, a, n, t0);
         __syncthreads();
+#ifdef CPC_C0_DBG
+#endif
         for (int it = 0; it < C0_TB / ROWS_PER_PASS; ++it) {
             const int slot = it * ROWS_PER_PASS + wave * RPW + gi;
             const int t = t0 + slot;
@@ -201,6 +228,12 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
             float4 gcur[VPL];
 #pragma unroll
             for (int v = 0; v < VPL; ++v) gcur[v] = valid ? gnext[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef CPC_C0_DBG
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                dbg_dy += __float_as_uint(gcur[v].x) + __float_as_uint(gcur[v].y) + __float_as_uint(gcur[v].z) + __float_as_uint(gcur[v].w);
+            if (gl == 0) dbg_st += __float_as_uint(mean) + __float_as_uint(rstd);
+#endif
             if (it + 1 < C0_TB / ROWS_PER_PASS) request(n, t + ROWS_PER_PASS);
             float xh[VPL][4], gx[VPL][4];
             float s1 = 0.f, s2 = 0.f;
@@ -257,6 +290,33 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
         __syncthreads();
     }
     for (int c = threadIdx.x; c < 13 * H; c += 256) a.part[(long)blockIdx.x * 13 * H + c] = red[c];
+#ifdef CPC_C0_DBG
+    atomicAdd(&dbg_s[1], dbg_dy);
+    atomicAdd(&dbg_s[2], dbg_st);
+    {
+        // is the staged signal still what was loaded?  (LDS words changed behind the block's back: another workgroup's stores)
+        const int last = blockIdx.x < a.n_tiles ? blockIdx.x + ((a.n_tiles - 1 - blockIdx.x) / gridDim.x) * gridDim.x : -1;
+        if (last >= 0) {
+            const int n = last / a.tiles_per_sample, t0 = (last - n * a.tiles_per_sample) * C0_TB;
+            const float *xn = a.x + (long)n * a.L0;
+            for (int i = threadIdx.x; i < C0_S * C0_TB + C0_K - C0_S; i += blockDim.x) {
+                const int pos = C0_S * t0 - C0_P + i;
+                const float want = (pos >= 0 && pos < a.L0) ? xn[pos] : 0.f;
+                if (__float_as_uint(want) != __float_as_uint(xs[i])) { atomicAdd(&dbg_s[4], 1u); atomicMax(&dbg_s[3], (unsigned)i); }
+            }
+        }
+    }
+    {
+        const unsigned hwid1 = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        if (threadIdx.x == 0) {
+            dbg_s[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_in);
+            dbg_s[6] = hwid0;
+            dbg_s[7] = hwid1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && a.dbg != nullptr) a.dbg[blockIdx.x * 8 + threadIdx.x] = dbg_s[threadIdx.x];
+#endif
 }
 
 // sums[13][H] -> conv0.weight grad [H][1][10], bias grad, norm weight/bias grads
@@ -1133,6 +1193,10 @@ static int encoder_backward(const float *x, const float *const *prm, const float
     c0.N = N; c0.L0 = e.L[0]; c0.L1 = e.L[1]; c0.R0 = e.R[0]; c0.halo = kConv[1].p; c0.eps = eps;
     c0.tiles_per_sample = (int)cdiv(e.L[1], C0_TB);
     c0.n_tiles = N * c0.tiles_per_sample;
+#ifdef CPC_C0_DBG
+    // (diagnostic build, tools/dp_conv0_probe.py: the head of the weight-gradient scratch, idle by now)
+    c0.dbg = e.tn_bytes >= (size_t)CONV0_BWD_BLOCKS * 32 ? reinterpret_cast<unsigned *>(e.tn) : nullptr;
+#endif
     {
         ProfScope prof(PROF_CONV0_BWD, st);
         CPC_DISPATCH_H(H, hipLaunchKernelGGL(conv0_bwd_kernel<HH>, dim3(CONV0_BWD_BLOCKS), dim3(256), 0, st, c0));

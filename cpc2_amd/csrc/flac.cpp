@@ -193,6 +193,11 @@ bool decode_residual(BitReader &br, int32_t *res, int blocksize, int order)
     return idx == blocksize - order;
 }
 
+// A valid stream keeps every sample of a subframe inside its bps-bit range (bps <= 33 with the side channel's extra bit);
+// a corrupt one is rejected at the first sample that leaves it, so the 64-bit predictor arithmetic below cannot overflow:
+// |coef| < 2^14, |sample| <= 2^32, order <= 32.
+inline bool fits(int64_t v, int bps) { return v >= -(int64_t(1) << (bps - 1)) && v < (int64_t(1) << (bps - 1)); }
+
 bool decode_subframe(BitReader &br, int64_t *out, int blocksize, int bps, std::vector<int32_t> &res)
 {
     if (br.bits(1)) return false;
@@ -221,6 +226,7 @@ bool decode_subframe(BitReader &br, int64_t *out, int blocksize, int bps, std::v
             case 3: out[i] = r + 3 * out[i - 1] - 3 * out[i - 2] + out[i - 3]; break;
             default: out[i] = r + 4 * out[i - 1] - 6 * out[i - 2] + 4 * out[i - 3] - out[i - 4]; break;
             }
+            if (!fits(out[i], bps)) return false;
         }
     } else if (type >= 32) {
         const int order = (type & 31) + 1;
@@ -238,12 +244,13 @@ bool decode_subframe(BitReader &br, int64_t *out, int blocksize, int bps, std::v
             int64_t acc = 0;
             for (int j = 0; j < order; ++j) acc += coef[j] * out[i - 1 - j];
             out[i] = res[i - order] + (acc >> shift);
+            if (!fits(out[i], bps)) return false;
         }
     } else {
         return false;
     }
     if (wasted)
-        for (int i = 0; i < blocksize; ++i) out[i] <<= wasted;
+        for (int i = 0; i < blocksize; ++i) out[i] *= (int64_t(1) << wasted);      // (wasted < 33: bps stayed positive)
     return !br.fail;
 }
 
@@ -291,7 +298,7 @@ int decode_stream(const std::vector<uint8_t> &d, const Info &info, std::vector<i
         else if (ch_code == 10)
             for (int i = 0; i < blocksize; ++i) {
                 const int64_t side = ch[1][i];
-                const int64_t mid = (ch[0][i] << 1) | (side & 1);
+                const int64_t mid = ch[0][i] * 2 + (side & 1);
                 ch[0][i] = (mid + side) >> 1;
                 ch[1][i] = (mid - side) >> 1;
             }

@@ -86,7 +86,7 @@ label = torch.zeros(B, dtype=torch.long, device=DEV)
 model, crit, opt = build()
 names = [(off, n) for off, (n, _p) in zip(opt.offsets, list(crit.named_parameters()) + list(model.named_parameters()))]
 tape = Tape(opt.flat_grad.numel())
-losses = []
+losses, after_backward = [], []
 if mode in ("ranks", "nccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("nccl" if mode == "nccl" else "gloo", rank=rank, world_size=world)
@@ -102,6 +102,9 @@ if mode in ("ranks", "nccl"):
         tot, ls, _acc = cpcStep(x, x, label, model, crit, dp=dp)
         tot.backward()
         assert not overlap or (dp._fired and len(dp._pending) == len(dp.early))       # the early slices are on their way
+        if dp.late:
+            lo, hi = dp.late[0][0], dp.late[-1][1]
+            after_backward.append(opt.flat_grad[lo:hi].clone())      # the encoder's slice when backward has returned (on stream)
         dp.reduce_and_step()
         opt.zero_grad()
         losses.append(ls.detach().cpu())
@@ -151,7 +154,7 @@ elif mode == "ddp":
     dist.barrier()
     dist.destroy_process_group()
 else:
-    samplers = []
+    samplers, micro = [], []
     for r in range(SHARDS):
         smp = NegativeSampler()
         smp.seed(1234 + r)
@@ -164,6 +167,8 @@ else:
             tot, ls, _acc = cpcStep(x, x, label, model, crit)
             tot.backward()
             losses.append(ls.detach().cpu())
+            opt._gather_stray_grads()
+            micro.append(opt.flat_grad.clone())                   # accumulated after shard r (on stream)
         opt._gather_stray_grads()
         tape("pre", 0, opt.flat_grad.numel(), opt.flat_grad)          # the accumulated gradient of both shards
         tape("post", 0, opt.flat_grad.numel(), opt.flat_grad)
@@ -173,5 +178,9 @@ else:
 result = {"flat": opt.flat.detach().cpu(), "flat_sum": checksum(opt.flat), "losses": torch.stack(losses),
           "step_count": opt.step_count, "names": names, "mode": mode}
 result.update(tape.export())
+if mode == "single":
+    result["micro"] = torch.stack([m.cpu() for m in micro]).view(STEPS, SHARDS, -1)     # [step][shard]: accumulated so far
+if after_backward:
+    result["after_backward"] = torch.stack([t.cpu() for t in after_backward])
 torch.save(result, out)
 print("dp_job done", mode, rank, flush=True)

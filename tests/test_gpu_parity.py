@@ -926,7 +926,7 @@ def test_transformer_dropout_training_mode():
     a = net(x)
     torch.manual_seed(5)
     b = net(x)
-    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)     # same masks (split-K GEMMs add partial sums atomically)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)     # same masks (K splits are reduced in a fixed order: no atomics)
     assert not torch.allclose(a, ref, atol=1e-4)
     a.sum().backward()
     assert torch.isfinite(x.grad).all()
@@ -954,8 +954,12 @@ def test_transformer_dropout_gradient_is_consistent_at_head_size_32():
     assert abs(analytic - numeric) <= 2e-2 * max(1.0, abs(numeric)), (analytic, numeric)
 
 
-def test_model_with_transformer_ar_train_step_vs_oracle():
-    hidden, b, k, nn = 64, 2, 12, 16
+@pytest.mark.parametrize("hidden,nn", [(64, 16), (256, 128)])
+def test_model_with_transformer_ar_train_step_vs_oracle(hidden, nn):
+    """One full step with arMode='transformer' (feature_loader.py:216-220, transformers.py:119-134): loss and EVERY gradient
+    against the fp64 oracle.  (256, 128) is BASELINE configs[3] at its real shapes -- d_model 256 = head size 32: the MFMA
+    attention kernels, the plane-fed encoder GEMMs, the LDS-DMA InfoNCE kernels -- at b = 2."""
+    b, k = 2, 12
     mp = synth.encoder_params(hidden, 21)
     mp.update(synth.transformer_params(hidden, hidden, 128, 25))
     from cpc2_amd.transformers import buildTransformerAR

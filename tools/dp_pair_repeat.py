@@ -72,13 +72,35 @@ def main():
                        end_to_end_max=float((res["rank0"]["flat"] - res["single"]["flat"]).abs().max()),
                        ddp_end_to_end_max=float((res["ddp0"]["flat"] - res["single"]["flat"]).abs().max()))
         bad = any(rec.get(key) for key in ("kernel", "transport", "ddp_kernel", "ddp_transport")) or rec.get("records_ok") is not True
-        if bad:
+        if bad and "single" in res:
             findings += 1
-            shutil.copytree(tmp, os.path.join(out_dir, f"run{i}"), dirs_exist_ok=True)
+            # which rank, which elements, what values: a small record instead of the 15 MB of tensors
+            detail = {}
+            single = res["single"]
+            for pair, names_ in (("rank", ("rank0", "rank1")), ("ddp", ("ddp0", "ddp1"))):
+                for step in range(single["pre"].shape[0]):
+                    m0 = single["micro"][step][0]
+                    m1 = single["micro"][step][1] - m0
+                    for k, (nm, ref) in enumerate(zip(names_, (m0, m1))):
+                        got = res[nm]["pre"][step]
+                        d = (got - ref).abs()
+                        tol = 4e-6 * float(single["pre"][step].abs().max())
+                        idx = torch.nonzero(d > tol).view(-1)
+                        if idx.numel():
+                            per_param = {}
+                            for j in idx.tolist():
+                                nmp = T._where(single["names"], j)
+                                per_param[nmp] = per_param.get(nmp, 0) + 1
+                            detail[f"{nm}.step{step}"] = {
+                                "count": int(idx.numel()), "first": int(idx.min()), "last": int(idx.max()), "per_param": per_param,
+                                "max_abs_diff": float(d.max()), "ref_absmax": float(ref.abs().max()),
+                                "idx": idx[:24].tolist(), "got": [float(v) for v in got[idx[:24]]], "ref": [float(v) for v in ref[idx[:24]]],
+                                "ratio_got_over_ref_median": float((got[idx] / ref[idx]).median())}
+            rec["detail"] = detail
         shutil.rmtree(tmp, ignore_errors=True)
         log.write(json.dumps(rec) + "\n")
         log.flush()
-        print(json.dumps(rec)[:1500], flush=True)
+        print(json.dumps({k: v for k, v in rec.items() if k != "detail"})[:700], flush=True)
     print(f"runs {runs}, runs with a finding {findings}")
 
 
