@@ -445,6 +445,7 @@ def main():
     for name in [n for n in also.split(",") if n]:
         rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
         if rec is not None:
+            rec.pop("_gradient_bytes", None)
             others.append(rec)
     if rank == 0:
         if others:
