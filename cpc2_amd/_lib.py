@@ -73,6 +73,7 @@ SIGNATURES = {
     "cpc_infonce_saved_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_logits_offset": (c_size_t, [c_int] * 6),
+    "cpc_infonce_perm_offset": (c_size_t, [c_int] * 6),
     "cpc_infonce_forward": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_backward": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_forward_pred": (c_int, [c_ptr] * 8 + [c_int] * 5 + [c_ptr]),

@@ -492,7 +492,14 @@ class CPCUnsupersivedCriterion(BaseCriterion):
                       "infonce_forward_pred")
             off = lib.cpc_infonce_logits_offset(b, t, k, dim_ar, dim_enc, n_neg)
             n = b * windowSize * k * (n_neg + 1)
-            return saved[off:off + 4 * n].view(torch.float32).view(b, windowSize, k, n_neg + 1).clone()
+            slot_order = saved[off:off + 4 * n].view(torch.float32).view(b, windowSize, k, n_neg + 1)
+            # the kernel leaves a (b, t)'s negatives in the order it visited them (sorted by z-row block): back to the caller's
+            poff = lib.cpc_infonce_perm_offset(b, t, k, dim_ar, dim_enc, n_neg)
+            perm = saved[poff:poff + 2 * b * windowSize * n_neg].view(torch.int16).view(b, windowSize, 1, n_neg).long() & 0xFFFF
+            out = torch.empty_like(slot_order)
+            out[..., :1] = slot_order[..., :1]
+            out[..., 1:].scatter_(3, perm.expand(b, windowSize, k, n_neg), slot_order[..., 1:])
+            return out
 
     def getPrediction(self, cFeature, encodedData, label):
         """criterion.py:291-302: the K score tensors [b, 1 + negativeSamplingExt, W] (candidate 0 = the positive; score =

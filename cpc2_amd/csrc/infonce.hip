@@ -42,7 +42,8 @@ struct NceArgs {
                            // library: sorted by z-row block (nce_block_sort_kernel), slot g holds the caller's negative perm[g]
     const unsigned short *perm;   // [b][W][Nneg]: the caller's negative number of slot g (logits keep the caller's order)
     const float *weights;  // [b*W] or null
-    float *logits;         // [b*W][K][Nneg+1]
+    float *logits;         // [b*W][K][Nneg+1]: element 0 the positive, element 1 + g the negative in SLOT g of the block-sorted
+                           // list (not the caller's number perm[g]): the columns of a tile are then consecutive floats of a row
     float *lse;            // [b*W][K]
     float *lossp;          // [b*W][K]   w * CE
     float *hit;            // [b*W][K]   1 if argmax == 0
@@ -122,16 +123,12 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
     float pos[4] = {0.f, 0.f, 0.f, 0.f};
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // the wave's negative rows (and their numbers in the caller's order) go to LDS first, in one coalesced round trip: a
+    // the wave's negative rows go to LDS first, in one coalesced round trip: a
     // tile's row loads then issue at once instead of behind an index load of their own (two dependent L2 round trips per
     // tile were the kernel's critical path)
     extern __shared__ __attribute__((aligned(16))) int fwd_lds[];
     int *lrow = fwd_lds;                                                             // [Nneg]
-    unsigned short *lperm = reinterpret_cast<unsigned short *>(fwd_lds + a.Nneg);    // [Nneg]
-    for (int j = lane; j < a.Nneg; j += 64) {
-        lrow[j] = a.ext[(long)bt * a.Nneg + j];
-        lperm[j] = a.perm != nullptr ? a.perm[(long)bt * a.Nneg + j] : (unsigned short)j;
-    }
+    for (int j = lane; j < a.Nneg; j += 64) lrow[j] = a.ext[(long)bt * a.Nneg + j];
     __syncthreads();                           // one wave
     auto cand_row = [&](int g) -> long {       // z row of candidate g: the positive tile, then the negatives
 #if defined(NCE_DBG) && (NCE_DBG & 1)
@@ -182,12 +179,11 @@ template <int H> __global__ __launch_bounds__(64) void infonce_fwd_kernel(NceArg
         } else {
             const int j = 16 * (tile - 1) + r;              // negative slot of this lane's column
             if (j < a.Nneg) {
-                const int jo = lperm[j];                    // the caller's number of it
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = 4 * q + e;
                     const float x = acc[e] * inv_h;
-                    if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + jo] = x;
+                    if (k < a.K) a.logits[((long)bt * a.K + k) * (a.Nneg + 1) + 1 + j] = x;       // 16 lanes: 64 consecutive bytes
                     const float mn = fmaxf(m[e], x);
                     s[e] = s[e] * expf(m[e] - mn) + expf(x - mn);    // m = -inf: s = 0, exp(-inf) = 0
                     m[e] = mn;
@@ -249,7 +245,7 @@ constexpr int NCE_KC = 128;                                  // floats of a row 
 constexpr int NCE_PIECE = 1024 + 32;                         // bytes between pieces in LDS
 constexpr int NCE_PP = 16 * NCE_KC * 4 / 1024;               // pieces per element (8)
 constexpr int NCE_SLOT = NCE_PP * NCE_PIECE;
-constexpr int NCE_LIST = 1024 + 512;                         // bytes per index list in LDS: rows (int), numbers (ushort), <= 256
+constexpr int NCE_LIST = 1024;                               // bytes per index list in LDS: the rows (int) of <= 256 negatives
 template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel(NceArgs a, int n_bt)
 {
     static_assert(H % NCE_KC == 0 && NCE_KC == 128, "two rows per piece");
@@ -288,14 +284,13 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
         }
         wslot ^= NCE_SLOT;
     };
-    auto req_list = [&](int bt, int par) {                 // rows and numbers of (b,t)'s negatives
-        const unsigned dst = lds0 + 2 * NCE_SLOT + par * NCE_LIST;   // (the rows piece reads up to 1 KiB past a short list: inside `saved`)
+    auto req_list = [&](int bt, int par) {                 // rows of (b,t)'s negatives, in slot order
+        const unsigned dst = lds0 + 2 * NCE_SLOT + par * NCE_LIST;   // (the piece reads up to 1 KiB past a short list: inside `saved`)
         glds16(dst, lane * 16, reinterpret_cast<const char *>(a.ext) + (long)bt * a.Nneg * 4);
-        if (lane < 32) glds16(dst + 1024, lane * 16, reinterpret_cast<const char *>(a.perm) + (long)bt * a.Nneg * 2);
     };
     auto wait_newest = [&](int n) {                        // everything older than the newest n DMA instructions has landed
         if (n == NCE_PP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (n == NCE_PP + 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == NCE_PP + 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     static_assert(NCE_PP == 8, "the waits above are written for 8 pieces");
@@ -334,7 +329,6 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
         }
         // lists[par] has landed (it is older than the P elements' successors)
         const int *lrow = reinterpret_cast<const int *>(lists + par * NCE_LIST);
-        const unsigned short *lperm = reinterpret_cast<const unsigned short *>(lists + par * NCE_LIST + 1024);
         // Cross-entropy in base 2 on the raw accumulators (v_exp_f32 / v_log_f32 are single instructions, the natural-base
         // library forms ~15 each): score x = acc / H, x2 = x log2(e).
         float posacc[4] = {0.f, 0.f, 0.f, 0.f};              // raw accumulators of the positives
@@ -357,7 +351,7 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
                 } else if (bt_next < n_bt) {
                     req_p(bt_next, 0);
                     req_list(bt_next, par ^ 1);
-                    newest = NCE_PP + 2;
+                    newest = NCE_PP + 1;
                 } else {
                     newest = 0;
                 }
@@ -366,6 +360,10 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
                 read_frags(bf);
 #pragma unroll
                 for (int kk = 0; kk < FR; kk += 2) {
+#if defined(NCE_ABL) && (NCE_ABL & 4)
+                    acc0[0] += __builtin_bit_cast(f32x4, bf[kk])[0]; acc1[1] += __builtin_bit_cast(f32x4, bf[kk + 1])[1];
+                    continue;
+#endif
                     const float4 p0 = areg[half * FR + kk], p1 = areg[half * FR + kk + 1];
                     const f32x4 b0 = __builtin_bit_cast(f32x4, bf[kk]), b1 = __builtin_bit_cast(f32x4, bf[kk + 1]);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0.x, b0[0], acc0, 0, 0, 0);
@@ -389,15 +387,23 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
             } else {
                 const int j = 16 * (tile - 1) + r;              // negative slot of this lane's column
                 if (j < a.Nneg) {
-                    const int jo = lperm[j];                    // the caller's number of it
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (4 * q + e < a.K) lrow0[e * lstep + jo] = acc[e] * inv_h;
+#if !(defined(NCE_ABL) && (NCE_ABL & 1))
+                        // slot order: the 16 lanes of a row group write 64 consecutive bytes (in the caller's order these were
+                        // 64 scattered dwords per instruction -- 206 MB of write traffic for 46 MB of logits, and every store had
+                        // to retire before the next element's wait could pass: 17 % of the kernel)
+                        if (4 * q + e < a.K) lrow0[e * lstep + j] = acc[e] * inv_h;
+#endif
+#if defined(NCE_ABL) && (NCE_ABL & 2)
+                        m[e] = fmaxf(m[e], acc[e]);
+#else
                         const float x2 = acc[e] * sc2;
                         const float mn = fmaxf(m[e], x2);
                         sm[e] = sm[e] * __builtin_amdgcn_exp2f(m[e] - mn) + __builtin_amdgcn_exp2f(x2 - mn);   // m = -inf: 0 * 0 + ..
                         m[e] = mn;
                         macc[e] = fmaxf(macc[e], acc[e]);
+#endif
                     }
                 }
             }
@@ -501,7 +507,7 @@ template <int H> __global__ __launch_bounds__(64) void infonce_bwd_kernel(NceArg
                 if (g < NCE_POS) {
                     if (g == k) v = coef * (expf(lg[0] - l) - 1.f);
                 } else if (g - NCE_POS < a.Nneg) {
-                    v = coef * expf(lg[1 + (a.perm != nullptr ? (int)a.perm[bt * a.Nneg + g - NCE_POS] : g - NCE_POS)] - l);
+                    v = coef * expf(lg[1 + g - NCE_POS] - l);
                 }
             }
             dS[k * a.lw + g] = v;
@@ -647,7 +653,7 @@ template <int H> __global__ __launch_bounds__(64) void infonce_dz_store_kernel(N
 // that each own 128 of the H channels -- half the accumulators and operands of the one-wave form, so more waves per SIMD
 // stay resident and the candidate-row gathers of some overlap the 1 GB of contribution-row stores of others.
 //   phase 0  dS[16][lw] and the candidates' z rows into LDS.  ONE round of global loads: the index lists and the K logits
-//            rows are requested together (the rows land in LDS in the caller's order and are picked up through perm there);
+//            rows are requested together;
 //            under load a dependent global load costs microseconds
 //   phase 1  dP[k][d] (as infonce_bwd_kernel, d in this wave's 128 channels), the rows of the next 16 candidates
 //            requested before the current 16 are multiplied; phase 2 runs INSIDE phase 1's loop, group by group
@@ -695,8 +701,7 @@ template <int H, int NKK> __global__ __launch_bounds__(H / 2) void infonce_bwd_f
 #pragma unroll
     for (int i = 0; i < GI; ++i) {
         const int j = lane + 64 * i - NCE_POS;
-        const int pj = 1 + (int)a.perm[bt * a.Nneg + min(max(j, 0), a.Nneg - 1)];
-        gi[i] = j >= 0 && j < a.Nneg ? pj : 0;                     // (slot k < 16, the positive of step k: element 0)
+        gi[i] = j >= 0 && j < a.Nneg ? 1 + j : 0;                  // (slot k < 16, the positive of step k: element 0)
     }
     float coef[KW], lsek[KW];
 #pragma unroll
@@ -1339,6 +1344,14 @@ extern "C" size_t cpc_infonce_logits_offset(int b, int t, int k, int dim_ar, int
     char *const base = reinterpret_cast<char *>(4096);   // a fake base, never dereferenced: the layout only does arithmetic
     if (cpc::nce_layout(l, b, t, k, dim_ar, dim_enc, n_neg, base, nullptr) != CPC_OK) return (size_t)-1;
     return (size_t)(reinterpret_cast<char *>(l.logits) - base);
+}
+
+extern "C" size_t cpc_infonce_perm_offset(int b, int t, int k, int dim_ar, int dim_enc, int n_neg)
+{
+    cpc::NceLayout l;
+    char *const base = reinterpret_cast<char *>(4096);
+    if (cpc::nce_layout(l, b, t, k, dim_ar, dim_enc, n_neg, base, nullptr) != CPC_OK) return (size_t)-1;
+    return (size_t)(reinterpret_cast<char *>(l.perm) - base);
 }
 
 extern "C" size_t cpc_infonce_scratch_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg)

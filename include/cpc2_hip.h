@@ -274,8 +274,13 @@ int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_
 size_t cpc_infonce_saved_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
 size_t cpc_infonce_scratch_bytes(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
 /* byte offset, inside `saved`, of the logits the forward pass leaves there: float [b, W, K, 1 + n_neg], candidate 0 = the
- * positive -- what getPrediction (criterion.py:291-302) returns, before its permutation to K tensors [b, 1 + n_neg, W] */
+ * positive, the negatives in slot order (cpc_infonce_perm_offset) -- what getPrediction (criterion.py:291-302) returns once
+ * brought back to the caller's order and permuted to K tensors [b, 1 + n_neg, W] */
 size_t cpc_infonce_logits_offset(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
+/* The forward pass visits a (b, t)'s negatives sorted by z-row block and leaves the logits in THAT order (element 1 + g of a
+ * row = the negative in slot g: a tile's columns are then consecutive floats).  byte offset, inside `saved`, of the
+ * permutation: uint16 [b, W, n_neg], perm[g] = the caller's number (its position in ext_idx) of the negative in slot g */
+size_t cpc_infonce_perm_offset(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
 int cpc_infonce_forward(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
                         const float *weights, float *losses, float *acc, void *saved, void *scratch,
                         int b, int t, int k, int dim_ar, int dim_enc, int n_neg, cpc_stream_t stream);
