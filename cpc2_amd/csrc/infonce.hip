@@ -37,6 +37,7 @@ struct NceArgs {
     float *dPk[16];        // same addressing, gradients
     long p_stride;
     int p_rows;
+    int p_packed;          // the K prediction rows of a (b, t) are K*H consecutive floats (linear predictors: one GEMM output)
     const float *z;        // [b*T][H]
     const int32_t *ext;    // [b][W][Nneg]  TIME-MAJOR index layout (the negatives of one (b,t) are contiguous); inside the
                            // library: sorted by z-row block (nce_block_sort_kernel), slot g holds the caller's negative perm[g]
@@ -254,38 +255,63 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
     const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     const float inv_h = 1.f / H, sc2 = 1.4426950408889634f / H;
     extern __shared__ __attribute__((aligned(1024))) char dma_lds[];
-    const unsigned lds0 = lds_addr(dma_lds);
-    const char *lists = dma_lds + 2 * NCE_SLOT;                                // [2][NCE_LIST]
+    // the two index lists first, then the two slots: a slot's address minus the largest K-slice offset (glds16x8: M0 = address
+    // - offset) must not go below zero -- the hardware drops an LDS-DMA whose M0 is negative (tools/scratch/ldsdma_offset_probe.hip)
+    static_assert(2 * NCE_LIST >= (HS - 1) * NCE_KC * 4, "slot addresses stay above the K-slice offsets");
+    const char *lists = dma_lds;                                               // [2][NCE_LIST]
+    const unsigned lds0 = lds_addr(dma_lds) + 2 * NCE_LIST;
     const int ntiles = 1 + (a.Nneg + 15) / 16;
     unsigned wslot = 0;                                                        // slot the next request fills
     unsigned rslot = 0;                                                        // slot of the element to use next
     const int up = lane >> 5;                                                  // which of a piece's two rows this lane moves
     const unsigned vcol = (lane & 31) * 16;
 
-    // ---- requests: NCE_PP LDS-DMA instructions each (+ 2 for an index list)
-    auto req_rows = [&](int mine, int half) {              // lane r knows row r of the tile; K slice `half`
-        const unsigned dst = lds0 + wslot;
+    // ---- requests: NCE_PP LDS-DMA instructions each (+ 1 for an index list), all eight pieces of an element in one statement
+    // (glds16x8).  A lane's byte offsets into z for the eight pieces of a tile -- row of candidate 2 i + up, column vcol -- are
+    // formed once per tile (vr_*); the K slice of a request is the instruction's offset field.
+    const unsigned zmax = (unsigned)(a.b * a.T - 1);
+    auto rows_of_list = [&](const char *list, int tile, u32x2_t (&pr)[NCE_PP / 2]) {   // negatives 16 (tile - 1) + ..: issue only
+        const unsigned la = lds_addr(list) + (unsigned)(16 * (tile - 1) + up) * 4u;
+        pr[0] = lds_read2<0, 2>(la);   pr[1] = lds_read2<4, 6>(la);   pr[2] = lds_read2<8, 10>(la);   pr[3] = lds_read2<12, 14>(la);
+    };
+    auto rows_to_offsets = [&](const u32x2_t (&pr)[NCE_PP / 2], unsigned (&vr)[NCE_PP]) {   // after the reads' wait
 #pragma unroll
-        for (int i = 0; i < NCE_PP; ++i) {
-            const int r0 = __builtin_amdgcn_readlane(mine, 2 * i), r1 = __builtin_amdgcn_readlane(mine, 2 * i + 1);
-            const unsigned vo = (unsigned)(up ? r1 : r0) * (unsigned)(H * 4) + (unsigned)(half * NCE_KC * 4) + vcol;
-            glds16(dst + i * NCE_PIECE, vo, a.z);
-        }
+        for (int i = 0; i < NCE_PP; ++i) vr[i] = min(pr[i >> 1][i & 1], zmax) * (unsigned)(H * 4) + vcol;   // (slots past Nneg: any valid row)
+    };
+    auto req_rows = [&](const unsigned (&vr)[NCE_PP], int half) {
+        const unsigned dst = lds0 + wslot;
+        if (half == 0) glds16x8<NCE_PIECE, 0>(dst, vr, a.z);
+        else if (half == 1) glds16x8<NCE_PIECE, NCE_KC * 4>(dst, vr, a.z);
+        else if (half == 2) glds16x8<NCE_PIECE, 2 * NCE_KC * 4>(dst, vr, a.z);
+        else glds16x8<NCE_PIECE, 3 * NCE_KC * 4>(dst, vr, a.z);
         wslot ^= NCE_SLOT;
     };
+    static_assert(HS <= 4, "K slices through the offset field");
     auto req_p = [&](int bt, int half) {                   // the K prediction rows of (b,t) (rows >= K: row 0, unused)
         const int bb = bt / a.W, t = bt - bb * a.W;
         const unsigned dst = lds0 + wslot;
-        const long off = ((long)bb * a.p_rows + t) * a.p_stride + half * NCE_KC;
+        if (a.p_packed) {
+            // one tensor [b * p_rows][K * H]: row k of (b, t) is K-row number (bb p_rows + t) K + k of it
+            const unsigned r0 = (unsigned)((bb * a.p_rows + t) * a.K);
+            unsigned vp[NCE_PP];
 #pragma unroll
-        for (int i = 0; i < NCE_PP; ++i) {
-            const float *p0 = a.Pk[2 * i < a.K ? 2 * i : 0] + off, *p1 = a.Pk[2 * i + 1 < a.K ? 2 * i + 1 : 0] + off;
-            glds16_addr(dst + i * NCE_PIECE, reinterpret_cast<const char *>(up ? p1 : p0) + vcol);   // (the K predictions may be K tensors)
+            for (int i = 0; i < NCE_PP; ++i) vp[i] = (r0 + (2 * i + up < a.K ? 2 * i + up : 0)) * (unsigned)(H * 4) + vcol;
+            if (half == 0) glds16x8<NCE_PIECE, 0>(dst, vp, a.Pk[0]);
+            else if (half == 1) glds16x8<NCE_PIECE, NCE_KC * 4>(dst, vp, a.Pk[0]);
+            else if (half == 2) glds16x8<NCE_PIECE, 2 * NCE_KC * 4>(dst, vp, a.Pk[0]);
+            else glds16x8<NCE_PIECE, 3 * NCE_KC * 4>(dst, vp, a.Pk[0]);
+        } else {
+            const long off = ((long)bb * a.p_rows + t) * a.p_stride + half * NCE_KC;
+#pragma unroll
+            for (int i = 0; i < NCE_PP; ++i) {
+                const float *p0 = a.Pk[2 * i < a.K ? 2 * i : 0] + off, *p1 = a.Pk[2 * i + 1 < a.K ? 2 * i + 1 : 0] + off;
+                glds16_addr(dst + i * NCE_PIECE, reinterpret_cast<const char *>(up ? p1 : p0) + vcol);   // (the K predictions may be K tensors)
+            }
         }
         wslot ^= NCE_SLOT;
     };
     auto req_list = [&](int bt, int par) {                 // rows of (b,t)'s negatives, in slot order
-        const unsigned dst = lds0 + 2 * NCE_SLOT + par * NCE_LIST;   // (the piece reads up to 1 KiB past a short list: inside `saved`)
+        const unsigned dst = lds_addr(lists) + par * NCE_LIST;       // (the piece reads up to 1 KiB past a short list: inside `saved`)
         glds16(dst, lane * 16, reinterpret_cast<const char *>(a.ext) + (long)bt * a.Nneg * 4);
     };
     auto wait_newest = [&](int n) {                        // everything older than the newest n DMA instructions has landed
@@ -306,6 +332,21 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
                      : "memory");
         rslot ^= NCE_SLOT;
     };
+    // the same with the row indices of the NEXT tile requested alongside (one wait for both)
+    auto read_frags_rows = [&](frag_t (&f)[FR], const char *list, int tile_next, unsigned (&vr)[NCE_PP]) {
+        const unsigned fa = fbase + rslot;
+        u32x2_t pr[NCE_PP / 2];
+        rows_of_list(list, tile_next, pr);
+        f[0] = lds_read16<0>(fa);     f[1] = lds_read16<64>(fa);    f[2] = lds_read16<128>(fa);   f[3] = lds_read16<192>(fa);
+        f[4] = lds_read16<256>(fa);   f[5] = lds_read16<320>(fa);   f[6] = lds_read16<384>(fa);   f[7] = lds_read16<448>(fa);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(pr[0]), "+v"(pr[1]),
+                       "+v"(pr[2]), "+v"(pr[3])
+                     :
+                     : "memory");
+        rows_to_offsets(pr, vr);
+        rslot ^= NCE_SLOT;
+    };
 
     float4 areg[HS * FR];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -317,10 +358,16 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
         const int bb = bt / a.W, t = bt - bb * a.W;
         const int bt_next = bt + gridDim.x;
         // ---- the P elements (the first one travelled with the index list): into the A-operand registers
+        // byte offsets of the rows of the tile whose K slices are being requested; replaced by the next tile's (read from the
+        // list beside the fragments of K slice HS - 2) once the last slice of the current one has been requested
+        unsigned vr[NCE_PP];
+#pragma unroll
+        for (int i = 0; i < NCE_PP; ++i)                    // tile 0 = the positives z[b][t+1 ..]: no list needed
+            vr[i] = (unsigned)(2 * i + up < a.K ? bb * a.T + t + 1 + 2 * i + up : 0) * (unsigned)(H * 4) + vcol;
 #pragma unroll
         for (int half = 0; half < HS; ++half) {
             if (half + 1 < HS) req_p(bt, half + 1);
-            else req_rows(r < a.K ? bb * a.T + t + 1 + r : 0, 0);           // tile 0 = the positives z[b][t+1 ..]: no list needed
+            else req_rows(vr, 0);
             wait_newest(NCE_PP);
             frag_t f[FR];
             read_frags(f);
@@ -328,7 +375,7 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
             for (int kk = 0; kk < FR; ++kk) areg[half * FR + kk] = __builtin_bit_cast(float4, f[kk]);
         }
         // lists[par] has landed (it is older than the P elements' successors)
-        const int *lrow = reinterpret_cast<const int *>(lists + par * NCE_LIST);
+        const char *const list = lists + par * NCE_LIST;
         // Cross-entropy in base 2 on the raw accumulators (v_exp_f32 / v_log_f32 are single instructions, the natural-base
         // library forms ~15 each): score x = acc / H, x2 = x log2(e).
         float posacc[4] = {0.f, 0.f, 0.f, 0.f};              // raw accumulators of the positives
@@ -343,11 +390,9 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
                 // request the next element of the stream, then take this one
                 int newest = NCE_PP;
                 if (half + 1 < HS) {
-                    const int g = 16 * tile + r;
-                    req_rows(g < NCE_POS ? (g < a.K ? bb * a.T + t + 1 + g : 0) : (g - NCE_POS < a.Nneg ? lrow[g - NCE_POS] : 0), half + 1);
+                    req_rows(vr, half + 1);
                 } else if (tile + 1 < ntiles) {
-                    const int j = 16 * tile + r;                            // negative slot of candidate 16 (tile + 1) + r
-                    req_rows(j < a.Nneg ? lrow[j] : 0, 0);                  // (padding candidates: row 0, columns never used)
+                    req_rows(vr, 0);                                        // (the rows of tile + 1 by now)
                 } else if (bt_next < n_bt) {
                     req_p(bt_next, 0);
                     req_list(bt_next, par ^ 1);
@@ -357,7 +402,8 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
                 }
                 wait_newest(newest);
                 frag_t bf[FR];
-                read_frags(bf);
+                if (half == HS - 2) read_frags_rows(bf, list, min(tile + 1, ntiles - 1), vr);   // + the rows of tile + 1 (unused after the last tile)
+                else read_frags(bf);
 #pragma unroll
                 for (int kk = 0; kk < FR; kk += 2) {
 #if defined(NCE_ABL) && (NCE_ABL & 4)
@@ -1263,6 +1309,7 @@ static int infonce_forward(const float *c, const float *z, const float *wpred, c
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) a.Pk[k] = l.P + (size_t)k * Henc;
     a.p_stride = (long)K * Henc; a.p_rows = T;
+    a.p_packed = (size_t)b * T * K * Henc * sizeof(float) < (1ull << 32) ? 1 : 0;      // (32-bit byte offsets in the streaming kernel)
     return nce_launch_fwd(a, l, losses, acc, st);
 }
 
