@@ -38,43 +38,29 @@ __device__ __forceinline__ void glds16_addr(unsigned lds_dst, const void *lane_s
 
 // Eight pieces of one stream element in ONE statement: lane l of piece i writes 16 bytes at lds_dst + i * PSTEP + 16 l, read
 // from sbase + vo[i] + GOFF.  M0 is saved and restored once and stepped by an s_add between the pieces (the single-piece form
-// spends four scalar instructions per piece on it), and the eight per-lane offsets are inputs: no vector arithmetic between the
-// pieces.  GOFF (0 <= GOFF < 4096) goes into the instruction's offset field, which moves the LDS address by the same amount --
-// compensated in M0 -- so the K slices of a row share one offset register.
-template <int PSTEP, int GOFF> __device__ __forceinline__ void glds16x8(unsigned lds_dst, const unsigned (&vo)[8], const void *sbase)
+// spends four scalar instructions per piece on it), and the per-lane offsets are inputs: no vector arithmetic between the
+// pieces.  GOFF (0 <= GOFF < 4096) goes into the instruction's offset field, which moves the LDS address by the same amount
+// (tools/scratch/ldsdma_offset_probe.hip) -- compensated in M0, which must stay >= 0: a negative M0 drops the write -- so the K
+// slices of a row share one offset register.  NT: non-temporal loads (data read once -- prediction rows -- should not push the
+// gathered table out of L2).
+#define CPC_GLDS_FIRST(MOD) "s_mov_b32 %0, m0\n\ts_sub_u32 m0, %1, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %10 offset:%11" MOD "\n\t"
+#define CPC_GLDS_NEXT(N, MOD) "s_add_u32 m0, m0, %12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %" #N ", %10 offset:%11" MOD "\n\t"
+#define CPC_GLDS_BODY8(MOD)                                                                                                     \
+    CPC_GLDS_FIRST(MOD) CPC_GLDS_NEXT(3, MOD) CPC_GLDS_NEXT(4, MOD) CPC_GLDS_NEXT(5, MOD) CPC_GLDS_NEXT(6, MOD) CPC_GLDS_NEXT(7, MOD)   \
+    CPC_GLDS_NEXT(8, MOD) CPC_GLDS_NEXT(9, MOD)
+#define CPC_GLDS_OPS                                                                                                              \
+    : "=&s"(keep)                                                                                                                \
+    : "s"(lds_dst), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "v"(vo[5]), "v"(vo[6]), "v"(vo[7]), "s"(sbase), "n"(GOFF), \
+      "n"(PSTEP)                                                                                                                 \
+    : "memory", "scc"
+template <int PSTEP, int GOFF, bool NT = false>
+__device__ __forceinline__ void glds16x8(unsigned lds_dst, const unsigned (&vo)[8], const void *sbase)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_sub_u32 m0, %1, %11\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %3, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %4, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %5, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %6, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %7, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %8, %10 offset:%11\n\t"
-                 "s_add_u32 m0, m0, %12\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %9, %10 offset:%11\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_dst), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "v"(vo[5]), "v"(vo[6]), "v"(vo[7]), "s"(sbase),
-                   "n"(GOFF), "n"(PSTEP)
-                 : "memory", "scc");
+    if constexpr (NT) asm volatile(CPC_GLDS_BODY8(" nt") "s_mov_b32 m0, %0" CPC_GLDS_OPS);
+    else asm volatile(CPC_GLDS_BODY8("") "s_mov_b32 m0, %0" CPC_GLDS_OPS);
 }
+#undef CPC_GLDS_OPS
 
 // two dwords of LDS, `addr` + 4 * D0 and + 4 * D1 (asm for the same reason as lds_read16: no wait of the compiler's).  The
 // PAIR must go through the asm wait as it is ("+v" on the u32x2): elements taken out before the wait are copies of registers
