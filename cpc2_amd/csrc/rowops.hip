@@ -68,6 +68,11 @@ int coop_error_take(const char *where)
     if (g_err_host == nullptr) return CPC_OK;
     const int code = __atomic_exchange_n(g_err_host, 0, __ATOMIC_ACQ_REL);
     if (code == 0) return CPC_OK;
+    if (code == COOP_ERR_NONFINITE_GRAD) {
+        set_error("%s: the Adam step met non-finite gradient elements and did not apply them (parameters and moments of those "
+                  "elements are unchanged: the weights are those of the last good step)", where);
+        return CPC_ERR_HIP;
+    }
     set_error("%s: a cooperative recurrent kernel (%s pass) gave up waiting for the other workgroups of its group -- its "
               "workgroups were not all resident at once (another kernel on the device?); its outputs are NaN.  "
               "CPC_GRU_STREAM=1 selects the non-cooperative kernels", where, code == COOP_ERR_FWD_WAIT ? "forward" : "backward");
@@ -314,11 +319,17 @@ __global__ void window_gather_kernel(const float *audio, long total, const long 
 }
 
 // ---------------------------------------------------------------- Adam
+// A gradient element that is not finite (a cooperative recurrent kernel that timed out poisons its outputs with NaN, and
+// through the loss every gradient; with data parallelism the all-reduce carries it to every rank) is NOT applied: parameter
+// and moments of that element stay as they are and the asynchronous error word is set, so the next cpc_async_error_check /
+// recurrent entry point reports it -- the weights are still the ones of the last good step.
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n, float lr_c1, float rsqrt_c2,
-                            float beta1, float beta2, float eps, float grad_scale)
+                            float beta1, float beta2, float eps, float grad_scale, int *err)
 {
+    bool bad = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
+        if (!(fabsf(gi) <= 3.4028234e38f)) { bad = true; continue; }
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
@@ -326,6 +337,7 @@ __global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n
         const float denom = sqrtf(vi) * rsqrt_c2 + eps;
         p[i] -= lr_c1 * (mi / denom);
     }
+    if (bad) coop_report(err, COOP_ERR_NONFINITE_GRAD);
 }
 
 }  // namespace cpc
@@ -412,7 +424,7 @@ extern "C" int cpc_adam_step(float *p, const float *g, float *m, float *v, long 
     const float rsqrt_c2 = (float)(1.0 / std::sqrt(c2));
     const long blocks = std::min<long>(cpc::cdiv(n, 256), 4096);
     hipLaunchKernelGGL(cpc::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
-                       lr_c1, rsqrt_c2, beta1, beta2, eps, grad_scale);
+                       lr_c1, rsqrt_c2, beta1, beta2, eps, grad_scale, cpc::coop_error_word());
     CPC_CHECK_LAUNCH("adam_kernel");
     return CPC_OK;
 }

@@ -322,6 +322,9 @@ int cpc_window_gather(const float *audio, long total_samples, const long *offset
  * no amsgrad).  g is multiplied by grad_scale first (1/world_size after an all-reduce SUM).
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
  *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * An element whose gradient is not finite is left alone (p, m, v unchanged) and the asynchronous error word is set: the
+ * next cpc_async_error_check(stream) returns CPC_ERR_HIP.  A cooperative recurrent kernel that timed out therefore cannot
+ * poison the weights; recovery = continue from the current (last good) weights or reload the last checkpoint.
  * ------------------------------------------------------------------------------------------ */
 int cpc_adam_step(float *p, const float *g, float *m, float *v, long n, int step, float lr,
                   float beta1, float beta2, float eps, float grad_scale, cpc_stream_t stream);

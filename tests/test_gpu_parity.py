@@ -1598,6 +1598,30 @@ def test_cooperative_recurrence_timeout_is_reported(monkeypatch, mode):
     assert torch.equal(again, good)
 
 
+def test_adam_leaves_non_finite_gradient_elements_alone_and_reports_them():
+    """A NaN / inf gradient element (what a timed-out cooperative kernel leaves behind, on every rank after the all-reduce)
+    must not reach the weights: parameter and moments of that element stay, the others step, and the asynchronous error
+    check reports it (round-2 advice: the failure was loud but the weights were already poisoned)."""
+    lib = _lib.load()
+    stream = _lib.stream_ptr(DEV)
+    _lib.check(lib.cpc_async_error_check(stream))                       # (clear anything an earlier test left)
+    n = 5000
+    p = torch.linspace(-1, 1, n, device=DEV)
+    g = torch.full((n,), 0.5, device=DEV)
+    g[7], g[4097] = float("nan"), float("inf")
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p0 = p.clone()
+    _lib.check(lib.cpc_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, 1, 1e-2, 0.9, 0.999, 1e-8, 1.0, stream))
+    with pytest.raises(RuntimeError, match="non-finite gradient"):
+        _lib.check(lib.cpc_async_error_check(stream))
+    bad = torch.tensor([7, 4097], device=DEV)
+    assert torch.equal(p[bad], p0[bad]) and float(m[bad].abs().sum()) == 0 and float(v[bad].abs().sum()) == 0
+    good = torch.ones(n, dtype=torch.bool, device=DEV)
+    good[bad] = False
+    assert torch.allclose(p[good], p0[good] - 1e-2, atol=1e-6) and torch.isfinite(p).all()
+    _lib.check(lib.cpc_async_error_check(stream))                       # reported once, then clear
+
+
 # ----------------------------------------------------------------------------- BASELINE configs at their real shapes
 def _full_step_vs_oracle(hidden, layers, nneg, x, steps, lr, seed, tol_loss, tol_param):
     """`steps` Adam steps of the HIP path and of the fp32 CPU oracle on the same windows (reference semantics: 2b windows
