@@ -280,6 +280,9 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
     };
     auto req_rows = [&](const unsigned (&vr)[NCE_PP], int half) {
         const unsigned dst = lds0 + wslot;
+#if defined(NCE_ABL) && (NCE_ABL & 8)
+        half = 0;                                           // probe: every K slice re-reads slice 0 (a gather table of half the size)
+#endif
         if (half == 0) glds16x8<NCE_PIECE, 0>(dst, vr, a.z);
         else if (half == 1) glds16x8<NCE_PIECE, NCE_KC * 4>(dst, vr, a.z);
         else if (half == 2) glds16x8<NCE_PIECE, 2 * NCE_KC * 4>(dst, vr, a.z);
