@@ -299,11 +299,17 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
             unsigned vp[NCE_PP];
 #pragma unroll
             for (int i = 0; i < NCE_PP; ++i) vp[i] = (r0 + (2 * i + up < a.K ? 2 * i + up : 0)) * (unsigned)(H * 4) + vcol;
-            // (non-temporal: prediction rows are read once and should not push z out of L2 -- 538 -> 478 MB fetched per launch)
-            if (half == 0) glds16x8<NCE_PIECE, 0, true>(dst, vp, a.Pk[0]);
-            else if (half == 1) glds16x8<NCE_PIECE, NCE_KC * 4, true>(dst, vp, a.Pk[0]);
-            else if (half == 2) glds16x8<NCE_PIECE, 2 * NCE_KC * 4, true>(dst, vp, a.Pk[0]);
-            else glds16x8<NCE_PIECE, 3 * NCE_KC * 4, true>(dst, vp, a.Pk[0]);
+            // Non-temporal loads here (-DNCE_P_NT) take the kernel ALONE from 118 to 113 us -- the read-once rows no longer push z
+            // out of L2 -- but the backward pass re-reads P, finds it gone from the caches and loses 0.03 ms: net loss in the step.
+#ifdef NCE_P_NT
+            constexpr bool PNT = true;
+#else
+            constexpr bool PNT = false;
+#endif
+            if (half == 0) glds16x8<NCE_PIECE, 0, PNT>(dst, vp, a.Pk[0]);
+            else if (half == 1) glds16x8<NCE_PIECE, NCE_KC * 4, PNT>(dst, vp, a.Pk[0]);
+            else if (half == 2) glds16x8<NCE_PIECE, 2 * NCE_KC * 4, PNT>(dst, vp, a.Pk[0]);
+            else glds16x8<NCE_PIECE, 3 * NCE_KC * 4, PNT>(dst, vp, a.Pk[0]);
         } else {
             const long off = ((long)bb * a.p_rows + t) * a.p_stride + half * NCE_KC;
 #pragma unroll
@@ -443,7 +449,11 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
                         // slot order: the 16 lanes of a row group write 64 consecutive bytes (in the caller's order these were
                         // 64 scattered dwords per instruction -- 206 MB of write traffic for 46 MB of logits, and every store had
                         // to retire before the next element's wait could pass: 17 % of the kernel)
+#ifdef NCE_LOGITS_NT                                        /* (as NCE_P_NT: the backward pass reads the logits back) */
                         if (4 * q + e < a.K) __builtin_nontemporal_store(acc[e] * inv_h, lrow0 + e * lstep + j);
+#else
+                        if (4 * q + e < a.K) lrow0[e * lstep + j] = acc[e] * inv_h;
+#endif
 #endif
 #if defined(NCE_ABL) && (NCE_ABL & 2)
                         m[e] = fmaxf(m[e], acc[e]);
