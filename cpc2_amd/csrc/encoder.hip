@@ -25,6 +25,10 @@ namespace cpc {
 
 constexpr int C0_TB = 64;     // conv0: output rows per block tile
 constexpr int C0_K = 10, C0_S = 5, C0_P = 3;
+#ifndef C0_AHEAD_N
+#define C0_AHEAD_N 1
+#endif
+constexpr int C0_AHEAD = C0_AHEAD_N;   // conv0_bwd: dy rows requested ahead per lane group (measured 1..4, see the kernel)
 
 struct Conv0Args {
     const float *x;        // [N][L0]
@@ -196,45 +200,54 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
     }
 #endif
     constexpr int ROWS_PER_PASS = 4 * RPW;
-    // the dy row and the statistics of pass it+1 are requested before pass it is worked on: with two or three
-    // waves per SIMD nothing else hides the HBM round trip of a load that is consumed right away
-    float4 gnext[VPL];
-    float mean_next = 0.f, rstd_next = 0.f;
-    auto request = [&](int n, int t) {
+    // the dy rows and the statistics of passes it+1 .. it+C0_AHEAD are in flight while pass it is worked on: with two or three
+    // waves per SIMD nothing else hides the HBM round trip of a load that is consumed right away.  Measured at hidden 256
+    // (profiles/r03_conv0_bwd_ahead.txt): what pays is three waves per SIMD, not depth -- the pass loop left to the
+    // compiler's unroller took 192-214 VGPRs (two waves) and 180 us; held at one ring per trip (#pragma unroll 1) it takes
+    // <= 160 VGPRs and 158 us with 1 or 3 rows ahead, while 2 or 4 ahead (175-243 VGPRs, two waves) take 234-242 us.
+    constexpr int NPASS = C0_TB / ROWS_PER_PASS;
+    constexpr int AHEAD = NPASS < C0_AHEAD ? NPASS : C0_AHEAD;
+    float4 gq[AHEAD][VPL];
+    float mq[AHEAD], rq[AHEAD];
+    auto request = [&](int n, int t, int ring) {
         const bool ok = t < a.L1;
         const long row = (long)n * a.L1 + (ok ? t : 0);
-        mean_next = a.stats[row * 2 + 0];
-        rstd_next = ok ? a.stats[row * 2 + 1] : 0.f;
+        mq[ring] = a.stats[row * 2 + 0];
+        rq[ring] = ok ? a.stats[row * 2 + 1] : 0.f;
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) gnext[v] = reinterpret_cast<const float4 *>(a.dy + row * H)[v * G + gl];
+        for (int v = 0; v < VPL; ++v) gq[ring][v] = reinterpret_cast<const float4 *>(a.dy + row * H)[v * G + gl];
     };
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int n = tile / a.tiles_per_sample;
         const int t0 = (tile - n * a.tiles_per_sample) * C0_TB;
-        request(n, t0 + wave * RPW + gi);
+#pragma unroll
+        for (int d = 0; d < AHEAD; ++d) request(n, t0 + d * ROWS_PER_PASS + wave * RPW + gi, d);
         __syncthreads();
         conv0_load_segment<H>(xs, a, n, t0);
         __syncthreads();
-#ifdef CPC_C0_DBG
-#endif
-        for (int it = 0; it < C0_TB / ROWS_PER_PASS; ++it) {
+#pragma unroll 1
+        for (int it0 = 0; it0 < NPASS; it0 += AHEAD)
+#pragma unroll
+        for (int ring = 0; ring < AHEAD; ++ring) {
+            const int it = it0 + ring;
+            if (NPASS % AHEAD != 0 && it >= NPASS) break;
             const int slot = it * ROWS_PER_PASS + wave * RPW + gi;
             const int t = t0 + slot;
             const bool valid = t < a.L1;
             float xr[C0_K];
 #pragma unroll
             for (int j = 0; j < C0_K; ++j) xr[j] = xs[C0_S * slot + j];
-            const float mean = mean_next, rstd = rstd_next;     // rstd = 0 on rows past the end: du = 0 there
+            const float mean = mq[ring], rstd = rq[ring];       // rstd = 0 on rows past the end: du = 0 there
             float4 gcur[VPL];
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) gcur[v] = valid ? gnext[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = 0; v < VPL; ++v) gcur[v] = valid ? gq[ring][v] : make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef CPC_C0_DBG
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
                 dbg_dy += __float_as_uint(gcur[v].x) + __float_as_uint(gcur[v].y) + __float_as_uint(gcur[v].z) + __float_as_uint(gcur[v].w);
             if (gl == 0) dbg_st += __float_as_uint(mean) + __float_as_uint(rstd);
 #endif
-            if (it + 1 < C0_TB / ROWS_PER_PASS) request(n, t + ROWS_PER_PASS);
+            if (it + AHEAD < NPASS) request(n, t + AHEAD * ROWS_PER_PASS, ring);
             float xh[VPL][4], gx[VPL][4];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
