@@ -11,7 +11,8 @@ template <int H> struct CoopCfg {
     static constexpr int QS = H / 32;            // K slices of 32 columns
     static constexpr int U = 512 / QS;           // units per member
     static constexpr int G = H / U;              // workgroups per group
-    static constexpr int LDH = QS * 36;          // padded h row: chunk q of 32 floats at q*36
+    static constexpr int LDH = QS * 36 + 4;      // padded h row: chunk q of 32 floats at q*36; rows 4 banks apart (the gather
+                                                 // writes the NB windows of a unit from neighbouring lanes)
     static constexpr int HALVES = 512 / H;       // backward: threads per W_hh column
 };
 
@@ -20,11 +21,44 @@ typedef unsigned long long gu64_t;               // {epoch, value} granule
 
 __device__ __forceinline__ int coop_pad(int k) { return (k >> 5) * 36 + (k & 31); }
 
+// Forward granules: [group][set][member][unit u][window].  A member's piece of a set is ONE run of NB * U granules that nobody
+// else writes, and what a wave publishes (its 4 or 8 units x NB windows) is whole 128-byte lines.  Round 2 had
+// [group][set][window][H]: 32-byte pieces of lines shared with other members, which with a group on one XCD cost 5.4 us per
+// step at H = 512 against 2.35 (tools/exchange_probe.hip, profiles/r03_exchange_probe.txt).
+template <int H, int NB> __device__ __forceinline__ long coop_fwd_slot(int group, int set, int member, int u, int window)
+{
+    return (((long)group * 2 + set) * CoopCfg<H>::G + member) * (NB * CoopCfg<H>::U) + u * NB + window;
+}
+// granule idx (0 .. NB * H) of a set, in memory order -> window and unit k (0 .. H) of the group
+template <int H, int NB> __device__ __forceinline__ void coop_fwd_who(int idx, int &window, int &k)
+{
+    constexpr int U = CoopCfg<H>::U;
+    const int g = idx / (NB * U), p = idx - g * (NB * U);
+    window = p % NB;
+    k = g * U + p / NB;
+}
+
 // two f32 lanes per register pair: v_pk_fma_f32 issues at the rate of v_fma_f32 and does twice the work
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_lo(const float4 &v) { return f32x2{v.x, v.y}; }
 __device__ __forceinline__ f32x2 pk_hi(const float4 &v) { return f32x2{v.z, v.w}; }
+
+// Barrier between the phases of a time step.  The waves of a member talk to each other through LDS only, so only LDS
+// traffic has to have landed: __syncthreads() also waits for every global load and store of the wave (vmcnt(0)) -- the loads
+// requested a step ahead, the saved activations nobody waits for -- and put a memory round trip on every step's serial
+// path (H = 512: 2.2 us of the backward step's 8.2, profiles/r03_gru_stamps.txt).
+__device__ __forceinline__ void coop_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The weights are loaded once, before the time loop; used here so that the compiler waits for them HERE.  Left alone it waits
+// for the last of them at their first use inside the loop, with a vmcnt that counts the memory operations issued behind them
+// -- which in steady state are the loop's own requests and stores: every step then sat out a memory round trip in the middle
+// of its arithmetic (gru_bwd_coop_kernel<512>: s_waitcnt vmcnt(7) .. vmcnt(1) between the FMAs).
+template <int N> __device__ __forceinline__ void coop_weights_ready(f32x2 (&w)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(w[i]));
+}
 
 template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
 {

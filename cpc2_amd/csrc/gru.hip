@@ -14,6 +14,13 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef GRU_ABL_F
+#define GRU_ABL_F 8      // probes: K quarters of the slice actually multiplied (forward), of 8
+#endif
+#ifndef GRU_ABL_B
+#define GRU_ABL_B 24     // probes: row quarters multiplied (backward), of 24
+#endif
+
 namespace cpc {
 
 // W_hh [3H][H] -> wf[(k4*3 + g)*H + j] = W[g*H + j][4*k4 .. 4*k4+3]   (forward: thread j, all k)
@@ -205,11 +212,17 @@ __global__ void gru_bwd_kernel(GruArgs a)
 // suffice.  Every spin is bounded: on time-out the workgroup poisons its outputs with NaN and leaves.
 struct GruCoopArgs {
     GruArgs g;
-    gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
+    gu64_t *comm;          // granules, zeroed before the launch: fwd [groups][2][G][U][NB] (coop_fwd_slot), bwd [groups][2][G][NB][H]
     int groups, xcd_map;
     int *err;              // host-visible error word (coop.h), or nullptr
     int fault;             // tests: member 0 of group 0 withholds its publish of step 1
+    unsigned long long *stamps;   // -DGRU_STAMPS builds (probes): [workgroup][8] ticks of 10 ns summed over the steps, per phase
 };
+#ifdef GRU_STAMPS
+#define GRU_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); ph[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define GRU_STAMP(i) do { } while (0)
+#endif
 
 template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_kernel(GruCoopArgs ca)
 {
@@ -254,6 +267,9 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
         gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j];
     }
     bool dead = false;
+#ifdef GRU_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         // this lane finishes sample q (if q < NB); its input projections were requested one step ago, the next
@@ -269,7 +285,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
         for (int s = 0; s < NB; ++s) {
             f32x2 a2[3] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};    // even / odd columns of the slice
 #pragma unroll
-            for (int i4 = 0; i4 < 8; ++i4) {
+            for (int i4 = 0; i4 < GRU_ABL_F; ++i4) {
                 const float4 h4 = *reinterpret_cast<const float4 *>(&hs[cur][s][q * 36 + 4 * i4]);
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
@@ -278,6 +294,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[s][g] = coop_group_sum<QS>(a2[g].x + a2[g].y);
         }
+        GRU_STAMP(0);
         if (q < NB) {
             float g0 = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
@@ -292,7 +309,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
             if (dead) hv = NAN;
             // publish first (also for padding windows, so that every granule of the epoch gets written): the other
             // members wait for this store, nobody waits for the saved activations below
-            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
+            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + coop_fwd_slot<H, NB>(group, nxt, member, u, q));
             if (!(ca.fault && group == 0 && member == 0 && t == 1))
                 __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -305,6 +322,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
                 a.hall[((long)ns * (T + 1) + t + 1) * H + j] = hv;
             }
         }
+        GRU_STAMP(1);
         // gather the whole new h (all members) into the other LDS buffer; a thread's KP granules are polled together
         // (one L2 round trip per attempt, not KP in a row)
         if (t + 1 < T) {
@@ -312,7 +330,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
                 const int idx = tid + 512 * i;
-                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + idx / H) * H + (idx % H));
+                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + ((long)group * 2 + nxt) * (NB * H) + idx);      // memory order: coalesced
             }
             gu64_t x[KP];
             unsigned spins = dead ? (1u << 22) : 0u;            // once timed out, never wait again
@@ -327,15 +345,26 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
                     if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+#ifdef GRU_STAMPS
+                ph[4] += spins;
+#endif
+                GRU_STAMP(2);
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     const int idx = tid + 512 * i;
-                    hs[nxt][idx / H][coop_pad(idx % H)] = dead ? NAN : __uint_as_float((unsigned)x[i]);
+                    int gw, gk;
+                    coop_fwd_who<H, NB>(idx, gw, gk);
+                    hs[nxt][gw][coop_pad(gk)] = dead ? NAN : __uint_as_float((unsigned)x[i]);
                 }
             }
-            __syncthreads();            // `dead` stays with the thread that timed out: what it gathered is poisoned above
+            coop_lds_barrier();            // `dead` stays with the thread that timed out: what it gathered is poisoned above
+            GRU_STAMP(3);
         }
     }
+#ifdef GRU_STAMPS
+    if (ca.stamps != nullptr && (tid == 0 || tid == 511))
+        for (int i = 0; i < 5; ++i) ca.stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i] = ph[i];
+#endif
     if (a.hlast != nullptr && q < NB && n0 + q < a.N)
         a.hlast[(long)(n0 + q) * H + j] = a.hall[((long)(n0 + q) * (T + 1) + T) * H + j];
 }
@@ -388,7 +417,11 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
         p_hp = a.hall[((long)en * (T + 1) + t) * H + ej];
     };
     if (emine) request(T - 1);
+    coop_weights_ready(w);
     bool dead = false;
+#ifdef GRU_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
         const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
@@ -401,7 +434,6 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
                 const float r = p_r, z = p_z, c = p_c;
                 const float hnv = p_hn;
                 const float hp_ = p_hp;
-                if (t > 0) request(t - 1);
                 const float dc = dh * (1.f - z);
                 const float dz = dh * (hp_ - c);
                 const float dpn = dc * (1.f - c * c);
@@ -415,14 +447,17 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
                 gh[ej] = dpr; gh[H + ej] = dpz; gh[2 * H + ej] = dhn;
             }
             dgs[es][eu] = dpr; dgs[es][U + eu] = dpz; dgs[es][2 * U + eu] = dhn;
+            // behind the stores: a request in front of them made the compiler wait for it (vmcnt) where a store reused a register
+            if (emine && t > 0) request(t - 1);
         }
-        __syncthreads();
+        coop_lds_barrier();
+        GRU_STAMP(0);
         // partial[jc] over this thread's 96 rows, all NB windows
         f32x2 acc[NB];                                         // even / odd rows
 #pragma unroll
         for (int s = 0; s < NB; ++s) acc[s] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int i4 = 0; i4 < 24; ++i4) {
+        for (int i4 = 0; i4 < GRU_ABL_B; ++i4) {
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 const float4 d4 = *reinterpret_cast<const float4 *>(&dgs[s][half * 96 + 4 * i4]);
@@ -431,7 +466,8 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
         }
 #pragma unroll
         for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s].x + acc[s].y;
-        __syncthreads();
+        coop_lds_barrier();
+        GRU_STAMP(1);
         auto column = [&](int s, int k) {
             float v = part[0][s][k];
 #pragma unroll
@@ -449,6 +485,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
                 __hip_atomic_store(slot, ((gu64_t)epoch << 32) | (gu64_t)__float_as_uint(dead ? NAN : v), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
+            GRU_STAMP(2);
             if (ew) {
                 float sum = keep + column(es, ej);
                 // the partners' pieces are polled together: one L2 round trip per attempt, not G - 1 in a row
@@ -473,12 +510,43 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
 #pragma unroll
                 for (int d = 0; d < G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
                 carry = dead ? NAN : sum;
+#ifdef GRU_STAMPS
+                ph[4] += spins;
+#endif
             }
+            GRU_STAMP(3);
             // no barrier here: dgs is rewritten before the next step's first barrier, part after it, and every thread has
             // finished reading both when it gets there; `dead` stays with the thread that timed out (its carry is poisoned)
         }
     }
+#ifdef GRU_STAMPS
+    if (ca.stamps != nullptr && (tid == 0 || tid == 511))
+        for (int i = 0; i < 5; ++i) ca.stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i] = ph[i];
+#endif
 }
+
+#ifdef GRU_STAMPS
+static int gru_print_stamps(const char *what, const unsigned long long *stamps, int nblk, int H, int nb, int T, hipStream_t st)
+{
+    static unsigned long long host[512 * 8];
+    static int calls = 0;
+    CPC_CHECK_HIP(hipStreamSynchronize(st));
+    CPC_CHECK_HIP(hipMemcpy(host, stamps, sizeof(host), hipMemcpyDeviceToHost));
+    if (++calls % 7 != 0) return CPC_OK;
+    for (int who = 0; who < 2; ++who) {
+        double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nblk; ++b)
+            for (int i = 0; i < 5; ++i) {
+                const double v = (double)host[(b * 2 + who) * 8 + i];
+                sum[i] += v; mx[i] = std::max(mx[i], v);
+            }
+        fprintf(stderr, "gru stamps H=%d nb=%d thread %3d, us per step (mean, slowest workgroup) %s: %.2f (%.2f) | %.2f (%.2f) | %.2f (%.2f) | %.2f (%.2f); "
+                "failed polls per step %.2f (%.2f)\n", H, nb, who ? 511 : 0, what, sum[0] / nblk / T * 0.01, mx[0] / T * 0.01, sum[1] / nblk / T * 0.01,
+                mx[1] / T * 0.01, sum[2] / nblk / T * 0.01, mx[2] / T * 0.01, sum[3] / nblk / T * 0.01, mx[3] / T * 0.01, sum[4] / nblk / T, mx[4] / T);
+    }
+    return CPC_OK;
+}
+#endif
 
 template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
@@ -599,10 +667,20 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
             ca.err = coop_error_word(); ca.fault = coop_fault_injection();
             CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * nb * H, st));
-            ProfScope prof(PROF_GRU_FWD, st);
-            const dim3 grid((unsigned)(ca.groups * G));
-            if (H == 256) launch_coop_fwd<256>(nb, grid, st, ca);
-            else launch_coop_fwd<512>(nb, grid, st, ca);
+#ifdef GRU_STAMPS
+            static unsigned long long *stamps = nullptr;
+            if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 512 * 8 * sizeof(unsigned long long)));
+            ca.stamps = stamps;
+#endif
+            {
+                ProfScope prof(PROF_GRU_FWD, st);
+                const dim3 grid((unsigned)(ca.groups * G));
+                if (H == 256) launch_coop_fwd<256>(nb, grid, st, ca);
+                else launch_coop_fwd<512>(nb, grid, st, ca);
+            }
+#ifdef GRU_STAMPS
+            CPC_TRY(gru_print_stamps("fwd: math | gates+publish | wait | lds+barrier", stamps, ca.groups * G, H, nb, T, st));
+#endif
         } else {
             ProfScope prof(PROF_GRU_FWD, st);
             const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * 3 * hp);
@@ -643,10 +721,20 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
             ca.err = coop_error_word(); ca.fault = coop_fault_injection();
             CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * G * nb * H, st));
-            ProfScope prof(PROF_GRU_BWD, st);
-            const dim3 grid((unsigned)(ca.groups * G));
-            if (H == 256) launch_coop_bwd<256>(nb, grid, st, ca);
-            else launch_coop_bwd<512>(nb, grid, st, ca);
+#ifdef GRU_STAMPS
+            static unsigned long long *stamps = nullptr;
+            if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 512 * 8 * sizeof(unsigned long long)));
+            ca.stamps = stamps;
+#endif
+            {
+                ProfScope prof(PROF_GRU_BWD, st);
+                const dim3 grid((unsigned)(ca.groups * G));
+                if (H == 256) launch_coop_bwd<256>(nb, grid, st, ca);
+                else launch_coop_bwd<512>(nb, grid, st, ca);
+            }
+#ifdef GRU_STAMPS
+            CPC_TRY(gru_print_stamps("bwd: gates | math | publish | wait", stamps, ca.groups * G, H, nb, T, st));
+#endif
         } else {
             hipLaunchKernelGGL(gru_pack_bwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);
             CPC_CHECK_LAUNCH("gru_pack_bwd_kernel");

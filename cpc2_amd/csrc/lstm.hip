@@ -234,7 +234,7 @@ __global__ void lstm_bwd_kernel(LstmArgs a)
 // thread.  The cell state of (window q, unit j) stays in the register of the lane that finishes that pair.
 struct LstmCoopArgs {
     LstmArgs g;
-    gu64_t *comm;          // fwd [groups][2][NB][H], bwd [groups][2][G][NB][H] granules, zeroed before the launch
+    gu64_t *comm;          // granules, zeroed before the launch: fwd [groups][2][G][U][NB] (coop_fwd_slot), bwd [groups][2][G][NB][H]
     int groups, xcd_map;
     int *err;              // host-visible error word (coop.h), or nullptr
     int fault;             // tests: member 0 of group 0 withholds its publish of step 1
@@ -322,7 +322,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
             if (dead) hv = NAN;
             // publish first (also for padding windows, so that every granule of the epoch gets written): the other
             // members wait for this store, nobody waits for the saved activations below
-            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + q) * H + j);
+            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + coop_fwd_slot<H, NB>(group, nxt, member, u, q));
             if (!(ca.fault && group == 0 && member == 0 && t == 1))
                 __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -341,7 +341,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
                 const int idx = tid + 512 * i;
-                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + (((long)group * 2 + nxt) * NB + idx / H) * H + (idx % H));
+                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + ((long)group * 2 + nxt) * (NB * H) + idx);      // memory order: coalesced
             }
             gu64_t x[KP];
             unsigned spins = dead ? (1u << 22) : 0u;            // once timed out, never wait again
@@ -359,10 +359,12 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     const int idx = tid + 512 * i;
-                    hs[nxt][idx / H][coop_pad(idx % H)] = dead ? NAN : __uint_as_float((unsigned)x[i]);
+                    int gw, gk;
+                    coop_fwd_who<H, NB>(idx, gw, gk);
+                    hs[nxt][gw][coop_pad(gk)] = dead ? NAN : __uint_as_float((unsigned)x[i]);
                 }
             }
-            __syncthreads();            // `dead` stays with the thread that timed out: what it gathered is poisoned above
+            coop_lds_barrier();            // `dead` stays with the thread that timed out: what it gathered is poisoned above
         }
     }
     if (mine) {
@@ -422,6 +424,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
         p_c = a.call[((long)en * (T + 1) + T) * H + ej];
         request(T - 1);
     }
+    coop_weights_ready(w);
     bool dead = false;
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
@@ -433,7 +436,6 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
                 const float dh = p_dout + carry;
                 const float ig = p_i, fg = p_f, gg = p_g, og = p_o, cv = p_c, cp = p_cp;
                 p_c = cp;                                       // c_{t-1} is the next step's c_t
-                if (t > 0) request(t - 1);
                 const float tc = tanhf(cv);
                 const float dcv = dh * og * (1.f - tc * tc) + carry_c;
                 dpi = dcv * gg * ig * (1.f - ig);
@@ -447,8 +449,9 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
                 gh[ej] = dpi; gh[H + ej] = dpf; gh[2 * H + ej] = dpg; gh[3 * H + ej] = dpo;
             }
             dgs[es][eu] = dpi; dgs[es][U + eu] = dpf; dgs[es][2 * U + eu] = dpg; dgs[es][3 * U + eu] = dpo;
+            if (emine && t > 0) request(t - 1);                 // behind the stores (see gru_bwd_coop_kernel)
         }
-        __syncthreads();
+        coop_lds_barrier();
         if (t == 0) break;                                      // dh_{-1} is not needed
         // partial[jc] over this thread's RW rows, all NB windows
         f32x2 acc[NB];                                         // even / odd rows
@@ -464,7 +467,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
         }
 #pragma unroll
         for (int s = 0; s < NB; ++s) part[half][s][jc] = acc[s].x + acc[s].y;
-        __syncthreads();
+        coop_lds_barrier();
         auto column = [&](int s, int k) {
             float v = part[0][s][k];
 #pragma unroll

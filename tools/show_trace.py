@@ -17,14 +17,19 @@ for c in copies:
 ev.sort()
 tot, prev_end = 0.0, t0
 agg = {}
+gaps = []
 for s, e, name, extra in ev:
     d_us = (e - s) / 1e3
     gap = (s - prev_end) / 1e3
     if not name.startswith("COPY"):
+        gaps.append(max(gap, 0.0))
         tot += d_us
         prev_end = max(prev_end, e)
         agg[name] = agg.get(name, 0) + d_us
     print(f"{(s - t0) / 1e3:9.1f} {d_us:8.1f} {'gap %6.1f' % gap if gap > 3 else '          '} {name:44s} {extra}")
 print("kernel sum %.1f us, span %.1f us" % (tot, (t1 - t0) / 1e3))
+print("launches %d; idle between consecutive kernels: total %.1f us (gaps <= 3 us: %d, sum %.1f; 3-10 us: %d, sum %.1f; > 10 us: %d, sum %.1f)" % (
+    len(gaps), sum(gaps), sum(g <= 3 for g in gaps), sum(g for g in gaps if g <= 3), sum(3 < g <= 10 for g in gaps),
+    sum(g for g in gaps if 3 < g <= 10), sum(g > 10 for g in gaps), sum(g for g in gaps if g > 10)))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
     print("  %8.1f  %s" % (v, k))
