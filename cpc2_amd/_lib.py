@@ -76,6 +76,8 @@ SIGNATURES = {
     "cpc_infonce_perm_offset": (c_size_t, [c_int] * 6),
     "cpc_infonce_forward": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_backward": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
+    "cpc_infonce_backward_deferred": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
+    "cpc_infonce_join": (c_int, [c_ptr]),
     "cpc_infonce_forward_pred": (c_int, [c_ptr] * 8 + [c_int] * 5 + [c_ptr]),
     "cpc_infonce_backward_pred": (c_int, [c_ptr] * 9 + [c_int] * 5 + [c_ptr]),
     "cpc_flac_info": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
@@ -142,9 +144,10 @@ def ptr_array(tensors):
 _scratch = {}
 
 
-def scratch(nbytes, device):
-    # one buffer per (device, stream): ops enqueued on different streams may run at the same time
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+def scratch(nbytes, device, tag=None):
+    # one buffer per (device, stream): ops enqueued on different streams may run at the same time.  `tag`: a buffer of its
+    # own for an op whose kernels outlive the call on a stream of the library's (the deferred criterion backward)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0, tag)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

@@ -11,6 +11,7 @@ produce (the reference's CPU path); by default the criterion consumes -- and adv
 global CPU generator, so `torch.manual_seed(s)` gives bit-identical indices to the reference.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -153,14 +154,73 @@ def _packed_view(tensors):
     return torch.as_strided(first, (k,) + tuple(first.shape), (first.numel(),) + tuple(first.stride()))
 
 
-class _InfoNCEFn(torch.autograd.Function):
-    """inputs: c, z, ext_idx, weights, n_neg, then the K predictor weights [dim_enc, dim_ar]."""
+# ---- the deferred backward (cpc2_hip.h, cpc_infonce_backward_deferred) --------------------------------------------------------
+# The criterion's dz and predictor weight gradients are produced on a stream of the library's while the context network's
+# backward runs; whoever consumes them has to sit behind join_deferred().  That is guaranteed for an encodedData that came
+# out of grad_join() (CPCModel.forward applies it BEFORE the context network, so autograd runs its backward after the context
+# network's and before anything that reads the summed gradient of the encoder output); such a tensor carries `_cpc_join`, and
+# only then does the criterion defer.  A callback at the end of the backward pass joins whatever is still pending (an encoder
+# without gradient: nobody reads dz, the optimiser reads the weight gradients).
+_deferred = {}          # device index -> tensors the side stream still reads / writes (kept alive until the join)
+
+
+def join_deferred(device):
+    """Make the current stream of `device` wait for a pending deferred criterion backward (no-op when none is)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if _deferred.pop(idx, None) is not None:
+        check(_lib.load().cpc_infonce_join(stream_ptr(device)), "infonce_join")
+
+
+class _GradJoin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
 
     @staticmethod
-    def forward(ctx, c, z, ext_idx, weights, n_neg, *wk):
+    def backward(ctx, g):
+        join_deferred(g.device)
+        return g
+
+
+def grad_join(encoded):
+    """Identity on the encoder output; its backward is where a deferred criterion backward is joined.  Returns the tensor the
+    criterion should be given (marked `_cpc_join`; `_cpc_join_source` = the tensor whose gradient is the complete one)."""
+    if not (encoded.is_cuda and encoded.requires_grad and torch.is_grad_enabled()):
+        return encoded
+    out = _GradJoin.apply(encoded)
+    out._cpc_join = True
+    out._cpc_join_source = encoded
+    return out
+
+
+def carry_join(view, parent, start):
+    """`view` = parent[start:start + n] (windows) of a grad_join() output.  The criterion then differentiates with respect to
+    `parent` itself (its dz lands in rows start.. of a gradient of parent's size), so that no slicing node of autograd's --
+    which would read dz BEFORE the context network's backward, i.e. before the join -- sits between the two."""
+    if getattr(parent, "_cpc_join", False) and parent.is_contiguous() and view.is_contiguous() and \
+            view.data_ptr() == parent.data_ptr() + start * parent.stride(0) * parent.element_size():
+        view._cpc_join = True
+        view._cpc_join_parent = (parent, int(start))
+    return view
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """inputs: c, z, ext_idx, weights, n_neg, defer, then the K predictor weights [dim_enc, dim_ar].  defer: None, or
+    (start, n): the criterion's targets are windows start .. start + n of z and the backward is the deferred one."""
+
+    @staticmethod
+    def forward(ctx, c, z, ext_idx, weights, n_neg, defer, *wk):
         require_gpu(c, z, ext_idx, *wk)
         lib = _lib.load()
-        c, z = f32c(c), f32c(z)
+        c = f32c(c)
+        ctx.z_full_shape = None
+        if defer is not None:
+            ctx.z_full_shape, ctx.z_start = tuple(z.shape), defer[0]
+            z = z[defer[0]:defer[0] + defer[1]]
+        z = f32c(z)
         wpred = _packed_view([w.detach() for w in wk])
         if wpred is None:
             wpred = torch.stack([f32c(w.detach()) for w in wk], dim=0)
@@ -194,19 +254,39 @@ class _InfoNCEFn(torch.autograd.Function):
         c, z, wpred, ext_idx, w, saved = ctx.saved_tensors
         b, t, k, dim_ar, dim_enc, n_neg = ctx.dims
         dlosses = f32c(dlosses)
-        dc, dz = torch.empty_like(c), torch.empty_like(z)
+        dc = torch.empty_like(c)
+        defer = ctx.z_full_shape is not None
+        if defer and ctx.z_full_shape != tuple(z.shape):
+            dz_out = torch.zeros(ctx.z_full_shape, dtype=z.dtype, device=z.device)
+            dz = dz_out[ctx.z_start:ctx.z_start + z.shape[0]]
+        else:
+            dz_out = dz = torch.empty_like(z)
         gw = grad_buffers(ctx.param_refs)
         dw = _packed_view(gw)                 # contiguous in the flat gradient buffer -> written in place
         direct = dw is not None
         if not direct:
             dw = torch.empty_like(wpred)
-        sc = scratch(lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg), c.device)
-        check(lib.cpc_infonce_backward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
-                                       ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
-                                       stream_ptr(c.device)), "infonce_backward")
+        nscratch = lib.cpc_infonce_scratch_bytes(b, t, k, dim_ar, dim_enc, n_neg)
+        # (the weight gradients may only be late when nothing reads them before the end of the backward pass: written in place
+        #  into the flat gradient buffer.  A private buffer is added to .grad by autograd as soon as this function returns.)
+        if defer and direct:
+            join_deferred(c.device)            # (one pending backward per device)
+            sc = scratch(nscratch, c.device, tag="infonce_deferred")
+            check(lib.cpc_infonce_backward_deferred(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                                    ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
+                                                    stream_ptr(c.device)), "infonce_backward_deferred")
+            idx = c.device.index if c.device.index is not None else torch.cuda.current_device()
+            _deferred[idx] = (c, z, wpred, ext_idx, w, dlosses, saved, sc, dz_out, dw)
+            device = c.device
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: join_deferred(device))
+        else:
+            sc = scratch(nscratch, c.device)
+            check(lib.cpc_infonce_backward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                           ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
+                                           stream_ptr(c.device)), "infonce_backward")
         if not direct:
             gw = list(dw.unbind(0))
-        return (dc, dz, None, None, None) + tuple(gw)
+        return (dc, dz_out, None, None, None, None) + tuple(gw)
 
 
 class _InfoNCEPredFn(torch.autograd.Function):
@@ -528,6 +608,13 @@ class CPCUnsupersivedCriterion(BaseCriterion):
     def forward(self, cFeature, encodedData, label, signal_quality=None):
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
+        # deferred backward (see grad_join): only for an encodedData that sits behind a join, and not in reverse mode (the flip is
+        # an autograd node of its own that would read dz at once)
+        defer = None
+        if getattr(encodedData, "_cpc_join", False) and self.mode != "reverse" and not os.environ.get("CPC_NCE_NO_DEFER") \
+                and encodedData.dtype == torch.float32 and encodedData.is_contiguous():
+            zFull, start = getattr(encodedData, "_cpc_join_parent", (encodedData, 0))
+            defer = (start, batchSize)
         cFeature, encodedData = self._prepare(cFeature, encodedData)
         if signal_quality is not None:                  # criterion.py:334-338
             quality_weighting = self.weighting_function(signal_quality.mean(dim=1))
@@ -539,8 +626,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         if preds is not None:
             losses, acc = _InfoNCEPredFn.apply(encodedData, extIdx, quality_weighting, self.negativeSamplingExt, *preds)
         else:
-            losses, acc = _InfoNCEFn.apply(cFeature, encodedData, extIdx, quality_weighting, self.negativeSamplingExt,
-                                           *[p.weight for p in self.wPrediction.predictors])
+            losses, acc = _InfoNCEFn.apply(cFeature, zFull if defer is not None else encodedData, extIdx, quality_weighting,
+                                           self.negativeSamplingExt, defer, *[p.weight for p in self.wPrediction.predictors])
         losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
         return losses.view(1, -1), acc.view(1, -1)
 

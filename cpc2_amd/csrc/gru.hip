@@ -709,6 +709,7 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         a.wpack = g.wpack; a.hall = g.hall[l]; a.gates = g.gates[l]; a.hn = g.hn[l];
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
+        CPC_TRY(infonce_deferred_mark(st));       // (see infonce_deferred_start below)
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
         static const int n_cus = coop_cu_count();
         int G = 0;
@@ -743,6 +744,7 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
             hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
         }
         CPC_CHECK_LAUNCH("gru_bwd_kernel");
+        CPC_TRY(infonce_deferred_start(st));      // (no-op unless a deferred criterion backward is waiting to run beside this)
 
         // dW_hh[g][k] = sum_{n,t} dGH[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)
         CPC_TRY(gemm_tn(g.dgh, 3L * H, g.hall[l], H, grads[4 * l + 1], H, 3 * H, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, st));

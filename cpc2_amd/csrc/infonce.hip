@@ -16,6 +16,7 @@
 #include "rowcfg.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -1056,7 +1057,7 @@ struct NceLayout {
     unsigned short *perm;               // saved: slot -> the caller's negative number
     int nblk, rows_per_block;
     size_t saved_bytes;
-    float *lossp, *hit, *dP, *wt, *tn;  // scratch
+    float *lossp, *hit, *dP, *wt, *tn, *tn_late;  // scratch
     float *vbuf;                        // scratch: [b*W][K + Nneg][Henc] contribution rows of the dz product
     float *ds_buf;                      // scratch: [b*W][17][lw]
     int *counts, *offsets, *entries;    // scratch: reference lists (counts doubles as the fill cursor)
@@ -1092,6 +1093,7 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     l.wt = sc.take<float>((size_t)K * Henc * Har);
     l.tn_bytes = std::max(gemm_tn_scratch_bytes(K * Henc, Har, (long)b * T), gemm_nt_scratch_bytes((long)b * T, Har, K * Henc));
     l.tn = sc.take<float>(l.tn_bytes / sizeof(float));
+    l.tn_late = sc.take<float>(l.tn_bytes / sizeof(float));   // the weight gradient's slabs when it runs beside dc's K split (deferred form)
     l.counts = sc.take<int>((size_t)b * T);
     l.offsets = sc.take<int>((size_t)b * T + 1);
     l.entries = sc.take<int>((size_t)b * l.W * Nneg);
@@ -1203,6 +1205,16 @@ static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *
 struct NceSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    // deferred form of the backward (cpc_infonce_backward_deferred): `mid` = the fused backward kernel has run on the caller's
+    // stream, `late` = dz and the predictor weight gradients are complete on the side stream; `pending` until cpc_infonce_join
+    hipEvent_t mid = nullptr, late = nullptr;
+    std::atomic<bool> pending{false};
+    // what is left to launch of the pending backward (infonce_deferred_start): it is started by the NEXT backward entry point
+    // called on the caller's stream (the context network's, right behind its first kernel) or, failing that, by the join
+    bool marked = false, started = false, late_fused = false;     // marked: `mid` recorded
+    NceLayout l;
+    float *dz = nullptr, *dwpred = nullptr;
+    const float *c = nullptr;
 };
 
 static int nce_side(NceSide **out)
@@ -1214,9 +1226,13 @@ static int nce_side(NceSide **out)
     std::lock_guard<std::mutex> lk(mu);
     NceSide &sd = sides[dev];
     if (sd.stream == nullptr) {
-        CPC_CHECK_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+        int lo = 0, hi = 0;                       // lowest priority: what runs beside the caller's stream must not be served first
+        CPC_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CPC_CHECK_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, lo));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+        CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.mid, hipEventDisableTiming));
+        CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.late, hipEventDisableTiming));
     }
     *out = &sd;
     return CPC_OK;
@@ -1224,7 +1240,18 @@ static int nce_side(NceSide **out)
 
 // dz of the criterion: CPC_NCE_ATOMIC in the environment selects the fp32-atomic form, the default stores every
 // contribution once and sums per target row (see infonce_bwd_kernel)
-static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t st)
+static int nce_launch_gather(const NceLayout &l, float *dz, bool fused, hipStream_t st)
+{
+    const int rows = l.b * l.T;
+    NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_gather_kernel<HH>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, l.vbuf,
+                                             l.offsets, l.entries, dz, l.b, l.T, l.W, l.K, l.Nneg, fused ? NCE_POS : l.K));
+    CPC_CHECK_LAUNCH("infonce_dz_gather_kernel");
+    return CPC_OK;
+}
+
+// `late` (deferred form): the sum of the contribution rows into dz is NOT launched; *late is left pointing at the side record
+// (the reference lists are queued on its stream) and the caller launches nce_launch_gather there when it wants it to start
+static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t st, NceSide **late = nullptr)
 {
     static const bool atomic_dz = getenv("CPC_NCE_ATOMIC") != nullptr;
     const long n = (long)l.b * l.W * l.Nneg;
@@ -1301,10 +1328,13 @@ static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t
             NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_store_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_bwd, st, a));
             CPC_CHECK_LAUNCH("infonce_dz_store_kernel");
         }
+        if (late != nullptr) {                  // the caller launches the sum on the side stream (nce_launch_gather), later
+            *late = side;
+            side->late_fused = fused;
+            return CPC_OK;
+        }
         CPC_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
-        NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_gather_kernel<HH>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, l.vbuf,
-                                                 l.offsets, l.entries, dz, l.b, l.T, l.W, l.K, l.Nneg, fused ? NCE_POS : l.K));
-        CPC_CHECK_LAUNCH("infonce_dz_gather_kernel");
+        CPC_TRY(nce_launch_gather(l, dz, fused, st));
     }
     return CPC_OK;
 }
@@ -1329,7 +1359,7 @@ static int infonce_forward(const float *c, const float *z, const float *wpred, c
 
 static int infonce_backward(const float *c, const float *z, const float *wpred, const int32_t *ext, const float *weights,
                             const float *dlosses, void *saved, void *scratch, float *dc, float *dz, float *dwpred, int b, int T,
-                            int K, int Har, int Henc, int Nneg, hipStream_t st)
+                            int K, int Har, int Henc, int Nneg, hipStream_t st, bool defer)
 {
     NceLayout l;
     CPC_TRY(nce_layout(l, b, T, K, Har, Henc, Nneg, saved, scratch));
@@ -1338,14 +1368,69 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
     for (int k = 0; k < K; ++k) { a.Pk[k] = l.P + (size_t)k * Henc; a.dPk[k] = l.dP + (size_t)k * Henc; }
     a.p_stride = (long)K * Henc; a.p_rows = T;
     a.dloss = dlosses;
-    CPC_TRY(nce_launch_bwd(a, l, dz, st));
+    // Deferred form: only dc -- what the context network's backward waits for -- is produced on `st`.  dz (a memory-bound sum
+    // over ~1 GB of contribution rows) and the predictors' weight gradients run on the side stream, beside whatever the caller
+    // queues on `st` next (the recurrent backward: latency-bound, the chip mostly idle), until cpc_infonce_join.
+    NceSide *late = nullptr;
+    CPC_TRY(nce_launch_bwd(a, l, dz, st, defer ? &late : nullptr));
     // dc = dP . W  (rows t >= W of dP are zero)
     CPC_TRY(transpose2d(wpred, l.wt, K * Henc, Har, st));                        // [Har][K*Henc]
     RowMap none{};
     none.splitk_scratch = l.tn; none.splitk_bytes = l.tn_bytes;                  // few tiles, K = 12 H: ordered K split
     CPC_TRY(gemm_nt(l.dP, (long)K * Henc, l.wt, (long)K * Henc, dc, Har, nullptr, (long)b * T, Har, K * Henc, none, st));
     // dW_k[e][a] = sum_{b,t} dP[(b,t)][k*Henc + e] * c[b,t,a]
-    CPC_TRY(gemm_tn(l.dP, (long)K * Henc, c, Har, dwpred, Har, K * Henc, Har, (long)b * T, l.tn, l.tn_bytes, 0, 0, st));
+    if (late != nullptr) {
+        // nothing is queued on the side stream yet: queued here, beside the product above, it took the chip from it (85 -> 280 us)
+        // and then stood in the way of the small kernels in front of the recurrent backward instead of filling its idle time
+        late->l = l; late->dz = dz; late->dwpred = dwpred; late->c = c;
+        late->started = false; late->marked = false;
+        late->pending.store(true);
+    } else {
+        CPC_TRY(gemm_tn(l.dP, (long)K * Henc, c, Har, dwpred, Har, K * Henc, Har, (long)b * T, l.tn, l.tn_bytes, 0, 0, st));
+    }
+    return CPC_OK;
+}
+
+// Queue the rest of a pending deferred backward on the side stream (no-op when nothing is pending or it has been started),
+// ordered behind what `st` held at infonce_deferred_mark (or holds now, if that was not called).  The recurrent backward entry
+// points mark in front of their first kernel and start behind it: both run at once, and the recurrent kernel -- which needs
+// every workgroup resident -- is dispatched first; the sum and the weight gradient take what the chip has left.
+int infonce_deferred_mark(hipStream_t st)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    if (!side->pending.load() || side->started || side->marked) return CPC_OK;
+    CPC_CHECK_HIP(hipEventRecord(side->mid, st));
+    side->marked = true;
+    return CPC_OK;
+}
+
+int infonce_deferred_start(hipStream_t st)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    if (!side->pending.load() || side->started) return CPC_OK;
+    const NceLayout &l = side->l;
+    CPC_TRY(infonce_deferred_mark(st));
+    CPC_CHECK_HIP(hipStreamWaitEvent(side->stream, side->mid, 0));
+    CPC_TRY(nce_launch_gather(l, side->dz, side->late_fused, side->stream));
+    CPC_TRY(gemm_tn(l.dP, (long)l.K * l.Henc, side->c, l.Har, side->dwpred, l.Har, l.K * l.Henc, l.Har, (long)l.b * l.T, l.tn_late, l.tn_bytes, 0,
+                    0, side->stream));
+    CPC_CHECK_HIP(hipEventRecord(side->late, side->stream));
+    side->started = true;
+    return CPC_OK;
+}
+
+// every stream that is going to touch dz / dwpred of a deferred backward waits here (no-op when nothing is pending)
+static int infonce_join(hipStream_t st)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    if (side->pending.load()) {
+        CPC_TRY(infonce_deferred_start(st));
+        CPC_CHECK_HIP(hipStreamWaitEvent(st, side->late, 0));
+        side->pending.store(false);
+    }
     return CPC_OK;
 }
 
@@ -1435,8 +1520,19 @@ extern "C" int cpc_infonce_backward(const float *c, const float *z, const float 
                                     int t, int k, int dim_ar, int dim_enc, int n_neg, cpc_stream_t stream)
 {
     return cpc::infonce_backward(c, z, wpred, ext_idx, weights, dlosses, saved, scratch, dc, dz, dwpred, b, t, k, dim_ar, dim_enc,
-                                 n_neg, static_cast<hipStream_t>(stream));
+                                 n_neg, static_cast<hipStream_t>(stream), false);
 }
+
+extern "C" int cpc_infonce_backward_deferred(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
+                                             const float *weights, const float *dlosses, void *saved, void *scratch, float *dc,
+                                             float *dz, float *dwpred, int b, int t, int k, int dim_ar, int dim_enc, int n_neg,
+                                             cpc_stream_t stream)
+{
+    return cpc::infonce_backward(c, z, wpred, ext_idx, weights, dlosses, saved, scratch, dc, dz, dwpred, b, t, k, dim_ar, dim_enc,
+                                 n_neg, static_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int cpc_infonce_join(cpc_stream_t stream) { return cpc::infonce_join(static_cast<hipStream_t>(stream)); }
 
 extern "C" int cpc_infonce_forward_pred(const float *const *pred, const float *z, const int32_t *ext_idx, const float *weights,
                                         float *losses, float *acc, void *saved, void *scratch, int b, int t, int k, int dim_enc,

@@ -682,6 +682,7 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         a.wpack = g.wpack; a.whh = w_hh; a.hall = g.hall[l]; a.call = g.call[l]; a.gates = g.gates[l];
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
         a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
+        CPC_TRY(infonce_deferred_mark(st));       // (see infonce_deferred_start below)
         int members = 0;
         int nb = lstm_coop_windows(G, H, N, &members);
         if (nb != 0 && !(H == 256 ? lstm_coop_bwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * members), coop_cu_count())
@@ -705,6 +706,7 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
             hipLaunchKernelGGL(lstm_bwd_kernel<G>, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
         }
         CPC_CHECK_LAUNCH("lstm_bwd_kernel");
+        CPC_TRY(infonce_deferred_start(st));      // (no-op unless a deferred criterion backward is waiting to run beside this)
         const int GH = G * H;
         // dW_hh[g][k] = sum_{n,t} dG[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)
         CPC_TRY(gemm_tn(g.dgh, GH, g.hall[l], H, grads[4 * l + 1], H, GH, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, st));

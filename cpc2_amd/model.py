@@ -440,5 +440,9 @@ class CPCModel(nn.Module):
             encodedData = self.gEncoder(batchData).permute(0, 2, 1)
         if self.mask_prob > 0.0:
             encodedData = self.getMask(encodedData)
+        # (before the context network: autograd then runs this node's backward AFTER the context network's, and a criterion
+        #  backward that was deferred beside it is joined there -- criterion.py, grad_join)
+        from .criterion import grad_join
+        encodedOut = grad_join(encodedData)
         cFeature = self.gAR(encodedData)
-        return cFeature, encodedData, label
+        return cFeature, encodedOut, label

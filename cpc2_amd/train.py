@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .criterion import CPCUnsupersivedCriterion, NoneCriterion
+from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join
 from .model import CPCAR, CPCEncoder, CPCModel
 
 
@@ -285,6 +285,7 @@ class DataParallelContext:
     def attach(self, encoder_output):
         """Register the hook that starts the early reductions when the gradient of `encoder_output` is ready (everything
         downstream of the encoder has then written its parameter gradients)."""
+        encoder_output = getattr(encoder_output, "_cpc_join_source", encoder_output)   # (criterion.py, grad_join)
         if not (self.active and self.early and encoder_output.requires_grad):
             return
         if self._fired:
@@ -351,7 +352,7 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     if dp is not None:
         dp.attach(encoded_data)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
     c_feature = c_feature[:b, :, :]
-    encoded_data = encoded_data[b:, :, :]
+    encoded_data = carry_join(encoded_data[b:, :, :], encoded_data, b)
     label = label[:b]
     allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
     return allLosses.sum(), allLosses, allAcc

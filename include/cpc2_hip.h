@@ -288,6 +288,17 @@ int cpc_infonce_backward(const float *c, const float *z, const float *wpred, con
                          const float *weights, const float *dlosses, void *saved, void *scratch,
                          float *dc, float *dz, float *dwpred, int b, int t, int k, int dim_ar,
                          int dim_enc, int n_neg, cpc_stream_t stream);
+/* Deferred form of the same backward.  On return only `dc` -- what the context network's backward (cpc/model.py:158-207 under
+ * autograd) needs next -- is ordered on `stream`; `dz` and `dwpred` are produced on a stream of the library's, beside whatever
+ * the caller enqueues on `stream` afterwards, and NOTHING may read them (nor reuse c, z, ext_idx, saved, scratch) until
+ * cpc_infonce_join(stream') has been called for the stream' that will: it makes stream' wait for them (a no-op when nothing is
+ * pending; one deferred backward may be pending per device).  The context network's backward is latency-bound and leaves the
+ * chip idle; the criterion's dz is a memory-bound sum over ~1 GB -- together they take the time of the longer one. */
+int cpc_infonce_backward_deferred(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
+                                  const float *weights, const float *dlosses, void *saved, void *scratch,
+                                  float *dc, float *dz, float *dwpred, int b, int t, int k, int dim_ar,
+                                  int dim_enc, int n_neg, cpc_stream_t stream);
+int cpc_infonce_join(cpc_stream_t stream);
 
 /* The same criterion when the K predictions come from predictor MODULES instead of linear maps
  * (rnnMode="transformer": criterion.py:136-143; the predictions are produced by cpc_transformer_*):
