@@ -1363,6 +1363,92 @@ def test_training_steps_are_reproducible_bit_for_bit():
         assert torch.equal(finals[0], finals[1]), f"hidden {hidden}: parameters differ between two identical runs"
 
 
+@pytest.mark.parametrize("dedup", [False, True])
+def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch, dedup):
+    """cpc_infonce_backward_deferred + cpc_infonce_join (dz and the predictor weight gradients on the library's side stream,
+    beside the recurrent backward; joined where autograd sums the encoder output's gradient) runs the SAME kernels as the
+    immediate form: every gradient and the parameters after two steps are equal bit for bit, with the reference's 2b-window
+    batch (the criterion then differentiates with respect to the full encoder output, rows b.. only) and with dedup."""
+    from cpc2_amd import criterion as crit_mod
+    hidden, b = 256, 6
+    results = []
+    for defer in (True, False):
+        if defer:
+            monkeypatch.delenv("CPC_NCE_NO_DEFER", raising=False)
+        else:
+            monkeypatch.setenv("CPC_NCE_NO_DEFER", "1")
+        mp = synth.encoder_params(hidden, 21)
+        mp.update(synth.gru_params(hidden, hidden, 1, 22))
+        model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+        model.load_state_dict(mp)
+        crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128)
+        crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 23))
+        model, crit = model.to(DEV), crit.to(DEV)
+        opt = buildOptimizer(model, crit, lr=2e-4)
+        crit.seed(5)
+        x = synth.audio_windows(b, 20480, 24).to(DEV)
+        label = torch.zeros(b, dtype=torch.long, device=DEV)
+        seen = []
+        real = crit_mod._InfoNCEFn.apply
+
+        def spy(*a):
+            seen.append(a[5])
+            return real(*a)
+        monkeypatch.setattr(crit_mod._InfoNCEFn, "apply", staticmethod(spy))
+        grads = []
+        for _ in range(2):
+            tot, _losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup)
+            tot.backward()
+            assert not crit_mod._deferred, "a deferred backward is still pending after the backward pass"
+            grads.append(opt.flat_grad.detach().clone())
+            opt.step()
+            opt.zero_grad()
+        monkeypatch.setattr(crit_mod._InfoNCEFn, "apply", real)
+        assert all((d is not None) == defer for d in seen), seen
+        if defer:
+            assert seen[0] == ((0, b) if dedup else (b, b))
+        results.append((grads, opt.flat.detach().clone()))
+    for step in range(2):
+        assert torch.equal(results[0][0][step], results[1][0][step]), f"step {step}: gradients differ between the two forms"
+    assert torch.equal(results[0][1], results[1][1])
+
+
+def test_infonce_backward_deferred_c_entry_matches_the_immediate_one():
+    """The C entry points themselves: deferred + join on the calling stream == cpc_infonce_backward, bit for bit; a second join
+    is a no-op."""
+    from cpc2_amd import _lib
+    lib = _lib.load()
+    b, t, k, h, nn = 4, 128, 12, 256, 32
+    g = torch.Generator().manual_seed(3)
+    c = torch.randn(b, t, h, generator=g).to(DEV)
+    z = torch.randn(b, t, h, generator=g).to(DEV)
+    wpred = (0.05 * torch.randn(k, h, h, generator=g)).to(DEV)
+    ext = torch.randint(0, b * t, (b * (t - k) * nn,), generator=g, dtype=torch.int32).to(DEV)
+    dl = torch.rand(k, generator=g).to(DEV)
+    st = _lib.stream_ptr(c.device)
+    nsaved = lib.cpc_infonce_saved_bytes(b, t, k, h, h, nn)
+    nscr = lib.cpc_infonce_scratch_bytes(b, t, k, h, h, nn)
+    outs = []
+    for deferred in (False, True):
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=DEV)
+        scr = torch.empty(nscr, dtype=torch.uint8, device=DEV)
+        losses, acc = torch.empty(k, device=DEV), torch.empty(k, device=DEV)
+        _lib.check(lib.cpc_infonce_forward(_lib.ptr(c), _lib.ptr(z), _lib.ptr(wpred), _lib.ptr(ext), None, _lib.ptr(losses), _lib.ptr(acc),
+                                           _lib.ptr(saved), _lib.ptr(scr), b, t, k, h, h, nn, st), "fwd")
+        dc, dz, dw = torch.empty_like(c), torch.empty_like(z), torch.empty_like(wpred)
+        fn = lib.cpc_infonce_backward_deferred if deferred else lib.cpc_infonce_backward
+        _lib.check(fn(_lib.ptr(c), _lib.ptr(z), _lib.ptr(wpred), _lib.ptr(ext), None, _lib.ptr(dl), _lib.ptr(saved), _lib.ptr(scr),
+                      _lib.ptr(dc), _lib.ptr(dz), _lib.ptr(dw), b, t, k, h, h, nn, st), "bwd")
+        if deferred:
+            _lib.check(lib.cpc_infonce_join(st), "join")
+            _lib.check(lib.cpc_infonce_join(st), "join again")
+        torch.cuda.synchronize()
+        outs.append((dc, dz, dw))
+    for name, a, bb in zip(("dc", "dz", "dwpred"), outs[0], outs[1]):
+        assert torch.equal(a, bb), name
+    assert float(outs[0][1].abs().max()) > 0
+
+
 def test_train_step_with_signal_quality_files(tmp_path):
     """The feeder's third batch element (dataset.py:327-330) reaches the criterion's quality weighting
     (train.py:88-94,107; criterion.py:230,334-338): an epoch of trainStep on the fixture with generated estimate files."""
