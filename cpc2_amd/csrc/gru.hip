@@ -369,6 +369,237 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
         a.hlast[(long)(n0 + q) * H + j] = a.hall[((long)(n0 + q) * (T + 1) + T) * H + j];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same recurrence with the step's product on the bf16 matrix pipe (many windows per group: H = 512, NB = 8, where the
+// VALU form spends 2.4 of a 5.8 us step on 768 FMAs per thread).  Per member and step out[16][3U] = A[16][H] B[H][3U]:
+//   B = the member's 3U rows of W_hh (column c = gate * U + unit) as the three bf16 terms of every weight, held in registers
+//       as v_mfma_f32_16x16x32_bf16 operands: the 3U / 16 column tiles x 4 (or 2) K parts make 24 units of 4 K steps, three
+//       per wave -- three tiles of ONE K part -- (144 VGPRs);
+//   A = the three bf16 terms of h (LDS, [plane][window][H + 8]), with windows 0-7 of term 0 in rows 0-7 and of term 1 -- or 2 --
+//       in rows 8-15, so that FOUR products per K step give the six of the exact split (gemm_f32.hip):
+//       [h0|h1] w0 -> h0w0, h1w0;  [h0|h1] w1 -> h0w1, h1w1;  [h0|h2] w2 -> h0w2 (+ h2w2: 2^-32, harmless);  [h2|0] w0 -> h2w0.
+// The units' 16 x 16 partial tiles go through LDS ([unit][column][row]); the lane that finishes (window q, unit u) adds the
+// K parts and the two row halves in a fixed order.  Everything else -- granules, polling, saved activations -- is the
+// cooperative kernel's.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+struct MfmaFrag { unsigned d[4]; };                     // 8 bf16: one operand of v_mfma_f32_16x16x32_bf16
+
+__device__ __forceinline__ unsigned short bf16_rne(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// v = t0 + t1 + t2 (bf16 each, round to nearest): exact to 2^-27 |v| (gemm_f32.hip)
+__device__ __forceinline__ void split3(float v, unsigned short (&t)[3])
+{
+    t[0] = bf16_rne(v);
+    v -= __uint_as_float((unsigned)t[0] << 16);
+    t[1] = bf16_rne(v);
+    v -= __uint_as_float((unsigned)t[1] << 16);
+    t[2] = bf16_rne(v);
+}
+
+template <int H> struct MfmaCfg {
+    using C = CoopCfg<H>;
+    static constexpr int N3 = 3 * C::U;                  // columns of the member: gate * U + unit
+    static constexpr int TILES = N3 / 16;                // 6 (H = 512), 12 (H = 256)
+    static constexpr int KS = 24 / TILES;                // K parts per tile: 24 units for 8 waves
+    static constexpr int KPU = (H / 32) / KS;            // K steps of 32 per unit
+    static constexpr int LDK = H + 8;                    // bf16 per (plane, window) row: rows 4 banks apart
+    static_assert(N3 % 16 == 0 && 24 % TILES == 0 && (H / 32) % KS == 0 && KPU == 4, "24 units of 4 K steps");
+};
+
+template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_mfma_kernel(GruCoopArgs ca)
+{
+    using C = CoopCfg<H>;
+    using M = MfmaCfg<H>;
+    constexpr int QS = C::QS, U = C::U, G = C::G;
+    constexpr int KP = NB * H / 512 > 0 ? NB * H / 512 : 1;
+    constexpr int LDK = M::LDK;
+    static_assert(NB <= 8 && NB <= QS, "eight windows fill half the rows of a 16-row tile");
+    __shared__ __attribute__((aligned(16))) unsigned short hp[2][3][8][LDK];     // the three terms of h, two steps
+    __shared__ __attribute__((aligned(16))) unsigned short zrow[LDK];            // rows 8-15 of the fourth product
+    __shared__ __attribute__((aligned(16))) float part[24][16][16];              // [unit][column][row]
+    const GruArgs &a = ca.g;
+    const int T = a.T;
+    int group, member;
+    coop_who<G>(ca.groups, ca.xcd_map, group, member);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = tid & (QS - 1), u = tid / QS;
+    const int j = member * U + u;
+    const int n0 = group * NB;
+
+    // ---- this wave's three units: B operands (all three terms) of 4 K steps each
+    MfmaFrag bw[3][4][3];
+    // (the three units of a wave share their K part: its A fragments are read once per K step, not once per unit -- the
+    //  step's arithmetic is bound by LDS reads, 295 KB per member and step otherwise)
+    const int kpart = wave % M::KS, tile0 = 3 * (wave / M::KS);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int tile = tile0 + i;
+        const int col = tile * 16 + (lane & 15);
+        const long row = (long)((col / U) * H + member * U + (col % U)) * H;          // row of W_hh
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = (kpart * 4 + ks) * 32 + 8 * (lane >> 4);
+            const float4 v0 = *reinterpret_cast<const float4 *>(a.whh + row + k);
+            const float4 v1 = *reinterpret_cast<const float4 *>(a.whh + row + k + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            unsigned short t[8][3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split3(v[e], t[e]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bw[i][ks][pl].d[d] = (unsigned)t[2 * d][pl] | ((unsigned)t[2 * d + 1][pl] << 16);
+        }
+    }
+    const float bh0 = a.bhh[j], bh1 = a.bhh[H + j], bh2 = a.bhh[2 * H + j];
+
+    // ---- h0 -> planes of step 0 (windows >= NB: zeros), the zero row
+    for (int idx = tid; idx < 8 * H; idx += 512) {
+        const int s = idx / H, k = idx - s * H;
+        const int n = n0 + s;
+        const float v = (s < NB && n < a.N && a.h0 != nullptr) ? a.h0[(long)n * H + k] : 0.f;
+        unsigned short t[3];
+        split3(v, t);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { hp[0][pl][s][k] = t[pl]; hp[1][pl][s][k] = 0; }
+        if (s < NB && n < a.N && (k / U) == member) a.hall[((long)n * (T + 1)) * H + k] = v;
+    }
+    for (int k = tid; k < LDK; k += 512) zrow[k] = 0;
+    __syncthreads();
+
+    const int ns = n0 + q;
+    const bool mine = q < NB && ns < a.N;
+    float hprev = (mine && a.h0 != nullptr) ? a.h0[(long)ns * H + j] : 0.f;
+    float gin0 = 0.f, gin1 = 0.f, gin2 = 0.f;
+    if (mine) {
+        const float *gp = a.gi + (long)ns * T * 3 * H;
+        gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j];
+    }
+    // A operand addresses (bytes inside one step's planes): lane -> row lane % 16, K group lane / 16
+    const int arow = lane & 15, akg = lane >> 4;
+    const unsigned aoff0 = (unsigned)(((0 * 8 + (arow & 7)) * LDK + 8 * akg) * 2);
+    const unsigned aoff1 = (unsigned)(((1 * 8 + (arow & 7)) * LDK + 8 * akg) * 2);
+    const unsigned aoff2 = (unsigned)(((2 * 8 + (arow & 7)) * LDK + 8 * akg) * 2);
+    const bool upper = arow >= 8;
+    // where this lane's finished sums are: column c = gate * U + u -> tile c / 16, column c % 16 of the tile
+    int ptile[3], pcol[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { ptile[g] = (g * U + u) / 16; pcol[g] = (g * U + u) % 16; }
+    bool dead = false;
+#ifdef GRU_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const float gi0 = gin0, gi1 = gin1, gi2 = gin2;
+        if (mine && t + 1 < T) {
+            const float *gp = a.gi + ((long)ns * T + t + 1) * 3 * H;
+            gin0 = gp[j]; gin1 = gp[H + j]; gin2 = gp[2 * H + j];
+        }
+        const char *planes = reinterpret_cast<const char *>(&hp[cur][0][0][0]);
+        const char *pa1 = planes + (upper ? aoff1 : aoff0);                  // [h0 | h1]
+        const char *pa2 = planes + (upper ? aoff2 : aoff0);                  // [h0 | h2]
+        const char *pa3 = upper ? reinterpret_cast<const char *>(zrow) + 16 * akg : planes + aoff2;   // [h2 | 0]
+        f32x4_t acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kb = (kpart * 4 + ks) * 64;                                       // bytes: 32 bf16 per K step
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t *>(pa1 + kb);
+            const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t *>(pa2 + kb);
+            const bf16x8_t a3 = *reinterpret_cast<const bf16x8_t *>(pa3 + (upper ? 0 : kb));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {                                               // three independent accumulator chains
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, bw[i][ks][0]), acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, bw[i][ks][1]), acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8_t, bw[i][ks][2]), acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, __builtin_bit_cast(bf16x8_t, bw[i][ks][0]), acc[i], 0, 0, 0);
+            }
+        }
+        // lane: column lane % 16, rows 4 (lane / 16) .. + 3 of unit (tile, kpart)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<f32x4_t *>(&part[(tile0 + i) * M::KS + kpart][lane & 15][4 * (lane >> 4)]) = acc[i];
+        GRU_STAMP(0);
+        coop_lds_barrier();
+        if (q < NB) {
+            float gs[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float v = 0.f;
+#pragma unroll
+                for (int p = 0; p < M::KS; ++p) {
+                    v += part[ptile[g] * M::KS + p][pcol[g]][q];
+                    v += part[ptile[g] * M::KS + p][pcol[g]][q + 8];
+                }
+                gs[g] = v;
+            }
+            const float g0 = gs[0] + bh0, g1 = gs[1] + bh1, g2 = gs[2] + bh2;
+            const float r = sigmoidf_(gi0 + g0);
+            const float z = sigmoidf_(gi1 + g1);
+            const float c = tanhf(gi2 + r * g2);
+            float hv = (1.f - z) * c + z * hprev;
+            if (dead) hv = NAN;
+            hprev = hv;
+            COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + coop_fwd_slot<H, NB>(group, nxt, member, u, q));
+            if (!(ca.fault && group == 0 && member == 0 && t == 1))
+                __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine) {
+                const long row = (long)ns * T + t;
+                float *gsv = a.gates + row * 3 * H;
+                gsv[j] = r; gsv[H + j] = z; gsv[2 * H + j] = c;
+                a.hn[row * H + j] = g2;
+                a.out[row * H + j] = hv;
+                a.hall[((long)ns * (T + 1) + t + 1) * H + j] = hv;
+            }
+        }
+        GRU_STAMP(1);
+        if (t + 1 < T) {
+            COOP_GLOBAL gu64_t *slot[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i)
+                slot[i] = (COOP_GLOBAL gu64_t *)(ca.comm + ((long)group * 2 + nxt) * (NB * H) + tid + 512 * i);
+            gu64_t x[KP];
+            unsigned spins = dead ? (1u << 22) : 0u;
+            if (tid < NB * H) {
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
+                    if (ready) break;
+                    if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#ifdef GRU_STAMPS
+                ph[4] += spins;
+#endif
+                GRU_STAMP(2);
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    int gw, gk;
+                    coop_fwd_who<H, NB>(tid + 512 * i, gw, gk);
+                    unsigned short tt[3];
+                    split3(dead ? NAN : __uint_as_float((unsigned)x[i]), tt);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) hp[nxt][pl][gw][gk] = tt[pl];
+                }
+            }
+            coop_lds_barrier();
+            GRU_STAMP(3);
+        }
+    }
+#ifdef GRU_STAMPS
+    if (ca.stamps != nullptr && (tid == 0 || tid == 511))
+        for (int i = 0; i < 5; ++i) ca.stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i] = ph[i];
+#endif
+    if (a.hlast != nullptr && q < NB && n0 + q < a.N) a.hlast[(long)(n0 + q) * H + j] = hprev;
+}
+
 // Backward twin of gru_fwd_coop_kernel: member m keeps the SAME 3 U rows of W_hh (its U units x 3 gates) in
 // registers, now one COLUMN j' per thread (thread (j', half): 96 rows), forms its partial W_hh^T dGH for all H
 // columns and the members exchange the U-column pieces the others own.
@@ -548,8 +779,17 @@ static int gru_print_stamps(const char *what, const unsigned long long *stamps, 
 }
 #endif
 
+// the matrix-pipe form of the step: where a group has enough windows to fill half of a 16-row tile (CPC_GRU_NO_MFMA=1: A/B switch)
+template <int H> static bool use_mfma_fwd(int nb)
+{
+    static const bool off = getenv("CPC_GRU_NO_MFMA") != nullptr;
+    static const bool fits = coop_fits(gru_fwd_mfma_kernel<H, 8>, 1, 1);
+    return !off && H == 512 && nb == 8 && fits;
+}
+
 template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
+    if (use_mfma_fwd<H>(nb)) { hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 8>), grid, dim3(512), 0, st, ca); return; }
     if (nb == 1) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
     else if (nb == 2) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
     else if (nb == 4) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
@@ -679,7 +919,7 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
                 else launch_coop_fwd<512>(nb, grid, st, ca);
             }
 #ifdef GRU_STAMPS
-            CPC_TRY(gru_print_stamps("fwd: math | gates+publish | wait | lds+barrier", stamps, ca.groups * G, H, nb, T, st));
+            CPC_TRY(gru_print_stamps("fwd: math | (barrier+) gates+publish | wait | lds+barrier", stamps, ca.groups * G, H, nb, T, st));
 #endif
         } else {
             ProfScope prof(PROF_GRU_FWD, st);
