@@ -756,6 +756,195 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
 #endif
 }
 
+template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_mfma_kernel(GruCoopArgs ca)
+{
+    using C = CoopCfg<H>;
+    constexpr int U = C::U, G = C::G;
+    constexpr int K3 = 3 * U, LDK = K3 + 8;                                 // K = the member's 3U rows of W_hh, in steps of 32
+    static_assert(C::HALVES == 1 && K3 % 32 == 0 && H / 16 == 32, "H = 512: 32 column tiles, four per wave, all of K each");
+    static_assert(NB <= 8 && NB * U <= 512, "one elementwise thread per (window, unit)");
+    __shared__ __attribute__((aligned(16))) unsigned short dgp[3][8][LDK];  // the three bf16 terms of this member's dGH rows
+    __shared__ __attribute__((aligned(16))) unsigned short zrow[LDK];
+    __shared__ float part[2][8][H];                                          // [row half of the tile][window][column]
+    const GruArgs &a = ca.g;
+    const int T = a.T;
+    int group, member;
+    coop_who<G>(ca.groups, ca.xcd_map, group, member);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = group * NB;
+
+    // B operands: B[k = local row (gate * U + unit)][n = column jc] = W_hh[gate * H + member * U + unit][jc]; wave w: column
+    // tiles 4 w .. 4 w + 3, every K step (no K split: the tile's sums are complete in its accumulators)
+    MfmaFrag bw[4][K3 / 32][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int jcol = (wave * 4 + i) * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < K3 / 32; ++ks) {
+            unsigned short t[8][3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int lr = ks * 32 + 8 * (lane >> 4) + e;
+                split3(a.whh[(long)((lr / U) * H + member * U + (lr % U)) * H + jcol], t[e]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bw[i][ks][pl].d[d] = (unsigned)t[2 * d][pl] | ((unsigned)t[2 * d + 1][pl] << 16);
+        }
+    }
+    for (int idx = tid; idx < 3 * 8 * LDK; idx += 512) (&dgp[0][0][0])[idx] = 0;
+    for (int kk = tid; kk < LDK; kk += 512) zrow[kk] = 0;
+    __syncthreads();
+    const int arow = lane & 15, akg = lane >> 4;
+    const bool upper = arow >= 8;
+    const char *const planes = reinterpret_cast<const char *>(&dgp[0][0][0]);
+    const char *const pa1 = planes + (((upper ? 1 : 0) * 8 + (arow & 7)) * LDK + 8 * akg) * 2;      // [d0 | d1]
+    const char *const pa2 = planes + (((upper ? 2 : 0) * 8 + (arow & 7)) * LDK + 8 * akg) * 2;      // [d0 | d2]
+    const char *const pa3 = upper ? reinterpret_cast<const char *>(zrow) + 16 * akg : planes + ((2 * 8 + arow) * LDK + 8 * akg) * 2;   // [d2 | 0]
+    // elementwise role: thread (es, eu) for tid < NB*U
+    const int es = tid / U, eu = tid - es * U;
+    const int ej = member * U + eu;
+    const int en = n0 + es;
+    const bool ew = tid < NB * U;
+    const bool emine = ew && en < a.N;
+    float carry = 0.f;
+    if (emine) {                                               // zero junk row T of dGH
+        float *zr = a.dgh + ((long)en * (T + 1) + T) * 3 * H;
+        zr[ej] = 0.f; zr[H + ej] = 0.f; zr[2 * H + ej] = 0.f;
+    }
+    // the saved activations of step t-1 are requested while step t runs (same reason as in the forward kernel)
+    float p_dout = 0.f, p_r = 0.f, p_z = 0.f, p_c = 0.f, p_hn = 0.f, p_hp = 0.f;
+    auto request = [&](int t) {
+        const long row = (long)en * T + t;
+        const float *gs = a.gates + row * 3 * H;
+        p_dout = a.dout[row * H + ej];
+        p_r = gs[ej]; p_z = gs[H + ej]; p_c = gs[2 * H + ej];
+        p_hn = a.hn[row * H + ej];
+        p_hp = a.hall[((long)en * (T + 1) + t) * H + ej];
+    };
+    if (emine) request(T - 1);
+    bool dead = false;
+#ifdef GRU_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
+        float keep = 0.f;
+        if (ew) {
+            float dpr = 0.f, dpz = 0.f, dhn = 0.f;
+            if (emine) {
+                const long row = (long)en * T + t;
+                const float dh = p_dout + carry;
+                const float r = p_r, z = p_z, c = p_c;
+                const float hnv = p_hn;
+                const float hp_ = p_hp;
+                const float dc = dh * (1.f - z);
+                const float dz = dh * (hp_ - c);
+                const float dpn = dc * (1.f - c * c);
+                dpr = dpn * hnv * r * (1.f - r);
+                dpz = dz * z * (1.f - z);
+                dhn = dpn * r;
+                keep = dh * z;
+                float *gi = a.dgi + row * 3 * H;
+                gi[ej] = dpr; gi[H + ej] = dpz; gi[2 * H + ej] = dpn;
+                float *gh = a.dgh + ((long)en * (T + 1) + t) * 3 * H;
+                gh[ej] = dpr; gh[H + ej] = dpz; gh[2 * H + ej] = dhn;
+            }
+            {
+                unsigned short t0[3], t1[3], t2[3];
+                split3(dpr, t0); split3(dpz, t1); split3(dhn, t2);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { dgp[pl][es][eu] = t0[pl]; dgp[pl][es][U + eu] = t1[pl]; dgp[pl][es][2 * U + eu] = t2[pl]; }
+            }
+            // behind the stores: a request in front of them made the compiler wait for it (vmcnt) where a store reused a register
+            if (emine && t > 0) request(t - 1);
+        }
+        coop_lds_barrier();
+        GRU_STAMP(0);
+        // out[window][column] = sum over the member's rows: four products per K step (see gru_fwd_mfma_kernel), four column
+        // tiles per wave sharing the A fragments
+        {
+            f32x4_t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < K3 / 32; ++ks) {
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t *>(pa1 + ks * 64);
+                const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t *>(pa2 + ks * 64);
+                const bf16x8_t a3 = *reinterpret_cast<const bf16x8_t *>(pa3 + (upper ? 0 : ks * 64));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, bw[i][ks][0]), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, bw[i][ks][1]), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8_t, bw[i][ks][2]), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, __builtin_bit_cast(bf16x8_t, bw[i][ks][0]), acc[i], 0, 0, 0);
+                }
+            }
+            // lane: column lane % 16 of the tile, rows 4 (lane / 16) .. + 3: rows 0-7 = the windows, rows 8-15 = the second half
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = (wave * 4 + i) * 16 + (lane & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[lane >> 5][4 * ((lane >> 4) & 1) + e][col] = acc[i][e];
+            }
+        }
+        coop_lds_barrier();
+        GRU_STAMP(1);
+        auto column = [&](int s, int k) { return part[0][s][k] + part[1][s][k]; };
+        // publish the columns other members own (this member's own columns stay in LDS)
+        if (t > 0) {
+            for (int idx = tid; idx < NB * H; idx += 512) {
+                const int s = idx / H, k = idx - s * H;
+                if (k / U == member) continue;
+                const float v = column(s, k);
+                COOP_GLOBAL gu64_t *slot =
+                    (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * G + member) * NB + s) * H + k);
+                __hip_atomic_store(slot, ((gu64_t)epoch << 32) | (gu64_t)__float_as_uint(dead ? NAN : v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            GRU_STAMP(2);
+            if (ew) {
+                float sum = keep + column(es, ej);
+                // the partners' pieces are polled together: one L2 round trip per attempt, not G - 1 in a row
+                COOP_GLOBAL gu64_t *slot[G - 1];
+#pragma unroll
+                for (int d = 1; d < G; ++d) {
+                    const int src = (member + d) & (G - 1);
+                    slot[d - 1] = (COOP_GLOBAL gu64_t *)(ca.comm + ((((long)group * 2 + par) * G + src) * NB + es) * H + ej);
+                }
+                gu64_t x[G - 1];
+                unsigned spins = dead ? (1u << 22) : 0u;
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int d = 0; d < G - 1; ++d) x[d] = __hip_atomic_load(slot[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int d = 0; d < G - 1; ++d) ready = ready && (unsigned)(x[d] >> 32) == epoch;
+                    if (ready) break;
+                    if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_BWD_WAIT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int d = 0; d < G - 1; ++d) sum += __uint_as_float((unsigned)x[d]);
+                carry = dead ? NAN : sum;
+#ifdef GRU_STAMPS
+                ph[4] += spins;
+#endif
+            }
+            GRU_STAMP(3);
+            // no barrier here: dgs is rewritten before the next step's first barrier, part after it, and every thread has
+            // finished reading both when it gets there; `dead` stays with the thread that timed out (its carry is poisoned)
+        }
+    }
+#ifdef GRU_STAMPS
+    if (ca.stamps != nullptr && (tid == 0 || tid == 511))
+        for (int i = 0; i < 5; ++i) ca.stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i] = ph[i];
+#endif
+}
+
 #ifdef GRU_STAMPS
 static int gru_print_stamps(const char *what, const unsigned long long *stamps, int nblk, int H, int nb, int T, hipStream_t st)
 {
@@ -795,8 +984,20 @@ template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, 
     else if (nb == 4) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
     else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
 }
+template <int H> static bool use_mfma_bwd(int nb)
+{
+    if constexpr (H == 512) {
+        static const bool off = getenv("CPC_GRU_NO_MFMA") != nullptr;
+        static const bool fits = coop_fits(gru_bwd_mfma_kernel<512, 8>, 1, 1);
+        return !off && nb == 8 && fits;
+    }
+    return false;
+}
+
 template <int H> static void launch_coop_bwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
+    if constexpr (H == 512)
+        if (use_mfma_bwd<H>(nb)) { hipLaunchKernelGGL((gru_bwd_mfma_kernel<512, 8>), grid, dim3(512), 0, st, ca); return; }
     if (nb == 1) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
     else if (nb == 2) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
     else if (nb == 4) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
