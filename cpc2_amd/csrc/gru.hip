@@ -761,7 +761,8 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_mfma_ker
     using C = CoopCfg<H>;
     constexpr int U = C::U, G = C::G;
     constexpr int K3 = 3 * U, LDK = K3 + 8;                                 // K = the member's 3U rows of W_hh, in steps of 32
-    static_assert(C::HALVES == 1 && K3 % 32 == 0 && H / 16 == 32, "H = 512: 32 column tiles, four per wave, all of K each");
+    constexpr int TW = H / 16 / 8;                                          // column tiles per wave: 4 (H = 512), 2 (H = 256)
+    static_assert(K3 % 32 == 0 && TW * 8 * 16 == H && TW * (K3 / 32) == 12, "twelve (tile, K step) operands per wave, all of K each");
     static_assert(NB <= 8 && NB * U <= 512, "one elementwise thread per (window, unit)");
     __shared__ __attribute__((aligned(16))) unsigned short dgp[3][8][LDK];  // the three bf16 terms of this member's dGH rows
     __shared__ __attribute__((aligned(16))) unsigned short zrow[LDK];
@@ -775,11 +776,11 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_mfma_ker
     const int n0 = group * NB;
 
     // B operands: B[k = local row (gate * U + unit)][n = column jc] = W_hh[gate * H + member * U + unit][jc]; wave w: column
-    // tiles 4 w .. 4 w + 3, every K step (no K split: the tile's sums are complete in its accumulators)
-    MfmaFrag bw[4][K3 / 32][3];
+    // tiles TW w .. TW w + TW - 1, every K step (no K split: the tile's sums are complete in its accumulators)
+    MfmaFrag bw[TW][K3 / 32][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int jcol = (wave * 4 + i) * 16 + (lane & 15);
+    for (int i = 0; i < TW; ++i) {
+        const int jcol = (wave * TW + i) * 16 + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < K3 / 32; ++ks) {
             unsigned short t[8][3];
@@ -867,16 +868,16 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_mfma_ker
         // out[window][column] = sum over the member's rows: four products per K step (see gru_fwd_mfma_kernel), four column
         // tiles per wave sharing the A fragments
         {
-            f32x4_t acc[4];
+            f32x4_t acc[TW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < TW; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < K3 / 32; ++ks) {
                 const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t *>(pa1 + ks * 64);
                 const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t *>(pa2 + ks * 64);
                 const bf16x8_t a3 = *reinterpret_cast<const bf16x8_t *>(pa3 + (upper ? 0 : ks * 64));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < TW; ++i) {
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, bw[i][ks][0]), acc[i], 0, 0, 0);
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, bw[i][ks][1]), acc[i], 0, 0, 0);
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8_t, bw[i][ks][2]), acc[i], 0, 0, 0);
@@ -885,8 +886,8 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_mfma_ker
             }
             // lane: column lane % 16 of the tile, rows 4 (lane / 16) .. + 3: rows 0-7 = the windows, rows 8-15 = the second half
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = (wave * 4 + i) * 16 + (lane & 15);
+            for (int i = 0; i < TW; ++i) {
+                const int col = (wave * TW + i) * 16 + (lane & 15);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) part[lane >> 5][4 * ((lane >> 4) & 1) + e][col] = acc[i][e];
             }
@@ -968,40 +969,34 @@ static int gru_print_stamps(const char *what, const unsigned long long *stamps, 
 }
 #endif
 
-// the matrix-pipe form of the step: where a group has enough windows to fill half of a 16-row tile (CPC_GRU_NO_MFMA=1: A/B switch)
-template <int H> static bool use_mfma_fwd(int nb)
+// The matrix-pipe form of the step.  Measured (profiles/r03_gru_stamps.txt): H = 512 with 8 windows per group -- forward 1.47 ->
+// 1.23 ms, backward 2.03 -> 1.37 ms per CPC-large step; H = 256 with 2 windows per group (CPC-small: a 16-row tile is 3/4
+// padding) -- forward 0.28 -> 0.38 ms (the K parts' partial tiles cost a barrier and LDS round trip more than the FMAs they
+// replace), backward 0.30 -> 0.275 ms (no K split there).  CPC_GRU_NO_MFMA=1 / CPC_GRU_MFMA_ALL=1: never / always.
+static bool mfma_wanted(int H, int nb, bool backward)
 {
-    static const bool off = getenv("CPC_GRU_NO_MFMA") != nullptr;
-    static const bool fits = coop_fits(gru_fwd_mfma_kernel<H, 8>, 1, 1);
-    return !off && H == 512 && nb == 8 && fits;
+    static const bool off = getenv("CPC_GRU_NO_MFMA") != nullptr, all = getenv("CPC_GRU_MFMA_ALL") != nullptr;
+    if (off) return false;
+    return all || (H == 512 && nb == 8) || (backward && H == 256 && nb >= 2);
 }
+template <int H, int NB> static bool mfma_fits_fwd() { static const bool f = coop_fits(gru_fwd_mfma_kernel<H, NB>, 1, 1); return f; }
+template <int H, int NB> static bool mfma_fits_bwd() { static const bool f = coop_fits(gru_bwd_mfma_kernel<H, NB>, 1, 1); return f; }
 
 template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
-    if (use_mfma_fwd<H>(nb)) { hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 8>), grid, dim3(512), 0, st, ca); return; }
-    if (nb == 1) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
-    else if (nb == 2) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
-    else if (nb == 4) hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
-    else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
+    const bool mm = mfma_wanted(H, nb, false);
+    if (nb == 1) { if (mm && mfma_fits_fwd<H, 1>()) hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 1>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca); }
+    else if (nb == 2) { if (mm && mfma_fits_fwd<H, 2>()) hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 2>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca); }
+    else if (nb == 4) { if (mm && mfma_fits_fwd<H, 4>()) hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 4>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca); }
+    else { if (mm && mfma_fits_fwd<H, 8>()) hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 8>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca); }
 }
-template <int H> static bool use_mfma_bwd(int nb)
-{
-    if constexpr (H == 512) {
-        static const bool off = getenv("CPC_GRU_NO_MFMA") != nullptr;
-        static const bool fits = coop_fits(gru_bwd_mfma_kernel<512, 8>, 1, 1);
-        return !off && nb == 8 && fits;
-    }
-    return false;
-}
-
 template <int H> static void launch_coop_bwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
-    if constexpr (H == 512)
-        if (use_mfma_bwd<H>(nb)) { hipLaunchKernelGGL((gru_bwd_mfma_kernel<512, 8>), grid, dim3(512), 0, st, ca); return; }
-    if (nb == 1) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
-    else if (nb == 2) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
-    else if (nb == 4) hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
-    else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca);
+    const bool mm = mfma_wanted(H, nb, true);
+    if (nb == 1) { if (mm && mfma_fits_bwd<H, 1>()) hipLaunchKernelGGL((gru_bwd_mfma_kernel<H, 1>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca); }
+    else if (nb == 2) { if (mm && mfma_fits_bwd<H, 2>()) hipLaunchKernelGGL((gru_bwd_mfma_kernel<H, 2>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca); }
+    else if (nb == 4) { if (mm && mfma_fits_bwd<H, 4>()) hipLaunchKernelGGL((gru_bwd_mfma_kernel<H, 4>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca); }
+    else { if (mm && mfma_fits_bwd<H, 8>()) hipLaunchKernelGGL((gru_bwd_mfma_kernel<H, 8>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 8>), grid, dim3(512), 0, st, ca); }
 }
 
 // does the cooperative kernel fit a CU, and the grid the chip?  (cached per instance: the occupancy query is not free)

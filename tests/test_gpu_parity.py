@@ -414,6 +414,45 @@ def test_gru_vs_oracle_fp64(hid, layers, n, t_len):
         assert_close(p.grad, p64["gAR." + name].grad, 1e-4, f"gru grad {name}")
 
 
+_GRU_FORMS_SCRIPT = """
+import sys, torch
+sys.path.insert(0, {root!r})
+import cpc2_amd
+from oracle import synth
+hid, n, t_len = {hid}, {n}, {t_len}
+params = synth.gru_params(hid, hid, 1, 9)
+ar = cpc2_amd.CPCAR(hid, hid, False, 1)
+ar.load_state_dict({{k[len("gAR."):]: v for k, v in params.items()}})
+ar = ar.to("cuda:0")
+x = synth.features((n, t_len, hid), 10, relu=True).to("cuda:0").requires_grad_(True)
+out = ar(x)
+(out * synth.features((n, t_len, hid), 11).to("cuda:0")).sum().backward()
+torch.save({{"out": out.detach().cpu(), "dx": x.grad.cpu(), **{{k: p.grad.cpu() for k, p in ar.named_parameters()}}}}, {dst!r})
+"""
+
+
+@pytest.mark.parametrize("hid,n,t_len", [(256, 128, 9), (512, 24, 7)])
+def test_gru_matrix_pipe_and_valu_forms_agree(tmp_path, hid, n, t_len):
+    """Both forms of the cooperative GRU step (FMAs on the member's register-resident weights; the exact bf16 split on the
+    matrix pipe) at window counts where only ONE of them is the default: CPC_GRU_MFMA_ALL / CPC_GRU_NO_MFMA select them (read
+    once per process, hence the child processes), and they agree to fp32 rounding."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form, env in (("mfma", {"CPC_GRU_MFMA_ALL": "1"}), ("valu", {"CPC_GRU_NO_MFMA": "1"})):
+        dst = str(tmp_path / f"{form}.pt")
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        e.pop("CPC_GRU_NO_MFMA" if form == "mfma" else "CPC_GRU_MFMA_ALL", None)
+        r = subprocess.run([sys.executable, "-c", _GRU_FORMS_SCRIPT.format(root=root, hid=hid, n=n, t_len=t_len, dst=dst)], env=e,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = torch.load(dst)
+    for key in res["valu"]:
+        assert_close(res["mfma"][key], res["valu"][key].double(), 2e-5, f"{key} (matrix pipe vs FMA form)")
+    assert not torch.equal(res["mfma"]["out"], res["valu"]["out"]), "the switch selected the same kernels twice"
+
+
 # ----------------------------------------------------------------------------- LSTM / RNN (model.py:171-176)
 _RECURRENT = {"LSTM": (synth.lstm_params, O.lstm_forward), "RNN": (synth.rnn_params, O.rnn_forward)}
 
