@@ -158,6 +158,8 @@ size_t gemm_nt_planes_scratch_bytes(long M, int N, int K, long out_rows);   // w
 int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
                    size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st);
 
+int gemm_mode();        // gemm_f32.hip: 0 exact bf16 split (six products), 1 f32 MFMA, 2 three products (opt-in, cpc_gemm_set_mode)
+
 // infonce.hip: start what a deferred criterion backward (cpc_infonce_backward_deferred) left to do, on the library's side
 // stream, ordered behind what `st` holds now; no-op when nothing is pending.  Called by the context networks' backward entry
 // points right behind their first kernel.

@@ -808,13 +808,14 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
 int gemm_set_mode(int mode)
 {
     const int prev = g_gemm_mode;
-    if (mode == 0 || mode == 1) g_gemm_mode = mode;
+    if (mode == 0 || mode == 1 || mode == 2) g_gemm_mode = mode;
     return prev;
 }
 
 }  // namespace cpc
 
 // ------------------------------------------------------------------------------------------------
+namespace cpc { int gemm_mode() { return g_gemm_mode; } }
 extern "C" int cpc_gemm_set_mode(int mode) { return cpc::gemm_set_mode(mode); }
 
 extern "C" int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,

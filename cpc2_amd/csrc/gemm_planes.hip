@@ -125,13 +125,17 @@ template <int Q> __device__ __forceinline__ void mma2(f32x16 &c0, f32x16 &c1, co
     mma1<Q>(c0, a, b[0]);
     mma1<Q>(c1, a, b[1]);
 }
-__device__ __forceinline__ void mma6(f32x16 &c0, f32x16 &c1, const frag_t (&a)[3], const frag_t (&b)[2][3], bool skip)
+// TERMS = 6: the exact product.  TERMS = 3 (cpc_gemm_set_mode(2), opt-in): a0 b0 + a0 b1 + a1 b0 only -- 16 bits of product
+// mantissa instead of 24 (TF32, what the reference's convolutions get on its own GPUs by default, keeps 10); the planes are moved
+// as before, the three small products are not multiplied.
+template <int TERMS> __device__ __forceinline__ void mma6(f32x16 &c0, f32x16 &c1, const frag_t (&a)[3], const frag_t (&b)[2][3], bool skip)
 {
     if (skip) {
         asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]));
         return;
     }
-    mma2<0>(c0, c1, a, b); mma2<1>(c0, c1, a, b); mma2<2>(c0, c1, a, b);
+    if constexpr (TERMS == 6) { mma2<0>(c0, c1, a, b); mma2<1>(c0, c1, a, b); mma2<2>(c0, c1, a, b); }
+    else asm volatile("" ::"v"(a[2]), "v"(b[0][2]), "v"(b[1][2]));
     mma2<3>(c0, c1, a, b); mma2<4>(c0, c1, a, b); mma2<5>(c0, c1, a, b);
 }
 
@@ -147,7 +151,7 @@ template <bool TN> __device__ __forceinline__ void read_b(frag_t (&b)[2][3], uns
     b[1][0] = lds_frag<TN, PT_PIECE>(fb); b[1][1] = lds_frag<TN, 9 * PT_PIECE>(fb);    b[1][2] = lds_frag<TN, 17 * PT_PIECE>(fb);
 }
 
-template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
+template <int DBG, bool TN, int TERMS = 6> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const unsigned long long rentry = (p.dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -272,17 +276,17 @@ template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_plane
         const unsigned nslot = slot == (PT_RING - 1) * PT_STAGE ? 0 : slot + PT_STAGE;
         read_a<TN, 1>(ay, fa);
         __builtin_amdgcn_sched_barrier(0);
-        mma6(acc[0][0], acc[0][1], ax, bc, nomma);
+        mma6<TERMS>(acc[0][0], acc[0][1], ax, bc, nomma);
         __builtin_amdgcn_sched_barrier(0);
         lds_wait3(ay);
         read_a<TN, 2>(ax, fa);
         __builtin_amdgcn_sched_barrier(0);
-        mma6(acc[1][0], acc[1][1], ay, bc, nomma);
+        mma6<TERMS>(acc[1][0], acc[1][1], ay, bc, nomma);
         __builtin_amdgcn_sched_barrier(0);
         lds_wait3(ax);
         read_a<TN, 3>(ay, fa);
         __builtin_amdgcn_sched_barrier(0);
-        mma6(acc[2][0], acc[2][1], ax, bc, nomma);
+        mma6<TERMS>(acc[2][0], acc[2][1], ax, bc, nomma);
         __builtin_amdgcn_sched_barrier(0);
         lds_wait3(ay);                          // every LDS read of stage t by this wave is done
         // (no branch may enclose an asm LDS read: hipcc would copy its destination registers at the join, before the wait)
@@ -295,11 +299,11 @@ template <int DBG, bool TN> __global__ __launch_bounds__(512, 2) void gemm_plane
         const Src q = stage_src(req ? t + 3 : t, slot);
         const unsigned fbn = fb0 + nslot, fan = fa0 + nslot;
 #define PT_SB __builtin_amdgcn_sched_barrier(0)
-        if (!nomma) { mma2<0>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        if (!nomma && TERMS == 6) { mma2<0>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
         bn[0][0] = lds_frag<TN, 0>(fbn); bn[0][1] = lds_frag<TN, 8 * PT_PIECE>(fbn); bn[0][2] = lds_frag<TN, 16 * PT_PIECE>(fbn); PT_SB;
-        if (!nomma) { mma2<1>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        if (!nomma && TERMS == 6) { mma2<1>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
         bn[1][0] = lds_frag<TN, PT_PIECE>(fbn); bn[1][1] = lds_frag<TN, 9 * PT_PIECE>(fbn); bn[1][2] = lds_frag<TN, 17 * PT_PIECE>(fbn); PT_SB;
-        if (!nomma) { mma2<2>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+        if (!nomma && TERMS == 6) { mma2<2>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
         read_a<TN, 0>(ax, fan); PT_SB;
         if (req) { issue1(q, 0); issue1(q, 1); } PT_SB;
         if (!nomma) { mma2<3>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
@@ -464,6 +468,8 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
         CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<2, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
         attr_set = true;
     }
     PlanesNTArgs a{};
@@ -498,6 +504,7 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     ProfScope prof(PROF_PLANES_NT, st);
     if ((a.dbg & 3) == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     else if ((a.dbg & 3) == 2) hipLaunchKernelGGL((gemm_planes_kernel<2, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
+    else if (gemm_mode() == 2) hipLaunchKernelGGL((gemm_planes_kernel<0, false, 3>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     else hipLaunchKernelGGL((gemm_planes_kernel<0, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");
     if (splits > 1) {
@@ -603,6 +610,8 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     if (!attr_set) {
         CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, true, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
         attr_set = true;
     }
     PlanesNTArgs a{};
@@ -616,8 +625,12 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     a.xcd_remap = (!no_remap && S % 8 == 0 && (M / PT_BM) * (N / PT_BN) > 1) ? 1 : 0;
     {
         ProfScope prof(PROF_PLANES_TN, st);
-        hipLaunchKernelGGL((gemm_planes_kernel<0, true>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
-                           st, a);
+        if (gemm_mode() == 2)
+            hipLaunchKernelGGL((gemm_planes_kernel<0, true, 3>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
+                               st, a);
+        else
+            hipLaunchKernelGGL((gemm_planes_kernel<0, true>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
+                               st, a);
     }
     CPC_CHECK_LAUNCH("gemm_planes_kernel (tn)");
     const long total = (long)M * N;

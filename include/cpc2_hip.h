@@ -69,7 +69,10 @@ int cpc_prof_read(const char *name, double *total_ms, long *count);
  * f32 in, f32 out, f32 accumulation.  Mode 0 (default) multiplies on the bf16 matrix pipe after an
  * exact three-term bf16 split of every operand (six partial products, error <= that of the f32
  * MFMA path, tests/test_gpu_parity.py::test_gemm_split_accuracy); mode 1 uses the f32 MFMA
- * (v_mfma_f32_32x32x2_f32).  cpc_gemm_set_mode returns the previous mode; other values only query.
+ * (v_mfma_f32_32x32x2_f32); mode 2 (opt-in, never the default) makes the encoder's plane-fed convolution products at
+ * hidden 256 / 512 multiply only a0 b0 + a0 b1 + a1 b0 of the split (16 bits of product mantissa, f32 accumulation: half the
+ * matrix work; TF32 -- what cuDNN gives the reference's convolutions on its own GPUs by default -- keeps 10 bits), everything
+ * else as mode 0.  cpc_gemm_set_mode returns the previous mode; other values only query.
  * cpc_gemm_nt splits K over workgroups when the output has few tiles and then adds the partial sums with
  * fp32 atomics (C is zeroed first); the module entry points below lend scratch for an ordered reduction instead.
  * ------------------------------------------------------------------------------------------ */
