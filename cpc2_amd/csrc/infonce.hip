@@ -1226,9 +1226,10 @@ static int nce_side(NceSide **out)
     std::lock_guard<std::mutex> lk(mu);
     NceSide &sd = sides[dev];
     if (sd.stream == nullptr) {
-        int lo = 0, hi = 0;                       // lowest priority: what runs beside the caller's stream must not be served first
-        CPC_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        CPC_CHECK_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, lo));
+        // DEFAULT priority, deliberately.  A lowest-priority stream looked right for work that runs beside the caller's, and costs
+        // nothing in a single-process run -- but in a process that has also initialised RCCL every kernel of the step ran ~45 %
+        // slower (7.7 against 5.3 ms per step with one rank; found by bisection, profiles/r03_dist_priority_bisect.txt).
+        CPC_CHECK_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.mid, hipEventDisableTiming));
