@@ -40,3 +40,17 @@ def test_no_packed_f32_valu_in_device_code(tmp_path):
         kernels += asm.count("_kernel")
     assert fmas > 1000 and kernels > 50, (fmas, kernels)        # (the disassembly did see the kernels)
     assert packed == 0, f"{packed} packed-f32 VALU instructions in the device code: build.py's DEVICE_FLAGS were not applied"
+
+
+def test_no_library_stream_is_created_with_a_priority():
+    """A lowest-priority side stream cost nothing in a single-process run and ~45 % of every kernel once the process had
+    initialised RCCL (profiles/r03_dist_priority_bisect.txt): the library's streams are created with the default priority."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpc2_amd", "csrc")
+    hits = []
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            for no, line in enumerate(open(os.path.join(root, name)), 1):
+                code = line.split("//")[0]
+                if "hipStreamCreateWithPriority" in code:
+                    hits.append(f"{name}:{no}")
+    assert not hits, hits
