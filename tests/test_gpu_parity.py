@@ -395,7 +395,8 @@ def test_gru_reverse_and_keep_hidden(golden):
 # window counts chosen to reach every windows-per-group variant of the cooperative kernels (H = 256: 64 groups of 4 CUs,
 # H = 512: 16 groups of 16 CUs) and a ragged last group
 @pytest.mark.parametrize("hid,layers,n,t_len", [(256, 1, 5, 128), (512, 2, 3, 40), (512, 1, 100, 12), (512, 1, 40, 10),
-                                                (512, 1, 20, 9), (256, 1, 300, 6), (256, 2, 130, 7), (512, 2, 128, 21)])
+                                                (512, 1, 20, 9), (256, 1, 300, 6), (256, 2, 130, 7), (512, 2, 128, 21),
+                                                (512, 1, 128, 1), (256, 1, 128, 2), (512, 1, 65, 3)])       # (sequence ends: no hand-off, one)
 def test_gru_vs_oracle_fp64(hid, layers, n, t_len):
     params = synth.gru_params(hid, hid, layers, 9)
     ar = load_ar(hid, hid, layers, params)
