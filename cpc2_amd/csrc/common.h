@@ -140,8 +140,23 @@ struct PlanesOperand {
 int split_planes(const float *x, long ld, long rows, int cols, unsigned short *planes, long plane, int sshift, long rts,
                  hipStream_t st);
 bool gemm_nt_planes_ok(long M, int N, int K);
+// ChannelNorm + ReLU + the three-term split fused into the product's epilogue (N == 256: a tile holds whole rows of the output,
+// no K split): C receives xhat = (y - mean) * rstd instead of y, `rstd` the per-row statistic, and relu(gamma * xhat + beta)
+// leaves as the NEXT layer's input planes (row of (sample n, frame t) = n * rows_next + halo + t; other rows are not written).
+struct PlanesNormOut {
+    const float *gamma, *beta;
+    float eps;
+    float *rstd;                 // [rows of C]
+    unsigned short *p;           // planes of the next layer's input (layout: PlanesOperand)
+    long plane;
+    int sshift;
+    long rts;
+    long rows_next;
+    int halo;
+};
+bool gemm_nt_planes_norm_ok(long M, int N, int K);
 int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
-                   const RowMap &map, hipStream_t st);
+                   const RowMap &map, hipStream_t st, const PlanesNormOut *norm = nullptr);
 // weight-gradient form: C[i][j] = sum_{r < R} X(r, i) * Y(r, j); column x of an operand is channel x % C of tap tap0 + x / C,
 // i.e. element x % C of signal row r * s + tap.  Rows R .. round_up(R, 32) - 1 of A must be ZERO and those of B finite.
 struct PlanesTNOperand {

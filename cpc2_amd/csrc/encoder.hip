@@ -672,6 +672,23 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
     }
 }
 
+// Rows of a layer's input planes that no output frame lands in (a sample's halo rows, the slack behind the last sample): zeros.
+// (norm_fwd_pl_kernel writes them itself; the product's fused epilogue -- gemm_nt_planes with a PlanesNormOut -- writes frames only.)
+__global__ void zero_plane_rows_kernel(PlaneOut o, long total_rows, int N, long rows_next, int halo, int lout, int chunks)
+{
+    const long r = (long)blockIdx.x * blockDim.y + threadIdx.y;          // signal row; threadIdx.x: (plane, chunk) pairs
+    if (r >= total_rows) return;
+    const long n = r / rows_next;
+    const int t = (int)(r - n * rows_next) - halo;
+    if (n < N && t >= 0 && t < lout) return;
+    const long smask = (1L << o.sshift) - 1;
+    for (int i = threadIdx.x; i < 3 * chunks * 2; i += blockDim.x) {
+        const int pl = i / (chunks * 2), rem = i - pl * chunks * 2, c = rem >> 1, half = rem & 1;
+        const long chunk = (((long)c << o.sshift) + (r & smask)) * o.rts + (r >> o.sshift);
+        *reinterpret_cast<uint4 *>(o.p + pl * o.plane + chunk * 16 + half * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // ChannelNorm + ReLU of layers 1..3 -> xhat (f32, in place) and the next layer's input as planes; tiles of 16 rows of Y
 template <int H> __global__ __launch_bounds__(256) void norm_fwd_pl_kernel(NormArgs a, PlaneOut o, long n_tiles)
 {
@@ -1110,6 +1127,18 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
             RowMap out{};
             out.enabled = 1; out.rv = e.L[i + 1]; out.out_stride = 1; out.out_off = 0; out.l_max = e.Rv[i]; out.rows_out = e.Rv[i];
             out.splitk_scratch = e.tn; out.splitk_bytes = e.tn_bytes;
+            if (i < 4 && gemm_nt_planes_norm_ok((long)N * e.L[i + 1], H, k * H)) {
+                // ChannelNorm + ReLU + split in the product's epilogue (hidden 256, products that do not split K: conv1, conv2 at the
+                // training shapes): the tile holds whole rows, so y never goes to memory and back
+                const PlaneOut o{e.Yp[i], e.Yplane[i], log2i(kConv[i + 1].s), e.Yrts[i]};
+                const PlanesNormOut nf{prm[4 * i + 2], prm[4 * i + 3], eps, e.rstd[i], o.p, o.plane, o.sshift, o.rts, (long)e.R[i], kConv[i + 1].p};
+                const long rows = (long)kConv[i + 1].s * e.Yrts[i];
+                hipLaunchKernelGGL(zero_plane_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(64, 4), 0, st, o, rows, N, (long)e.R[i],
+                                   kConv[i + 1].p, e.L[i + 1], H / 16);
+                CPC_CHECK_LAUNCH("zero_plane_rows_kernel");
+                CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st, &nf));
+                continue;
+            }
             CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st));
         } else {
             RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk

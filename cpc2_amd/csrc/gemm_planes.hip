@@ -26,6 +26,7 @@
 // All LDS traffic is issued from inline asm: hipcc drains vmcnt to 0 before any LDS read it can see behind an LDS-DMA.
 #include "common.h"
 #include "ldsdma.h"
+#include "rowcfg.h"
 
 #include <algorithm>
 
@@ -65,6 +66,7 @@ struct PlanesNTArgs {
     int kchunk;                                   // K range per blockIdx.y (multiple of 32)
     float *slabs;                                 // K split: partial product of blockIdx.y -> slabs + blockIdx.y * slab_rows * N
     long slab_rows;                               // output rows (after the row map)
+    PlanesNormOut norm;                           // NORM kernels only (N == 256, no K split)
     int dbg;                                      // probes: 1 no loads after the prologue, 2 no MFMAs, 8 clock stamps
     unsigned long long *stamps;                   // dbg & 8: [workgroup][8] = memtime, memrealtime at loop start and end, ...
 };
@@ -151,7 +153,24 @@ template <bool TN> __device__ __forceinline__ void read_b(frag_t (&b)[2][3], uns
     b[1][0] = lds_frag<TN, PT_PIECE>(fb); b[1][1] = lds_frag<TN, 9 * PT_PIECE>(fb);    b[1][2] = lds_frag<TN, 17 * PT_PIECE>(fb);
 }
 
-template <int DBG, bool TN, int TERMS = 6> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
+// four f32 -> their three bf16 terms, packed as 4 bf16 per term (round to nearest; exact to 2^-27, see gemm_f32.hip)
+__device__ __forceinline__ void split4_terms(const float (&a)[4], uint2 (&w)[3])
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    float lo0 = a[0], hi0 = a[1], lo1 = a[2], hi1 = a[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        f2 p0 = {lo0, hi0}, p1 = {lo1, hi1};
+        const uint32_t k0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, b2));
+        const uint32_t k1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, b2));
+        w[t] = make_uint2(k0, k1);
+        lo0 -= __uint_as_float(k0 << 16); hi0 -= __uint_as_float(k0 & 0xffff0000u);
+        lo1 -= __uint_as_float(k1 << 16); hi1 -= __uint_as_float(k1 & 0xffff0000u);
+    }
+}
+
+template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const unsigned long long rentry = (p.dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -353,6 +372,64 @@ template <int DBG, bool TN, int TERMS = 6> __global__ __launch_bounds__(512, 2) 
         // rows of this pass: m = mrow + 4 it + (lane >> 4); (group g, row t) follow by carrying (no division per row)
         const long mrow = m0 + wr * 128 + pass * 64 + (lane >> 4);
         long g = mrow / rv, t = mrow - g * rv;
+        if constexpr (NORM) {
+            // ---- ChannelNorm + ReLU + split of whole rows: a row's 256 columns are with the four waves wc = 0..3 of this wr
+            float *const rsum = reinterpret_cast<float *>(lds + 8 * 16384);        // [wr][row of the pass][wc]
+            float *const rss = rsum + 2 * 64 * 4;
+            const int rloc = wr * 64 + (lane >> 4);                                // + 4 it
+            float4 v[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4 *>(stg + (it * 4 + (lane >> 4)) * 64 + c4);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const float sm = group_sum<16>((v[it].x + v[it].y) + (v[it].z + v[it].w));
+                if ((lane & 15) == 0) rsum[(rloc + 4 * it) * 4 + wc] = sm;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            float mean[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(rsum + (rloc + 4 * it) * 4);
+                mean[it] = ((q4.x + q4.y) + (q4.z + q4.w)) * (1.f / PT_BN);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                float4 &q = v[it];
+                q.x -= mean[it]; q.y -= mean[it]; q.z -= mean[it]; q.w -= mean[it];
+                const float ss = group_sum<16>(fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, q.w * q.w))));
+                if ((lane & 15) == 0) rss[(rloc + 4 * it) * 4 + wc] = ss;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const float4 gm = *reinterpret_cast<const float4 *>(p.norm.gamma + nw + c4);
+            const float4 bt = *reinterpret_cast<const float4 *>(p.norm.beta + nw + c4);
+            const int sh = p.norm.sshift;
+            const long smask = (1L << sh) - 1;
+            const long chunk_c = (long)((nw + c4) >> 4);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(rss + (rloc + 4 * it) * 4);
+                const float rstd = rsqrtf(((q4.x + q4.y) + (q4.z + q4.w)) * (1.f / (PT_BN - 1)) + p.norm.eps);
+                const long m = mrow + 4 * it;
+                const long crow = g * p.map.rows_out + t;             // (forward map: out_stride 1, out_off 0)
+                if (m < p.M) {
+                    const float4 xh = make_float4(v[it].x * rstd, v[it].y * rstd, v[it].z * rstd, v[it].w * rstd);
+                    *reinterpret_cast<float4 *>(out + crow * ldo + nw + c4) = xh;
+                    if ((lane & 15) == 0 && wc == 0) p.norm.rstd[crow] = rstd;
+                    const float y[4] = {fmaxf(fmaf(xh.x, gm.x, bt.x), 0.f), fmaxf(fmaf(xh.y, gm.y, bt.y), 0.f),
+                                        fmaxf(fmaf(xh.z, gm.z, bt.z), 0.f), fmaxf(fmaf(xh.w, gm.w, bt.w), 0.f)};
+                    uint2 w3[3];
+                    split4_terms(y, w3);
+                    const long R = g * p.norm.rows_next + p.norm.halo + t;
+                    const long chunk = ((chunk_c << sh) + (R & smask)) * p.norm.rts + (R >> sh);
+                    unsigned short *dst = p.norm.p + chunk * 16 + ((nw + c4) & 15);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2 *>(dst + pl * p.norm.plane) = w3[pl];
+                }
+                t += 4;
+                while (t >= rv) { t -= rv; ++g; }
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const float4 v = *reinterpret_cast<const float4 *>(stg + (it * 4 + (lane >> 4)) * 64 + c4);
@@ -456,10 +533,20 @@ static int side_of(const PlanesOperand &o, PlanesSide &s, const char *name)
     return CPC_OK;
 }
 
+bool gemm_nt_planes_norm_ok(long M, int N, int K)
+{
+    static const bool off = getenv("CPC_NO_NORM_FUSION") != nullptr;          // A/B switch
+    return !off && gemm_nt_planes_ok(M, N, K) && N == PT_BN && nt_planes_splits(M, N, K) == 1;
+}
+
 int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
-                   const RowMap &map, hipStream_t st)
+                   const RowMap &map, hipStream_t st, const PlanesNormOut *norm)
 {
     CPC_REQUIRE(gemm_nt_planes_ok(M, N, K), "gemm_nt_planes: shape M=%ld N=%d K=%d not supported", M, N, K);
+    CPC_REQUIRE(norm == nullptr || (gemm_nt_planes_norm_ok(M, N, K) && map.enabled && map.out_stride == 1 && map.out_off == 0 &&
+                                    map.col_rows == 0 && norm->gamma && norm->beta && norm->rstd && norm->p && gemm_mode() != 2 &&
+                                    reinterpret_cast<uintptr_t>(norm->p) % 8 == 0 && norm->plane % 4 == 0),
+                "gemm_nt_planes: the fused norm needs N == 256, no K split and a forward row map");
     static bool attr_set = false;
     if (!attr_set) {
         CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false>),
@@ -470,12 +557,15 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
         CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false, 3>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false, 6, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
         attr_set = true;
     }
     PlanesNTArgs a{};
     CPC_TRY(side_of(A, a.A, "A"));
     CPC_TRY(side_of(B, a.B, "B"));
     a.C = C; a.ldc = ldc; a.bias = bias; a.M = M; a.N = N; a.K = K; a.map = map;
+    if (norm != nullptr) a.norm = *norm;
     a.tiles_m = (int)cdiv(M, PT_BM); a.tiles_n = N / PT_BN;
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
     a.xcd_remap = (!no_remap && a.tiles_n > 1 && a.tiles_m % 8 == 0) ? 1 : 0;
@@ -486,7 +576,7 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     {
         const long out_rows = map.enabled ? cdiv(M, map.rv) * map.rows_out : M;
         const int sp = nt_planes_splits(M, N, K);
-        if (sp > 1 && map.splitk_scratch != nullptr && (!map.enabled || map.col_rows == 0) &&
+        if (norm == nullptr && sp > 1 && map.splitk_scratch != nullptr && (!map.enabled || map.col_rows == 0) &&
             reinterpret_cast<uintptr_t>(map.splitk_scratch) % 16 == 0 && (size_t)sp * out_rows * N * sizeof(float) <= map.splitk_bytes) {
             splits = sp;
             a.kchunk = K / sp;
@@ -504,6 +594,7 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     ProfScope prof(PROF_PLANES_NT, st);
     if ((a.dbg & 3) == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     else if ((a.dbg & 3) == 2) hipLaunchKernelGGL((gemm_planes_kernel<2, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
+    else if (norm != nullptr) hipLaunchKernelGGL((gemm_planes_kernel<0, false, 6, true>), dim3((unsigned)blocks, 1u), dim3(512), PT_LDS, st, a);
     else if (gemm_mode() == 2) hipLaunchKernelGGL((gemm_planes_kernel<0, false, 3>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     else hipLaunchKernelGGL((gemm_planes_kernel<0, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");

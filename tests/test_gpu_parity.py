@@ -342,7 +342,8 @@ def test_encoder_vs_reference_golden(golden):
         assert_close(p.grad, t(g["grad." + name]), 1e-4, f"grad {name}")
 
 
-@pytest.mark.parametrize("hidden,n,length", [(256, 3, 20480), (64, 2, 3300), (512, 2, 4800), (128, 1, 20480)])
+# (256, 44, 20480): conv1's product has more than 160 tiles and does not split K -> ChannelNorm + ReLU + split in its epilogue
+@pytest.mark.parametrize("hidden,n,length", [(256, 3, 20480), (64, 2, 3300), (512, 2, 4800), (128, 1, 20480), (256, 44, 20480)])
 def test_encoder_vs_oracle_fp64(hidden, n, length):
     params = synth.encoder_params(hidden, seed=5)
     enc = load_encoder(hidden, params)
@@ -356,7 +357,55 @@ def test_encoder_vs_oracle_fp64(hidden, n, length):
     assert_close(out, ref, 2e-5, "encoder output")
     (out * gout.to(DEV)).sum().backward()
     for name, p in enc.named_parameters():
-        assert_close(p.grad, p64["gEncoder." + name].grad, 2e-4, f"grad {name}")
+        # Many windows: the gradients below a layer are conditioned by that layer's ReLU decisions, and a handful of the 1e7
+        # pre-activations fall the other way in ANY fp32 evaluation than in fp64 -- the oracle itself run in fp32 (plain torch on the
+        # CPU) is 1.9e-3 away from its fp64 run on conv1.weight at 16 windows, this path 4.3e-4; at 44 windows this path measures
+        # 2e-3 .. 7e-3, identically with and without the fused epilogue and in round 2's build (tools/scratch/enc_err.py).  A wrong
+        # kernel is off by O(1); the output itself is held to 2e-5 above.
+        tol = 2e-2 if n > 16 else 2e-4
+        assert_close(p.grad, p64["gEncoder." + name].grad, tol, f"grad {name}")
+
+
+_ENC_FORMS_SCRIPT = """
+import sys, torch
+sys.path.insert(0, {root!r})
+import cpc2_amd
+from oracle import synth
+hidden, n = 256, {n}
+enc = cpc2_amd.CPCEncoder(hidden)
+enc.load_state_dict({{k[len("gEncoder."):]: v for k, v in synth.encoder_params(hidden, seed=5).items()}})
+enc = enc.to("cuda:0")
+x = synth.audio_windows(n, 20480, seed=6).to("cuda:0")
+out = enc(x)
+(out * synth.features(tuple(out.shape), seed=7).to("cuda:0")).sum().backward()
+torch.save({{"out": out.detach().cpu(), **{{k: p.grad.cpu() for k, p in enc.named_parameters()}}}}, {dst!r})
+"""
+
+
+def test_encoder_with_and_without_the_fused_norm_epilogue(tmp_path):
+    """96 windows at hidden 256: conv1 AND conv2 run without a K split, so both take ChannelNorm + ReLU + split in the product's
+    epilogue (gemm_nt_planes with a PlanesNormOut).  CPC_NO_NORM_FUSION=1 (read once per process) gives the three-kernel form the
+    oracle tests cover at small window counts; the two agree to fp32 rounding in the output and in every gradient."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form, env in (("fused", {}), ("plain", {"CPC_NO_NORM_FUSION": "1"})):
+        dst = str(tmp_path / f"{form}.pt")
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        if form == "fused":
+            e.pop("CPC_NO_NORM_FUSION", None)
+        r = subprocess.run([sys.executable, "-c", _ENC_FORMS_SCRIPT.format(root=root, n=96, dst=dst)], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = torch.load(dst)
+    # (gradients: see the conditioning note in test_encoder_vs_oracle_fp64 -- two fp32 evaluation orders differ by ~1e-3 there)
+    for key in res["plain"]:
+        tol = 1e-2 if key != "out" else 2e-5
+        e = rel_err(res["fused"][key], res["plain"][key].double())
+        print(f"{key}: {e:.2e}")
+        assert e <= tol, f"{key} (fused epilogue vs norm kernel): rel err {e:.3e} > {tol:.1e}"
+    assert not torch.equal(res["fused"]["out"], res["plain"]["out"]), "the switch selected the same kernels twice"
 
 
 # ----------------------------------------------------------------------------- GRU
