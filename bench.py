@@ -113,12 +113,22 @@ def similarity_algorithmic_flops(b, cfg):
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
-    tools/summarize_pmc.py from the --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when absent."""
+    """HBM bytes per launch of a kernel FAMILY from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/summarize_pmc.py from the --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when absent.  `kernel` is
+    "<name prefix>:<config>": every instantiation of the newest profile whose name starts with the prefix counts (the plane-fed
+    NT kernel runs as <0, false, 6, false> and, with the norm in its epilogue, <0, false, 6, true>), weighted by its launches."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return table["kernels"][kernel]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+        prefix, cfg = kernel.rsplit(":", 1)
+        prefix = prefix.rstrip(">")
+        hits = [v for k, v in table.items() if k.endswith(":" + cfg) and k.startswith(prefix)]
+        if not hits:
+            return None
+        newest = max(h.get("source", "") for h in hits)
+        hits = [h for h in hits if h.get("source", "") == newest]
+        w = [h.get("launches_per_step", 1.0) for h in hits]
+        return int(round(sum(h["bytes_per_launch"] * x for h, x in zip(hits, w)) / sum(w)))
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 

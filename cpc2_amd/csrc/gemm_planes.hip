@@ -536,7 +536,7 @@ static int side_of(const PlanesOperand &o, PlanesSide &s, const char *name)
 bool gemm_nt_planes_norm_ok(long M, int N, int K)
 {
     static const bool off = getenv("CPC_NO_NORM_FUSION") != nullptr;          // A/B switch
-    return !off && gemm_nt_planes_ok(M, N, K) && N == PT_BN && nt_planes_splits(M, N, K) == 1;
+    return !off && gemm_mode() != 2 && gemm_nt_planes_ok(M, N, K) && N == PT_BN && nt_planes_splits(M, N, K) == 1;   // (mode 2: its own kernels)
 }
 
 int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,

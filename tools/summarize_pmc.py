@@ -50,6 +50,7 @@ for r in stats:
     if n in fetch and n in write:
         fr = 2 * 1024 * sum(fetch[n]) / len(fetch[n]); wr = 1024 * sum(write[n]) / len(write[n])
         table["kernels"][f"{full}:{config}"] = {"bytes_per_launch": round(fr + wr), "read": round(fr), "write": round(wr),
+                                                "launches_per_step": int(r["Calls"]) / steps,
                                                 "source": os.path.basename(root.rstrip("/"))}
 json.dump(table, open(path, "w"), indent=1, sort_keys=True)
 print(f"\ntotal GPU time per step: {tot/1e6/steps:.3f} ms ({steps} steps incl. warm-up)")
