@@ -156,11 +156,19 @@ def _packed_view(tensors):
 
 # ---- the deferred backward (cpc2_hip.h, cpc_infonce_backward_deferred) --------------------------------------------------------
 # The criterion's dz and predictor weight gradients are produced on a stream of the library's while the context network's
-# backward runs; whoever consumes them has to sit behind join_deferred().  That is guaranteed for an encodedData that came
-# out of grad_join() (CPCModel.forward applies it BEFORE the context network, so autograd runs its backward after the context
-# network's and before anything that reads the summed gradient of the encoder output); such a tensor carries `_cpc_join`, and
-# only then does the criterion defer.  A callback at the end of the backward pass joins whatever is still pending (an encoder
-# without gradient: nobody reads dz, the optimiser reads the weight gradients).
+# backward runs; whoever consumes them has to sit behind join_deferred().  Nothing but the caller can promise that, so the
+# deferral is an EXPLICIT opt-in of the caller's, never something a tensor attribute switches on by travelling through
+# wrappers: `with criterion.deferred_backward(encoded_full): criterion(c, z, label)` (cpcStep does it) states that
+#   * `encoded_full` came out of grad_join() (CPCModel.forward applies it BEFORE the context network, so autograd runs its
+#     backward after the context network's and before anything that reads the summed gradient of the encoder output),
+#   * the criterion call inside the scope is the ONLY consumer of that tensor (a second loss term on it, or a tensor hook,
+#     would make autograd read dz before the join), and
+#   * nothing reads the predictors' weight gradients before the backward pass has ended.
+# The scope is refused (the backward then runs at once, on the caller's stream) when the criterion object is not the bare
+# module (DistributedDataParallel / DataParallel around it: DDP's reducer copies a weight gradient into its bucket the moment
+# autograd accumulates it, i.e. before the side stream has written it) or when a predictor weight carries a backward or
+# post-accumulate hook.  A callback at the end of the backward pass joins whatever is still pending (an encoder without
+# gradient: nobody reads dz, the optimiser reads the weight gradients).
 _deferred = {}          # device index -> tensors the side stream still reads / writes (kept alive until the join)
 
 
@@ -205,6 +213,20 @@ def carry_join(view, parent, start):
         view._cpc_join = True
         view._cpc_join_parent = (parent, int(start))
     return view
+
+
+class _DeferScope:
+    def __init__(self, criterion, encoded_full):
+        self.criterion, self.tensor = criterion, encoded_full
+
+    def __enter__(self):
+        ok = getattr(self.tensor, "_cpc_join", False) and not hasattr(self.tensor, "_cpc_join_parent")
+        self.criterion._defer_scope = self.tensor if ok else None
+        return self
+
+    def __exit__(self, *exc):
+        self.criterion._defer_scope = None
+        return False
 
 
 class _InfoNCEFn(torch.autograd.Function):
@@ -491,10 +513,23 @@ class CPCUnsupersivedCriterion(BaseCriterion):
             raise ValueError("Invalid mode")
         self.mode = mode
         self.sampler = NegativeSampler()
+        self._defer_scope = None       # set by deferred_backward() for the duration of the caller's scope
 
     def seed(self, seed):
         """Use a private negative-index stream (e.g. one per data-parallel rank)."""
         self.sampler.seed(seed)
+
+    def _may_defer(self):
+        """No predictor weight with a hook that would read its gradient before the end of the backward pass."""
+        for p in self.wPrediction.parameters():
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        return True
+
+    def deferred_backward(self, encoded_full):
+        """Context manager: the criterion call(s) inside may run the deferred backward with respect to `encoded_full`, a
+        grad_join() output that nothing else consumes (see the comment above join_deferred)."""
+        return _DeferScope(self, encoded_full)
 
     def _prepare(self, cFeature, encodedData):
         if self.mode == "reverse":                      # criterion.py:292-294
@@ -608,13 +643,16 @@ class CPCUnsupersivedCriterion(BaseCriterion):
     def forward(self, cFeature, encodedData, label, signal_quality=None):
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
-        # deferred backward (see grad_join): only for an encodedData that sits behind a join, and not in reverse mode (the flip is
-        # an autograd node of its own that would read dz at once)
+        # deferred backward: only inside an explicit deferred_backward() scope of the caller's whose tensor this encodedData is
+        # (or is a window slice of: carry_join), and not in reverse mode (the flip is an autograd node of its own that would
+        # read dz at once)
         defer = None
-        if getattr(encodedData, "_cpc_join", False) and self.mode != "reverse" and not os.environ.get("CPC_NCE_NO_DEFER") \
-                and encodedData.dtype == torch.float32 and encodedData.is_contiguous():
+        scope = self._defer_scope
+        if scope is not None and self.mode != "reverse" and not os.environ.get("CPC_NCE_NO_DEFER") \
+                and encodedData.dtype == torch.float32 and encodedData.is_contiguous() and getattr(encodedData, "_cpc_join", False):
             zFull, start = getattr(encodedData, "_cpc_join_parent", (encodedData, 0))
-            defer = (start, batchSize)
+            if zFull is scope and self._may_defer():
+                defer = (start, batchSize)
         cFeature, encodedData = self._prepare(cFeature, encodedData)
         if signal_quality is not None:                  # criterion.py:334-338
             quality_weighting = self.weighting_function(signal_quality.mean(dim=1))

@@ -344,18 +344,31 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
         c_feature, encoded_data, label = cpcModel(past, label)
         if dp is not None:
             dp.attach(encoded_data)
-        allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
+        with _defer_scope(cpcCriterion, encoded_data):
+            allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
         return allLosses.sum(), allLosses, allAcc
     combined = torch.cat([past, future], dim=0)
     label = torch.cat([label, label])
-    c_feature, encoded_data, label = cpcModel(combined, label)
+    c_feature, encoded_full, label = cpcModel(combined, label)
     if dp is not None:
-        dp.attach(encoded_data)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
+        dp.attach(encoded_full)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
     c_feature = c_feature[:b, :, :]
-    encoded_data = carry_join(encoded_data[b:, :, :], encoded_data, b)
+    encoded_data = carry_join(encoded_full[b:, :, :], encoded_full, b)
     label = label[:b]
-    allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
+    with _defer_scope(cpcCriterion, encoded_full):
+        allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
     return allLosses.sum(), allLosses, allAcc
+
+
+def _defer_scope(cpcCriterion, encoded_full):
+    """The criterion's deferred backward (criterion.py, deferred_backward) is this function's to allow: the encoder output
+    never leaves cpcStep, so the criterion call is its only consumer.  Only for the bare criterion module -- wrapped the way
+    the reference wraps it (DistributedDataParallel, train.py:526; DataParallel, :531) the wrapper's reducer reads the
+    predictors' weight gradients as soon as autograd has accumulated them, before a side stream could have written them."""
+    import contextlib
+    if isinstance(cpcCriterion, CPCUnsupersivedCriterion):
+        return cpcCriterion.deferred_backward(encoded_full)
+    return contextlib.nullcontext()
 
 
 def _check_async(device):

@@ -145,6 +145,12 @@ int cpc_encoder_forward(const float *x, const float *const *params, float *z, vo
 int cpc_encoder_backward(const float *x, const float *const *params, const float *dz, void *saved,
                          void *scratch, float *const *grads, int n_windows, int length, int hidden,
                          float eps, cpc_stream_t stream);
+/* Inspection (tests only; the layout of `saved` is otherwise private): what the forward pass keeps of layer 1..4 --
+ * the ChannelNorm of model.py:52-60 as (xhat, rstd) and, at hidden 256 / 512, its ReLU'd output as the next layer's input
+ * planes.  out[0] byte offset of xhat [n_windows * out[2]][hidden] f32 (row n * out[2] + t, t < out[3] valid frames),
+ * out[1] byte offset of rstd [n_windows * out[2]] f32, out[4] byte offset of the three bf16 planes of the layer's output
+ * (-1: stored as f32, or layer 4), out[5] elements per plane, out[6] rows per phase, out[7] log2 of the reading stride. */
+int cpc_encoder_saved_layout(int n_windows, int length, int hidden, int layer, long *out);
 
 /* ------------------------------------------------------------------------------------------
  * CPCAR with mode="GRU" (model.py:158-207 -> torch.nn.GRU, batch_first, gate order r,z,n).

@@ -40,7 +40,7 @@ def _free_port():
 
 
 DP_TESTS = ("test_two_ranks_equal_one_process_with_two_micro_batches", "test_rccl_process_group_of_one_rank",
-            "test_reference_style_ddp_wrapping_with_flat_adam")
+            "test_reference_style_ddp_wrapping_with_flat_adam", "test_reference_ddp_arguments_do_not_defer_the_criterion_backward")
 
 
 def _dp_tests_selected(config):
@@ -79,14 +79,15 @@ def pytest_sessionstart(session):
         return
     tmp = tempfile.mkdtemp(prefix="cpc_dp_")
     job = os.path.join(ROOT, "tests", "dp_job.py")
-    port, port1, port2 = str(_free_port()), str(_free_port()), str(_free_port())
+    port, port1, port2, port3 = str(_free_port()), str(_free_port()), str(_free_port()), str(_free_port())
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = {}
     # groups, one after the other (a GPU box allows six processes on its card at once, this session included): the ranks of
     # a group are started together by a launcher process that never touches the GPU itself
     groups = [{"rank0": ("ranks", 0, 2, port), "rank1": ("ranks", 1, 2, port), "single": ("single", 0, 1, port),
                "nccl": ("nccl", 0, 1, port1)},
-              {"ddp0": ("ddp", 0, 2, port2), "ddp1": ("ddp", 1, 2, port2)}]
+              {"ddp0": ("ddp", 0, 2, port2), "ddp1": ("ddp", 1, 2, port2)},
+              {"ddpref0": ("ddpref", 0, 2, port3), "ddpref1": ("ddpref", 1, 2, port3)}]
     plan = []
     for group in groups:
         cmds = []

@@ -11,6 +11,9 @@ mode "nccl":   world_size 1 over RCCL: init, broadcast, overlapped + blocking al
 mode "ddp":    the reference's own arrangement (cpc/train.py:523-527): model and criterion wrapped in
                torch.nn.parallel.DistributedDataParallel (gloo, two ranks on cuda:0), FlatAdam as the optimiser -- DDP's
                buckets average the gradients that the fused backward kernels wrote into the flat buffer.
+mode "ddpref": the same with the reference's own DDP arguments (find_unused_parameters left False: the wrappers then hand
+               tensor attributes through, which is how a criterion that keyed its deferred backward on one would have let
+               DDP's reducer read predictor gradients that a side stream had not written yet -- round-3 advisor finding).
 
 Self-diagnosing (round-2 review): every rank keeps, per step, an ON-STREAM clone of its own gradient taken right before each
 all-reduce (DataParallelContext.trace, no device-wide synchronisation anywhere near it) and of the buffer of sums after the
@@ -118,15 +121,16 @@ if mode in ("ranks", "nccl"):
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
-elif mode == "ddp":
+elif mode in ("ddp", "ddpref"):
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     from torch.nn.parallel import DistributedDataParallel as DDP
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if rank != 0:
         opt.flat.mul_(1.5)                     # DDP's constructor broadcasts rank 0's parameters (into the flat buffer's views)
-    ddp_model = DDP(model, device_ids=[0], find_unused_parameters=True)
-    ddp_crit = DDP(crit, device_ids=[0], find_unused_parameters=True)
+    unused = mode == "ddp"
+    ddp_model = DDP(model, device_ids=[0], find_unused_parameters=unused)
+    ddp_crit = DDP(crit, device_ids=[0], find_unused_parameters=unused)
     home = {id(p): off for p, off in zip(opt.params, opt.offsets)}
 
     def tap_then_allreduce(_state, bucket):
@@ -145,6 +149,8 @@ elif mode == "ddp":
         tape.begin()
         tot, ls, _acc = cpcStep(x, x, label, ddp_model, ddp_crit)
         tot.backward()
+        from cpc2_amd import criterion as _cm
+        assert not _cm._deferred, "a criterion inside DistributedDataParallel must not defer its backward"
         opt._gather_stray_grads()
         tape("post", 0, opt.flat_grad.numel(), opt.flat_grad)         # DDP's averages, back in the parameters' gradients
         opt.step()

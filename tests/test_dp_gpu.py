@@ -145,3 +145,18 @@ def test_reference_style_ddp_wrapping_with_flat_adam(dp_jobs):
     _end_to_end(d0, d1, single)
     both = torch.stack([d0["losses"], d1["losses"]], dim=1).reshape(single["losses"].shape)
     assert torch.allclose(both, single["losses"], rtol=2e-5, atol=1e-6)
+
+
+def test_reference_ddp_arguments_do_not_defer_the_criterion_backward(dp_jobs):
+    """cpc/train.py:524-527 with the reference's own arguments (find_unused_parameters False: the wrappers then pass tensor
+    attributes through).  The criterion inside DistributedDataParallel must run its backward at once -- DDP's reducer reads a
+    predictor's weight gradient the moment autograd accumulates it (the job asserts that nothing was deferred) -- and the
+    update must be the single process' one, predictor gradients included, under the same strict comparison."""
+    single, d0, d1 = dp_jobs["single"], dp_jobs["ddpref0"], dp_jobs["ddpref1"]
+    for who in ("ddpref0", "ddpref1"):
+        _verify_record(dp_jobs[who], who)
+    assert d0["step_count"] == d1["step_count"] == 2
+    kernel, transport = _compare((d0, d1), single, scale=0.5)
+    assert not kernel, "\n".join(kernel)
+    assert not transport, "DistributedDataParallel (find_unused_parameters=False) over gloo:\n" + "\n".join(transport)
+    _end_to_end(d0, d1, single)

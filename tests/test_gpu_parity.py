@@ -358,13 +358,24 @@ def test_encoder_vs_oracle_fp64(hidden, n, length):
     assert tuple(out.shape) == tuple(ref.shape)
     assert_close(out, ref, 2e-5, "encoder output")
     (out * gout.to(DEV)).sum().backward()
+    # Many windows: the gradients below a layer are conditioned by that layer's ReLU decisions, and a handful of the 1e7
+    # pre-activations fall the other way in ANY fp32 evaluation than in fp64, each flipping a gradient term of sums that cancel
+    # to a small fraction of their terms.  The yardstick is therefore computed HERE, not quoted: the same oracle run in fp32
+    # (plain torch on the CPU) against its own fp64 run, per parameter; this path may be off by at most three times that (and
+    # never by more than the coarse 2e-2 gate; at few windows by the fixed 2e-4).  The saved statistics themselves are pinned
+    # directly by test_fused_norm_epilogue_saves_the_same_state_as_the_norm_kernel.
+    yard = {}
+    if n > 16:
+        p32 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        ref32 = O.encoder_forward(x, p32, "gEncoder.")
+        (ref32 * gout).sum().backward()
+        for name, _p in enc.named_parameters():
+            yard[name] = rel_err(p32["gEncoder." + name].grad, p64["gEncoder." + name].grad)
     for name, p in enc.named_parameters():
-        # Many windows: the gradients below a layer are conditioned by that layer's ReLU decisions, and a handful of the 1e7
-        # pre-activations fall the other way in ANY fp32 evaluation than in fp64 -- the oracle itself run in fp32 (plain torch on the
-        # CPU) is 1.9e-3 away from its fp64 run on conv1.weight at 16 windows, this path 4.3e-4; at 44 windows this path measures
-        # 2e-3 .. 7e-3, identically with and without the fused epilogue and in round 2's build (tools/scratch/enc_err.py).  A wrong
-        # kernel is off by O(1); the output itself is held to 2e-5 above.
-        tol = 2e-2 if n > 16 else 2e-4
+        tol = 2e-4
+        if n > 16:
+            tol = min(2e-2, max(2e-4, 3.0 * yard[name]))
+            print(f"{name}: fp32 oracle {yard[name]:.2e}, this path {rel_err(p.grad, p64['gEncoder.' + name].grad):.2e}, bar {tol:.2e}")
         assert_close(p.grad, p64["gEncoder." + name].grad, tol, f"grad {name}")
 
 
@@ -408,6 +419,84 @@ def test_encoder_with_and_without_the_fused_norm_epilogue(tmp_path):
         print(f"{key}: {e:.2e}")
         assert e <= tol, f"{key} (fused epilogue vs norm kernel): rel err {e:.3e} > {tol:.1e}"
     assert not torch.equal(res["fused"]["out"], res["plain"]["out"]), "the switch selected the same kernels twice"
+
+
+_ENC_SAVED_SCRIPT = """
+import ctypes, sys, torch
+sys.path.insert(0, {root!r})
+from cpc2_amd import _lib
+from oracle import synth
+lib = _lib.load()
+hidden, n, length = 256, {n}, {length}
+dev = torch.device("cuda:0")
+params = [v.to(dev).contiguous() for v in synth.encoder_params(hidden, seed=5).values()]
+x = synth.audio_windows(n, length, seed=6).to(dev)
+frames = lib.cpc_encoder_frames(length)
+z = torch.empty(n, frames, hidden, device=dev)
+saved = torch.zeros(lib.cpc_encoder_saved_bytes(n, length, hidden), dtype=torch.uint8, device=dev)
+scratch = torch.empty(lib.cpc_encoder_scratch_bytes(n, length, hidden), dtype=torch.uint8, device=dev)
+_lib.check(lib.cpc_encoder_forward(_lib.ptr(x), _lib.ptr_array(params), _lib.ptr(z), _lib.ptr(saved), _lib.ptr(scratch), n, length,
+                                   hidden, 1e-5, _lib.stream_ptr(dev)), "encoder_forward")
+torch.cuda.synchronize()
+out = {{"z": z.cpu()}}
+for layer in (1, 2, 3):
+    lay = (ctypes.c_long * 8)()
+    _lib.check(lib.cpc_encoder_saved_layout(n, length, hidden, layer, lay), "saved_layout")
+    xo, ro, rv, lv, po, plane, rts, sshift = list(lay)
+    xh = saved[xo:xo + 4 * n * rv * hidden].view(torch.float32).view(n, rv, hidden)[:, :lv]
+    rstd = saved[ro:ro + 4 * n * rv].view(torch.float32).view(n, rv)[:, :lv]
+    out[f"xhat{{layer}}"], out[f"rstd{{layer}}"] = xh.cpu(), rstd.cpu()
+    planes = saved[po:po + 2 * 3 * plane].view(torch.bfloat16).view(3, plane)
+    out[f"planes{{layer}}"] = planes.cpu().view(torch.int16)          # the three terms as stored (halo and slack rows included)
+torch.save(out, {dst!r})
+"""
+
+
+@pytest.mark.parametrize("n,length", [(44, 20480), (96, 20480), (43, 19800)])
+def test_fused_norm_epilogue_saves_the_same_state_as_the_norm_kernel(tmp_path, n, length):
+    """What the fused epilogue of conv1 / conv2 (gemm_planes_kernel<0, false, 6, true>) leaves for the backward pass and for the
+    next layer, read straight out of `saved` (cpc_encoder_saved_layout) and compared with the three-kernel form
+    (CPC_NO_NORM_FUSION=1, its own process: the switch is read once) -- model.py:52-60's statistics, not their effect on a
+    gradient: xhat and rstd of every valid row to 1e-6 (1e-5 of the largest element for single elements of xhat), and the next
+    layer's input planes, halo and slack rows included: their sum p0 + p1 + p2 equal to 1e-6, zero rows zero in both.
+    Layer 3 is the norm kernel in both forms (its product splits K); its input differs by the rounding above."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form, env in (("fused", {}), ("plain", {"CPC_NO_NORM_FUSION": "1"})):
+        dst = str(tmp_path / f"{form}.pt")
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        if form == "fused":
+            e.pop("CPC_NO_NORM_FUSION", None)
+        r = subprocess.run([sys.executable, "-c", _ENC_SAVED_SCRIPT.format(root=root, n=n, length=length, dst=dst)], env=e,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = torch.load(dst)
+    f, p = res["fused"], res["plain"]
+    assert_close(f["z"], p["z"], 2e-6, "encoder output")
+    for layer in (1, 2):
+        for key in (f"xhat{layer}", f"rstd{layer}"):
+            a, b = f[key].double(), p[key].double()
+            assert torch.isfinite(a).all()
+            e_max = float((a - b).abs().max() / b.abs().max())
+            e_rms = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+            print(f"{key}: max {e_max:.2e} rms {e_rms:.2e}")
+            assert e_rms <= 1e-6 and e_max <= (1e-6 if key.startswith("rstd") else 1e-5), f"{key}: rms {e_rms:.2e}, max {e_max:.2e}"
+        # per-row rstd: relative, element by element (a row's statistic is one number: nothing to average over)
+        rel = ((f[f"rstd{layer}"].double() - p[f"rstd{layer}"].double()).abs() / p[f"rstd{layer}"].double().abs()).max()
+        assert float(rel) <= 2e-6, f"rstd{layer}: worst row off by {float(rel):.2e} relative"
+        # (p0 + p1 + p2 is an f32 by construction: the f32 sum is exact.  A ReLU decision that falls the other way for a
+        #  pre-activation within rounding of zero shows as a difference of that size; a halo or slack row that one form left
+        #  non-zero would show as O(1))
+        pa, pb = f[f"planes{layer}"].view(torch.bfloat16).float(), p[f"planes{layer}"].view(torch.bfloat16).float()
+        ya, yb = (pa[0] + pa[1]) + pa[2], (pb[0] + pb[1]) + pb[2]
+        assert float(((ya == 0) != (yb == 0)).float().mean()) <= 1e-5, f"layer {layer}: zero pattern of the next layer's input differs"
+        e_y = float((ya - yb).abs().max() / yb.abs().max())
+        print(f"planes{layer}: max {e_y:.2e}")
+        assert e_y <= 1e-6, f"planes{layer}: p0 + p1 + p2 differs by {e_y:.2e}"
+    assert not torch.equal(f["xhat1"], p["xhat1"]), "the switch selected the same kernels twice"
+    assert_close(f["xhat3"], p["xhat3"], 1e-5, "xhat3")
 
 
 # ----------------------------------------------------------------------------- GRU
@@ -1540,6 +1629,83 @@ def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch
     for step in range(2):
         assert torch.equal(results[0][0][step], results[1][0][step]), f"step {step}: gradients differ between the two forms"
     assert torch.equal(results[0][1], results[1][1])
+
+
+def _spied_criterion_calls(monkeypatch, run):
+    """Runs `run()` with _InfoNCEFn.apply spied: the `defer` argument of every call."""
+    from cpc2_amd import criterion as crit_mod
+    seen = []
+    real = crit_mod._InfoNCEFn.apply
+
+    def spy(*a):
+        seen.append(a[5])
+        return real(*a)
+    monkeypatch.setattr(crit_mod._InfoNCEFn, "apply", staticmethod(spy))
+    try:
+        out = run()
+    finally:
+        monkeypatch.setattr(crit_mod._InfoNCEFn, "apply", real)
+    return seen, out
+
+
+def test_criterion_backward_is_deferred_only_inside_the_callers_scope(monkeypatch):
+    """Round-3 advisor finding: the deferral must be the caller's explicit promise (cpcStep's `deferred_backward` scope), not
+    something a tensor attribute switches on.  (1) model and criterion called directly, the way the reference's train.py
+    does, with a SECOND loss term on the encoder output -- autograd sums the two gradients of that tensor as soon as both
+    exist, i.e. before a join: nothing may be deferred, and the gradient is the sum of the two terms' own gradients.
+    (2) inside cpcStep, a predictor weight with a tensor hook (what DDP's reducer amounts to): not deferred either."""
+    from cpc2_amd import criterion as crit_mod
+    hidden, b = 256, 4
+    mp = synth.encoder_params(hidden, 21)
+    mp.update(synth.gru_params(hidden, hidden, 1, 22))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+    model.load_state_dict(mp)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 23))
+    model, crit = model.to(DEV), crit.to(DEV)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    x = synth.audio_windows(b, 20480, 24).to(DEV)
+    label = torch.zeros(b, dtype=torch.long, device=DEV)
+    probe = torch.randn(b, 128, hidden, generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def direct(with_nce, with_extra):
+        crit.seed(5)
+        opt.zero_grad()
+        c, z, _ = model(x, label)
+        assert getattr(z, "_cpc_join", False)                    # the attribute is there -- and must not be what decides
+        tot = 0.0
+        if with_nce:
+            losses, _acc = crit(c, z, label)
+            tot = tot + losses.sum()
+        if with_extra:
+            tot = tot + (z * probe).sum() * 1e-3
+        tot.backward()
+        assert not crit_mod._deferred
+        opt._gather_stray_grads()
+        return opt.flat_grad.detach().clone()
+    seen, both = _spied_criterion_calls(monkeypatch, lambda: direct(True, True))
+    assert seen == [None], seen
+    only_nce, only_extra = direct(True, False), direct(False, True)
+    ref = only_nce.double() + only_extra.double()
+    assert float((both.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(only_extra.abs().max()) > 0
+
+    # (2) cpcStep opens the scope; a hook on a predictor weight closes it again
+    def step():
+        crit.seed(5)
+        opt.zero_grad()
+        tot, _l, _a = cpcStep(x[:2], x[:2], label[:2], model, crit)
+        tot.backward()
+        opt._gather_stray_grads()
+        return opt.flat_grad.detach().clone()
+    seen, g_deferred = _spied_criterion_calls(monkeypatch, step)
+    assert seen == [(2, 2)], seen
+    touched = []
+    handle = crit.wPrediction.predictors[3].weight.register_hook(lambda g: touched.append(float(g.abs().sum())))
+    seen, g_hooked = _spied_criterion_calls(monkeypatch, step)
+    handle.remove()
+    assert seen == [None] and len(touched) == 1 and touched[0] > 0, (seen, touched)
+    assert torch.equal(g_deferred, g_hooked)
 
 
 def test_infonce_backward_deferred_c_entry_matches_the_immediate_one():
