@@ -47,6 +47,10 @@ CONFIGS = {
     # a0 b0 + a0 b1 + a1 b0 of the bf16 split, 16 bits of product mantissa -- TF32, what the reference's own convolutions get on
     # its GPUs by default, keeps 10).  Reported beside the exact mode so that the cost of exactness is a measured number.
     "small_3term": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", gemm_mode=2),
+    # NOT the headline either: CPC-small with ONE encoder / AR pass when past is future (no augmentation: dataset.py:308-321 yields
+    # the same window twice, so the two halves of train.py:99's 2b-window batch are identical; SURVEY 8d allows the one-pass
+    # step as a labelled extra).  Bit-identical losses and parameter updates at about half the encoder work.
+    "small_dedup": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", dedup=True),
 }
 GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
@@ -167,42 +171,61 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("CPC_BENCH_MAX_CORES", "16"))))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(cfg, seconds_budget):
-    """The oracle's train step (CPU restatement of the reference, fp32 torch-CPU ops) timed on this
-    host's cores on a bounded sample of the same workload."""
+    """The oracle's train step (CPU restatement of the reference, fp32 torch-CPU ops) timed on this host's cores on a bounded
+    sample of the same workload: b = 8 (the reference's default batchSizeGPU) and b = 16 windows, CPU model and
+    core count in the record.  `value` is the b = 8 rate."""
     from oracle import cpc_oracle as O, synth
     from oracle.mt19937 import MT19937
     torch.set_num_threads(host_cores())
     log(f"cpu baseline on {torch.get_num_threads()} threads")
-    b, h = 8, cfg["hidden"]
-    mp = synth.encoder_params(h, 1)
+    h = cfg["hidden"]
     ar = cfg["ar"] if cfg["ar"] in GATES else "GRU"          # the transformer configs keep the GRU-model baseline
-    mp.update(synth.gru_params(h, h, cfg["layers"], 2, gates=GATES[ar]))
-    cp = synth.predictor_params(cfg["npred"], h, h, 3)
-    x = synth.audio_windows(b, WINDOW, 4)
-    params = {k: v.clone().requires_grad_(True) for k, v in list(cp.items()) + list(mp.items())}
-    opt = O.Adam({k: v.data for k, v in params.items()})
-    mt = MT19937(1234)
 
-    def step():
-        tot, _l, _a = O.train_step_loss(x, x, {k: params[k] for k in mp}, {k: params[k] for k in cp}, mt,
-                                        cfg["npred"], cfg["nneg"], cfg["layers"], ar)
-        grads = torch.autograd.grad(tot, list(params.values()))
-        opt.step(dict(zip(params, grads)))
+    def run(b, budget, max_steps):
+        mp = synth.encoder_params(h, 1)
+        mp.update(synth.gru_params(h, h, cfg["layers"], 2, gates=GATES[ar]))
+        cp = synth.predictor_params(cfg["npred"], h, h, 3)
+        x = synth.audio_windows(b, WINDOW, 4)
+        params = {k: v.clone().requires_grad_(True) for k, v in list(cp.items()) + list(mp.items())}
+        opt = O.Adam({k: v.data for k, v in params.items()})
+        mt = MT19937(1234)
 
-    step()                                                  # warm-up
-    log("cpu baseline warm-up step done")
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
-        step()
-        n += 1
-        log(f"cpu baseline step {n}")
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(b * SECONDS_PER_WINDOW / dt, 3), "unit": "audio-seconds/sec",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle train step (fwd+bwd+Adam, reference semantics), b={b} windows, {n} steps, "
-                      f"{dt:.2f} s/step, fp32 torch-CPU"}
+        def step():
+            tot, _l, _a = O.train_step_loss(x, x, {k: params[k] for k in mp}, {k: params[k] for k in cp}, mt,
+                                            cfg["npred"], cfg["nneg"], cfg["layers"], ar)
+            grads = torch.autograd.grad(tot, list(params.values()))
+            opt.step(dict(zip(params, grads)))
+
+        step()                                                  # warm-up
+        log(f"cpu baseline b={b}: warm-up step done")
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < budget and n < max_steps):
+            step()
+            n += 1
+            log(f"cpu baseline b={b}: step {n}")
+        dt = (time.perf_counter() - t0) / n
+        return {"value": round(b * SECONDS_PER_WINDOW / dt, 3), "windows": b, "steps": n, "s_per_step": round(dt, 3)}
+
+    r8 = run(8, 0.45 * seconds_budget, 5)
+    r16 = run(16, 0.3 * seconds_budget, 3)
+    return {"value": r8["value"], "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
+            "kind": "port",
+            "sample": f"oracle train step (fwd+bwd+Adam, reference semantics), fp32 torch-CPU: b=8 windows, {r8['steps']} steps, "
+                      f"{r8['s_per_step']:.2f} s/step; b=16 windows, {r16['steps']} steps, {r16['s_per_step']:.2f} s/step",
+            "by_batch": {"b8": r8, "b16": r16}}
 
 
 def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_seconds):
@@ -223,9 +246,10 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     from cpc2_amd import _lib
     from cpc2_amd.train import DataParallelContext, cpcStep
     model, crit, opt = build(cfg, device)
+    dedup = bool(args.dedup or cfg.get("dedup"))
     # N > 1: the criterion / context-network gradient slices are all-reduced under the encoder's backward (train.py)
     dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()),
-                             overlap=not os.environ.get("CPC_BENCH_NO_OVERLAP"))
+                             overlap=not os.environ.get("CPC_BENCH_NO_OVERLAP"), timing=True)
     crit.seed(1234 + rank)                                  # per-rank negative stream
     crit.sampler.prefetch = True                            # host draws step i+1's MT19937 words during step i
     g = torch.Generator().manual_seed(1000 + rank)          # per-rank shard of the synthetic utterances
@@ -233,7 +257,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     label = torch.zeros(args.batch, dtype=torch.long, device=device)
 
     def step():
-        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=args.dedup, dp=dp)
+        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup, dp=dp)
         tot.backward()
         dp.reduce_and_step()
         opt.zero_grad()
@@ -254,20 +278,27 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     if prof:
         lib.cpc_prof_enable(2 if roof == "gemm_planes_nt" else 3)   # the roofline kernel only inside the timed region
     torch.cuda.synchronize()
+    dp.timing_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         losses = step()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0                  # this rank's own clock (before the closing barrier)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    exposed_ms = dp.timing_read()                            # per step: compute stream held by the exchange (events)
     lib.cpc_prof_enable(0)
     _lib.check(lib.cpc_async_error_check(_lib.stream_ptr(device)), "async error check")
     log(f"{cfg_name}: timed region done: {1e3 * elapsed / steps:.2f} ms/step")
+    rank_ms = [1e3 * own_elapsed / steps] * 2
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed, own_elapsed, -own_elapsed, exposed_ms if exposed_ms is not None else 0.0], dtype=torch.float64,
+                            device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = float(tmax[0].item())
+        rank_ms = [1e3 * float(-tmax[2].item()) / steps, 1e3 * float(tmax[1].item()) / steps]     # min, max over the ranks
+        exposed_ms = float(tmax[3].item()) if exposed_ms is not None else None
     final_loss = [round(float(v), 4) for v in losses.detach().cpu().view(-1)]
 
     kernels = {}
@@ -307,7 +338,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         "config": {"workload": f"CPC-{cfg_name} (hidden {cfg['hidden']}, {cfg['ar']} x{cfg['layers']}, nPredicts "
                                f"{cfg['npred']}, {cfg['nneg']} negatives, {('multi-head ' if cfg.get('multihead') else '') + cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
                                f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
-                                                         if args.dedup else
+                                                         if dedup else
                                                          "reference trainStep semantics (encoder+AR on 2b windows), ")
                                + "fwd+bwd+allreduce+Adam",
                    "windows_per_gpu": args.batch, "global_batch": world * args.batch,
@@ -315,10 +346,10 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                    "inputs": "x = 0.05 randn, generator seed 1000 + rank; criterion MT19937 stream seed 1234 + rank; model "
                              "init torch.manual_seed(0) on every rank (SURVEY 8d's recipe with per-rank shards)"},
     }
-    default_workload = args.batch == 64 and not args.dedup
+    default_workload = args.batch == 64 and not dedup
     if prof and roof in kernels:
         planes = roof == "gemm_planes_nt"
-        flops, launches = (planes_nt_algorithmic_flops if planes else gemm_nt_algorithmic_flops)(args.batch, cfg, args.dedup)
+        flops, launches = (planes_nt_algorithmic_flops if planes else gemm_nt_algorithmic_flops)(args.batch, cfg, dedup)
         k = kernels[roof]
         achieved = flops / (k["ms_per_step"] * 1e-3) / 1e12
         terms = 3 if (planes and cfg.get("gemm_mode", 0) == 2) else 6
@@ -350,6 +381,10 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                                       "traffic": measured_traffic(sim_kernel + ":" + cfg_name) if default_workload else None}
     out["kernels"] = kernels
     out["_gradient_bytes"] = 4 * opt.flat_grad.numel()
+    out["_comm"] = {"early_bytes": 4 * sum(hi - lo for lo, hi in dp.early), "late_bytes": 4 * sum(hi - lo for lo, hi in dp.late)
+                    if dp.early else 4 * opt.flat_grad.numel(),
+                    "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
+                    "rank_ms_per_step_min": round(rank_ms[0], 3), "rank_ms_per_step_max": round(rank_ms[1], 3)}
     if cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, cpu_seconds)
     del model, crit, opt, dp, x
@@ -463,17 +498,22 @@ def main():
             comm["env"] = {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE",
                                                           "HSA_ENABLE_IPC_MODE_LEGACY")}
         comm["gradient_bytes"] = out.pop("_gradient_bytes", None)
+        # what the exchange costs a step: `exposed_ms_per_step` = time the compute stream is held between the start of the late
+        # (encoder-slice) all-reduce and the end of the waits for the early ones, from events on that stream (max over ranks);
+        # early / late bytes = what is reduced under the encoder's backward / after it; per-rank step times: min and max
+        comm.update(out.pop("_comm", {}))
         comm["overlap"] = "criterion + context-network slices reduced under the encoder's backward" if (
             use_dist and not os.environ.get("CPC_BENCH_NO_OVERLAP")) else "one blocking all-reduce" if use_dist else None
         out["comm"] = comm
     also = args.also
     if also is None:
-        also = "large,transformer,small_3term" if (world == 1 and args.config == "small" and not args.no_prof) else ""
+        also = "large,transformer,small_3term,small_dedup" if (world == 1 and args.config == "small" and not args.no_prof) else ""
     others = []
     for name in [n for n in also.split(",") if n]:
         rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
         if rec is not None:
             rec.pop("_gradient_bytes", None)
+            rec.pop("_comm", None)
             others.append(rec)
     if rank == 0:
         if others:

@@ -118,6 +118,8 @@ static inline int coop_cu_count()
 int *coop_error_word();                         // device-visible address of the word (nullptr: allocation failed)
 int coop_error_take(const char *where);         // host: CPC_OK, or CPC_ERR_HIP (message set, word cleared)
 int coop_fault_injection();                     // tests: CPC_COOP_FAULT=1 makes member 0 of group 0 withhold one publish
+void coop_count_launch();                       // every cooperative recurrent launch is counted (cpc_coop_launches)
+long coop_launches();
 enum { COOP_ERR_FWD_WAIT = 1, COOP_ERR_BWD_WAIT = 2, COOP_ERR_NONFINITE_GRAD = 3 };     // 3: reported by the Adam kernel (rowops.hip)
 __device__ __forceinline__ void coop_report(int *err, int code)
 {

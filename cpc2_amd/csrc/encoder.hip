@@ -1303,19 +1303,24 @@ extern "C" size_t cpc_encoder_scratch_bytes(int n_windows, int length, int hidde
 extern "C" int cpc_encoder_saved_layout(int n_windows, int length, int hidden, int layer, long *out)
 {
     cpc::EncLayout e;
-    if (layer < 1 || layer > 4 || out == nullptr) { cpc::set_error("cpc_encoder_saved_layout: layer must be 1..4 and out non-null"); return CPC_ERR_INVALID; }
+    if (layer < 0 || layer > 4 || out == nullptr) { cpc::set_error("cpc_encoder_saved_layout: layer must be 0..4 and out non-null"); return CPC_ERR_INVALID; }
     char *const base = reinterpret_cast<char *>(uintptr_t(1) << 20);          // never dereferenced: offsets only
     CPC_TRY(cpc::enc_layout(e, n_windows, length, hidden, base, nullptr));
-    out[0] = (long)(reinterpret_cast<const char *>(e.Xh[layer]) - base);
-    out[1] = (long)(reinterpret_cast<const char *>(e.rstd[layer]) - base);
-    out[2] = e.Rv[layer];
+    for (int i = 0; i < 10; ++i) out[i] = 0;
+    out[0] = out[1] = out[4] = -1;
     out[3] = e.L[layer + 1];
-    out[4] = -1; out[5] = out[6] = out[7] = 0;
+    if (layer >= 1) {
+        out[0] = (long)(reinterpret_cast<const char *>(e.Xh[layer]) - base);
+        out[1] = (long)(reinterpret_cast<const char *>(e.rstd[layer]) - base);
+        out[2] = e.Rv[layer];
+    }
     if (e.planes && layer < 4) {
         out[4] = (long)(reinterpret_cast<const char *>(e.Yp[layer]) - base);
         out[5] = e.Yplane[layer];
         out[6] = e.Yrts[layer];
         out[7] = cpc::log2i(cpc::kConv[layer + 1].s);
+        out[8] = e.R[layer];
+        out[9] = cpc::kConv[layer + 1].p;
     }
     return CPC_OK;
 }

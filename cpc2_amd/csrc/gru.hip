@@ -984,6 +984,7 @@ template <int H, int NB> static bool mfma_fits_bwd() { static const bool f = coo
 
 template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
+    coop_count_launch();
     const bool mm = mfma_wanted(H, nb, false);
     if (nb == 1) { if (mm && mfma_fits_fwd<H, 1>()) hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 1>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca); }
     else if (nb == 2) { if (mm && mfma_fits_fwd<H, 2>()) hipLaunchKernelGGL((gru_fwd_mfma_kernel<H, 2>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca); }
@@ -992,6 +993,7 @@ template <int H> static void launch_coop_fwd(int nb, dim3 grid, hipStream_t st, 
 }
 template <int H> static void launch_coop_bwd(int nb, dim3 grid, hipStream_t st, const GruCoopArgs &ca)
 {
+    coop_count_launch();
     const bool mm = mfma_wanted(H, nb, true);
     if (nb == 1) { if (mm && mfma_fits_bwd<H, 1>()) hipLaunchKernelGGL((gru_bwd_mfma_kernel<H, 1>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca); }
     else if (nb == 2) { if (mm && mfma_fits_bwd<H, 2>()) hipLaunchKernelGGL((gru_bwd_mfma_kernel<H, 2>), grid, dim3(512), 0, st, ca); else hipLaunchKernelGGL((gru_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca); }

@@ -532,6 +532,7 @@ template <int H> static bool lstm_coop_bwd_fits(int nb, unsigned grid, int n_cus
 }
 template <int H> static void launch_lstm_coop_fwd(int nb, dim3 grid, hipStream_t st, const LstmCoopArgs &ca)
 {
+    coop_count_launch();
     if (nb == 1) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
     else if (nb == 2) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
     else if (nb == 4) hipLaunchKernelGGL((lstm_fwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);
@@ -539,6 +540,7 @@ template <int H> static void launch_lstm_coop_fwd(int nb, dim3 grid, hipStream_t
 }
 template <int H> static void launch_lstm_coop_bwd(int nb, dim3 grid, hipStream_t st, const LstmCoopArgs &ca)
 {
+    coop_count_launch();
     if (nb == 1) hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 1>), grid, dim3(512), 0, st, ca);
     else if (nb == 2) hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 2>), grid, dim3(512), 0, st, ca);
     else if (nb == 4) hipLaunchKernelGGL((lstm_bwd_coop_kernel<H, 4>), grid, dim3(512), 0, st, ca);

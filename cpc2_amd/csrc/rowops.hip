@@ -63,6 +63,10 @@ int *coop_error_word()
     });
     return g_err_dev;
 }
+static std::atomic<long> g_coop_launches{0};
+void coop_count_launch() { g_coop_launches.fetch_add(1, std::memory_order_relaxed); }
+long coop_launches() { return g_coop_launches.load(std::memory_order_relaxed); }
+
 int coop_error_take(const char *where)
 {
     if (g_err_host == nullptr) return CPC_OK;
@@ -434,3 +438,7 @@ extern "C" int cpc_async_error_check(cpc_stream_t stream)
     CPC_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return cpc::coop_error_take("cpc_async_error_check");
 }
+
+// Cooperative recurrent launches (GRU / LSTM kernels that need every workgroup resident) issued by this process so far: the
+// data-parallel glue asserts its collectives are ordered behind them (cpc2_amd/train.py, DataParallelContext.attach)
+extern "C" long cpc_coop_launches(void) { return cpc::coop_launches(); }

@@ -238,9 +238,12 @@ class DataParallelContext:
     ("pre": view = flat_grad[lo:hi] as this rank computed it) and after the last one of a step ("post": the whole
     buffer of sums) -- the equivalence tests clone what they see there (tests/dp_job.py)."""
 
-    def __init__(self, optimizer, early_params=None, overlap=True, trace=None):
+    def __init__(self, optimizer, early_params=None, overlap=True, trace=None, timing=False):
         self.opt = optimizer
         self.trace = trace
+        self.timing = timing                    # bench.py: events around the part of a step the exchange holds the stream for
+        self._spans = []
+        self._coop_seen = self._coop_at_attach = None
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
         self.early, self.late, self._pending, self._fired = [], [], [], False
@@ -282,6 +285,30 @@ class DataParallelContext:
             self.trace("pre", lo, hi, view)
         return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
 
+    # ---- what the exchange costs a step (bench.py's `comm.exposed_ms_per_step`)
+    def timing_reset(self):
+        self._spans = []
+
+    def timing_read(self):
+        """Mean milliseconds per reduce_and_step() during which the compute stream was held by the exchange (from the start of
+        the late all-reduce to the end of the waits for the early ones), or None without a process group / timing."""
+        if not (self.active and self.timing and self._spans):
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._spans) / len(self._spans)
+
+    def _span(self):
+        if not (self.timing and self.opt.flat_grad.is_cuda):
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    @staticmethod
+    def _coop_launches():
+        """Cooperative recurrent launches of this process so far (cpc2_hip.h, cpc_coop_launches)."""
+        return int(_lib.load().cpc_coop_launches())
+
     def attach(self, encoder_output):
         """Register the hook that starts the early reductions when the gradient of `encoder_output` is ready (everything
         downstream of the encoder has then written its parameter gradients)."""
@@ -291,24 +318,42 @@ class DataParallelContext:
         if self._fired:
             raise RuntimeError("DataParallelContext: a backward pass has already reduced the early gradient slices of this "
                                "step; call reduce_and_step() before the next forward pass (one backward pass per step)")
+        # Cooperative recurrent kernels (GRU / LSTM at hidden 256 / 512) need EVERY workgroup resident; a collective's kernels
+        # share the device.  The schedule keeps the two apart by stream order: the early all-reduce is issued behind the recurrent
+        # backward (it waits for everything the compute stream holds at that point), and reduce_and_step() makes the compute
+        # stream wait for every collective before the next step's forward pass.  The first half is asserted here: if the forward
+        # pass of this step launched cooperative kernels, the backward pass must have launched its own before the hook fires.
+        on_gpu = self.opt.flat_grad.is_cuda
+        now = self._coop_launches() if on_gpu else 0
+        fwd_coop = now - (self._coop_seen if self._coop_seen is not None else now)
+        self._coop_at_attach = now
 
         def start(_grad):
             if not self._fired:                 # once per backward pass
                 self._fired = True
+                if on_gpu and fwd_coop > 0 and self._coop_launches() == self._coop_at_attach:
+                    raise RuntimeError("DataParallelContext: the early all-reduce would be issued BEFORE the cooperative recurrent "
+                                       "backward of this step (a collective's kernels beside a kernel that needs every "
+                                       "workgroup resident): attach() must be given the encoder output, upstream of the context network")
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.early)     # a gradient autograd did not write in place (accumulation)
                 self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
         encoder_output.register_hook(start)
 
     def reduce_and_step(self):
+        if self.active and self.opt.flat_grad.is_cuda:
+            self._coop_seen = self._coop_launches()              # (the next step's forward launches count from here)
         if self.active:
             if self._fired and self._pending:
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.late)      # (the early slices hold SUMS by now)
+                t0 = self._span()
                 for lo, hi in self.late:
                     self._all_reduce(lo, hi)
                 for work in self._pending:
                     work.wait()
+                if t0 is not None:
+                    self._spans.append((t0, self._span()))
                 if self.trace is not None:
                     self.trace("post", 0, self.opt.flat_grad.numel(), self.opt.flat_grad)
                 # the optimiser must not take a stray early gradient for the reduced one again
@@ -324,7 +369,10 @@ class DataParallelContext:
                 return
             if getattr(self.opt, "direct_grads", False):
                 self.opt._gather_stray_grads()
+            t0 = self._span()
             self._all_reduce(0, self.opt.flat_grad.numel())
+            if t0 is not None:
+                self._spans.append((t0, self._span()))
             if self.trace is not None:
                 self.trace("post", 0, self.opt.flat_grad.numel(), self.opt.flat_grad)
             self._pending, self._fired = [], False

@@ -57,6 +57,10 @@ const char *cpc_last_error(void);
  * synchronises `stream`, then reports and clears it.  CPC_COOP_FAULT=1 in the environment (tests) makes one member
  * withhold one publish so that its group times out. */
 int cpc_async_error_check(cpc_stream_t stream);
+/* Cooperative recurrent launches (the GRU / LSTM kernels at hidden 256 / 512 that need every workgroup resident at once)
+ * issued by this process so far.  The data-parallel glue (train.py:523-527's role) checks with it that a gradient all-reduce
+ * is never issued between a step's forward and backward recurrent launches. */
+long cpc_coop_launches(void);
 int cpc_prof_enable(int on);
 int cpc_prof_read(const char *name, double *total_ms, long *count);
 
@@ -145,11 +149,14 @@ int cpc_encoder_forward(const float *x, const float *const *params, float *z, vo
 int cpc_encoder_backward(const float *x, const float *const *params, const float *dz, void *saved,
                          void *scratch, float *const *grads, int n_windows, int length, int hidden,
                          float eps, cpc_stream_t stream);
-/* Inspection (tests only; the layout of `saved` is otherwise private): what the forward pass keeps of layer 1..4 --
- * the ChannelNorm of model.py:52-60 as (xhat, rstd) and, at hidden 256 / 512, its ReLU'd output as the next layer's input
- * planes.  out[0] byte offset of xhat [n_windows * out[2]][hidden] f32 (row n * out[2] + t, t < out[3] valid frames),
- * out[1] byte offset of rstd [n_windows * out[2]] f32, out[4] byte offset of the three bf16 planes of the layer's output
- * (-1: stored as f32, or layer 4), out[5] elements per plane, out[6] rows per phase, out[7] log2 of the reading stride. */
+/* Inspection (tests only; the layout of `saved` is otherwise private): what the forward pass keeps of layer 0..4 --
+ * the ChannelNorm of model.py:52-60 as (xhat, rstd) (layers 1..4) and, at hidden 256 / 512, the layer's ReLU'd output as the
+ * next layer's input planes (layers 0..3).  out[10]:
+ *   [0] byte offset of xhat [n_windows * out[2]][hidden] f32 (row n * out[2] + t, t < out[3] valid frames; -1: layer 0),
+ *   [1] byte offset of rstd [n_windows * out[2]] f32 (-1: layer 0), [2] rows per window, [3] frames per window,
+ *   [4] byte offset of the three bf16 planes of the layer's output (-1: stored as f32, or layer 4), [5] elements per plane,
+ *   [6] rows per phase, [7] log2 of the reading stride s; channel ch of frame t of window n is element
+ *   ((((ch / 16) << [7]) + (R & (s - 1))) * [6] + (R >> [7])) * 16 + ch % 16 with R = n * [8] + [9] + t. */
 int cpc_encoder_saved_layout(int n_windows, int length, int hidden, int layer, long *out);
 
 /* ------------------------------------------------------------------------------------------

@@ -36,12 +36,21 @@ def channel_norm(x, weight, bias, eps=1e-5):
     return y
 
 
-def encoder_forward(x, p, prefix="", return_all=False):
-    """model.py:102-108.  x [N, 1, L] -> [N, H, L/160]; relu(norm_i(conv_i(.)))."""
+def encoder_forward(x, p, prefix="", return_all=False, masks=None, pre_out=None):
+    """model.py:102-108.  x [N, 1, L] -> [N, H, L/160]; relu(norm_i(conv_i(.))).
+
+    masks (test infrastructure): five 0/1 tensors shaped like the layer outputs; layer i then computes norm_i(.) * masks[i]
+    instead of relu(norm_i(.)) -- the same function wherever the mask is the sign of the pre-activation, with the ReLU
+    DECISIONS taken from somewhere else (an fp32 evaluation decides a pre-activation within rounding of zero the other way;
+    the gradients below that element then differ by whole terms, which says nothing about the arithmetic under test).
+    pre_out: a list that receives the five pre-activations (detached)."""
     outs = []
     for i, (_k, s, pad) in enumerate(ENCODER_GEOMETRY):
         x = F.conv1d(x, p[f"{prefix}conv{i}.weight"], p[f"{prefix}conv{i}.bias"], stride=s, padding=pad)
-        x = torch.relu(channel_norm(x, p[f"{prefix}batchNorm{i}.weight"], p[f"{prefix}batchNorm{i}.bias"]))
+        x = channel_norm(x, p[f"{prefix}batchNorm{i}.weight"], p[f"{prefix}batchNorm{i}.bias"])
+        if pre_out is not None:
+            pre_out.append(x.detach())
+        x = torch.relu(x) if masks is None else x * masks[i].to(x.dtype)
         outs.append(x)
     return outs if return_all else x
 

@@ -29,3 +29,10 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
     ratio = dist["ms_per_step"] / plain["ms_per_step"]
     # measured 1.02-1.03 (hooks + two collectives of one rank); the defect this guards against measured 1.45
     assert ratio < 1.2, f"process-group mode {dist['ms_per_step']} ms per step against {plain['ms_per_step']} plain"
+    # the fields an 8-GPU run will be read by (there is no multi-GPU node to measure a scaling curve on): what the exchange holds
+    # the compute stream for per step -- with one rank the wire costs nothing, so this is the floor of the collectives themselves
+    comm = dist["comm"]
+    assert comm["early_bytes"] > 0 and comm["late_bytes"] > 0 and comm["early_bytes"] + comm["late_bytes"] == comm["gradient_bytes"]
+    assert comm["exposed_ms_per_step"] is not None and 0 <= comm["exposed_ms_per_step"] < 0.2, comm
+    assert comm["rank_ms_per_step_min"] <= comm["rank_ms_per_step_max"] <= dist["ms_per_step"] * 1.01
+    assert plain["comm"]["exposed_ms_per_step"] is None

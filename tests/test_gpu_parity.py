@@ -358,25 +358,70 @@ def test_encoder_vs_oracle_fp64(hidden, n, length):
     assert tuple(out.shape) == tuple(ref.shape)
     assert_close(out, ref, 2e-5, "encoder output")
     (out * gout.to(DEV)).sum().backward()
-    # Many windows: the gradients below a layer are conditioned by that layer's ReLU decisions, and a handful of the 1e7
-    # pre-activations fall the other way in ANY fp32 evaluation than in fp64, each flipping a gradient term of sums that cancel
-    # to a small fraction of their terms.  The yardstick is therefore computed HERE, not quoted: the same oracle run in fp32
-    # (plain torch on the CPU) against its own fp64 run, per parameter; this path may be off by at most three times that (and
-    # never by more than the coarse 2e-2 gate; at few windows by the fixed 2e-4).  The saved statistics themselves are pinned
-    # directly by test_fused_norm_epilogue_saves_the_same_state_as_the_norm_kernel.
-    yard = {}
-    if n > 16:
-        p32 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-        ref32 = O.encoder_forward(x, p32, "gEncoder.")
-        (ref32 * gout).sum().backward()
-        for name, _p in enc.named_parameters():
-            yard[name] = rel_err(p32["gEncoder." + name].grad, p64["gEncoder." + name].grad)
+    # Many windows: the gradients below a layer are conditioned by that layer's ReLU decisions.  Of ~6e7 pre-activations a
+    # handful lie within fp32 rounding of zero and fall the other way in ANY fp32 evaluation than in fp64; each such decision
+    # changes the gradients below it by whole terms of sums that (under a random upstream gradient) cancel to ~1 / sqrt(terms)
+    # of their terms: one decision in layer 0 moves conv0.weight.grad by ~1e-3 of its largest element.  That says nothing about
+    # the arithmetic, so it is taken out of the comparison instead of being tolerated: the kernels' own ReLU decisions are read
+    # back (the layer outputs the forward pass keeps: cpc_encoder_saved_layout) and the fp64 oracle is differentiated WITH THOSE
+    # decisions -- then every gradient must agree to 5e-5 (measured <= 1.0e-5 at 43 / 44 windows with 1 / 3 decisions that differ,
+    # each of which alone accounts for the 7e-4 .. 7e-3 of the unconditioned comparison).  Separately: the decisions differ
+    # from fp64's own in at most 1e-6 of the elements, and only where the fp64 pre-activation is within 1e-5 of zero.  The
+    # unconditioned comparison stays as a coarse end-to-end gate (2e-2).
+    if n <= 16 or hidden % 256 != 0:
+        for name, p in enc.named_parameters():
+            assert_close(p.grad, p64["gEncoder." + name].grad, 2e-4, f"grad {name}")
+        return
     for name, p in enc.named_parameters():
-        tol = 2e-4
-        if n > 16:
-            tol = min(2e-2, max(2e-4, 3.0 * yard[name]))
-            print(f"{name}: fp32 oracle {yard[name]:.2e}, this path {rel_err(p.grad, p64['gEncoder.' + name].grad):.2e}, bar {tol:.2e}")
-        assert_close(p.grad, p64["gEncoder." + name].grad, tol, f"grad {name}")
+        assert rel_err(p.grad, p64["gEncoder." + name].grad) <= 2e-2, f"grad {name} (coarse gate)"
+    masks = _kernel_relu_decisions(hidden, params, x)
+    pm = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    pre = []
+    refm = O.encoder_forward(x.double(), pm, "gEncoder.", masks=masks, pre_out=pre)
+    (refm * gout.double()).sum().backward()
+    flips = 0
+    for i, (m, y) in enumerate(zip(masks, pre)):
+        diff = m.bool() != (y > 0)
+        flips += int(diff.sum())
+        assert float(diff.float().mean()) <= 1e-6, f"layer {i}: {int(diff.sum())} ReLU decisions differ from the fp64 oracle's"
+        if diff.any():
+            worst = float(y[diff].abs().max() / y.abs().max())
+            assert worst <= 1e-5, f"layer {i}: a pre-activation of relative size {worst:.2e} was decided the other way"
+    print(f"ReLU decisions that differ from fp64's: {flips}")
+    for name, p in enc.named_parameters():
+        print(f"{name}: unconditioned {rel_err(p.grad, p64['gEncoder.' + name].grad):.2e}, same decisions {rel_err(p.grad, pm['gEncoder.' + name].grad):.2e}")
+    for name, p in enc.named_parameters():
+        assert_close(p.grad, pm["gEncoder." + name].grad, 5e-5, f"grad {name} (the kernels' ReLU decisions)")
+
+
+def _kernel_relu_decisions(hidden, params, x):
+    """The 0/1 masks [N, H, L_i] of the five ReLUs as the HIP forward pass decided them, read from what it keeps: the outputs
+    of layers 0..3 are the next layers' input planes in `saved` (cpc_encoder_saved_layout), layer 4's is z."""
+    lib = _lib.load()
+    n, _one, length = x.shape
+    plist = [v.to(DEV).contiguous() for v in params.values()]
+    xd = x.to(DEV)
+    frames = lib.cpc_encoder_frames(length)
+    z = torch.empty(n, frames, hidden, device=DEV)
+    saved = torch.zeros(lib.cpc_encoder_saved_bytes(n, length, hidden), dtype=torch.uint8, device=DEV)
+    scratch = torch.empty(lib.cpc_encoder_scratch_bytes(n, length, hidden), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cpc_encoder_forward(_lib.ptr(xd), _lib.ptr_array(plist), _lib.ptr(z), _lib.ptr(saved), _lib.ptr(scratch), n, length,
+                                       hidden, 1e-5, _lib.stream_ptr(xd.device)), "encoder_forward")
+    masks = []
+    for layer in range(4):
+        lay = (ctypes.c_long * 10)()
+        _lib.check(lib.cpc_encoder_saved_layout(n, length, hidden, layer, lay), "saved_layout")
+        _xo, _ro, _rv, lv, po, plane, rts, sshift, rows_next, halo = list(lay)
+        assert po >= 0
+        planes = saved[po:po + 2 * 3 * plane].view(torch.bfloat16).view(3, plane)
+        ch = torch.arange(hidden, device=DEV).view(1, 1, hidden)
+        R = (torch.arange(n, device=DEV).view(n, 1, 1) * rows_next + halo + torch.arange(lv, device=DEV).view(1, lv, 1))
+        idx = ((((ch // 16) << sshift) + (R & ((1 << sshift) - 1))) * rts + (R >> sshift)) * 16 + ch % 16      # [n, lv, hidden]
+        y = (planes[0][idx].float() + planes[1][idx].float()) + planes[2][idx].float()
+        masks.append((y > 0).permute(0, 2, 1).contiguous().cpu())
+        del idx, y, R
+    masks.append((z > 0).permute(0, 2, 1).contiguous().cpu())
+    return masks
 
 
 _ENC_FORMS_SCRIPT = """
@@ -440,9 +485,9 @@ _lib.check(lib.cpc_encoder_forward(_lib.ptr(x), _lib.ptr_array(params), _lib.ptr
 torch.cuda.synchronize()
 out = {{"z": z.cpu()}}
 for layer in (1, 2, 3):
-    lay = (ctypes.c_long * 8)()
+    lay = (ctypes.c_long * 10)()
     _lib.check(lib.cpc_encoder_saved_layout(n, length, hidden, layer, lay), "saved_layout")
-    xo, ro, rv, lv, po, plane, rts, sshift = list(lay)
+    xo, ro, rv, lv, po, plane, rts, sshift, _rn, _halo = list(lay)
     xh = saved[xo:xo + 4 * n * rv * hidden].view(torch.float32).view(n, rv, hidden)[:, :lv]
     rstd = saved[ro:ro + 4 * n * rv].view(torch.float32).view(n, rv)[:, :lv]
     out[f"xhat{{layer}}"], out[f"rstd{{layer}}"] = xh.cpu(), rstd.cpu()
