@@ -42,6 +42,14 @@ constexpr int PT_PIECE = 1024;                    // bytes: 32 rows x 16 k x bf1
 constexpr int PT_STAGE = 48 * PT_PIECE;           // A: 3 planes x 8 blocks, B: 3 planes x 8 blocks
 constexpr int PT_RING = 3;
 constexpr int PT_LDS = PT_RING * PT_STAGE;        // 147456 bytes
+// "Pair" form of the NT kernel's K loop (a k = 2s convolution, forward or backward data): the taps j and j + s of a channel
+// chunk read the SAME rows of the signal one row apart, so the A tile of the pair is staged ONCE -- 257 rows: 8 blocks + the row
+// behind the tile as a ninth block -- and the second tap's fragments are read one row further down.  A double stage = A (27
+// pieces) + B of tap j (24) + B of tap j + s (24) = 75 pieces instead of 96: an LDS-DMA piece costs the SIMD's matrix pipe
+// ~60 cycles whichever wave issues it (measured: profiles/r04_planes_levers.md), so requests per MFMA are what bounds the loop.
+constexpr int PP_A = 27 * PT_PIECE;
+constexpr int PP_DS = 75 * PT_PIECE;              // 76800 bytes; ring of two double stages
+constexpr int PP_LDS = 2 * PP_DS;                 // 153600 bytes
 
 struct PlanesSide {                               // device view of a PlanesOperand
     const bf16_t *p; long plane;
@@ -67,7 +75,7 @@ struct PlanesNTArgs {
     float *slabs;                                 // K split: partial product of blockIdx.y -> slabs + blockIdx.y * slab_rows * N
     long slab_rows;                               // output rows (after the row map)
     PlanesNormOut norm;                           // NORM kernels only (N == 256, no K split)
-    int dbg;                                      // probes: 1 no loads after the prologue, 2 no MFMAs, 8 clock stamps
+    int dbg;                                      // probes: 1 no loads after the prologue, 2 no MFMAs, 8 clock stamps, 16 half the A requests, 32 a third fewer fragment reads
     int opt;                                      // schedule switches (planes_opt()): 1 waves 4-7 request half a stage later, 2 s_setprio 1 for waves 4-7
     unsigned long long *stamps;                   // dbg & 8: [workgroup][8] = memtime, memrealtime at loop start and end, ...
 };
@@ -171,8 +179,16 @@ __device__ __forceinline__ void split4_terms(const float (&a)[4], uint2 (&w)[3])
     }
 }
 
-template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
+template <int BLK> __device__ __forceinline__ void read_a_pair(frag_t (&a)[3], unsigned fa)
 {
+    a[0] = lds_frag<false, BLK * PT_PIECE>(fa);
+    a[1] = lds_frag<false, (9 + BLK) * PT_PIECE>(fa);
+    a[2] = lds_frag<false, (18 + BLK) * PT_PIECE>(fa);
+}
+
+template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false> __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(PlanesNTArgs p)
+{
+    static_assert(!(PAIR && TN), "the pair form is an NT form");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const unsigned long long rentry = (p.dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -236,6 +252,10 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
     }
     const unsigned lds0 = (unsigned)(unsigned long long)lds;
     constexpr bool noload = (DBG & 1) != 0, nomma = (DBG & 2) != 0;     // probes only
+    // probes with wrong numbers and valid timing: what a lever could win AT MOST, before building it.  DBG & 4: the A pieces of the
+    // odd stages are not requested (the L2 -> LDS traffic of a kernel that stages the A operand of a k = 2s convolution once per
+    // tap pair); DBG & 8: a third of the fragment reads is skipped (the LDS read traffic of 128 x 128 wave tiles)
+    constexpr bool half_a = (DBG & 4) != 0, fewer_reads = (DBG & 8) != 0;
     // stage t -> ring slot at byte offset `slot`: six pieces per wave, piece i of the stage requested by issue1<i>
     struct Src { unsigned dst; const char *ab, *bb; };
     auto stage_src = [&](int t, unsigned slot) {
@@ -258,7 +278,8 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
     auto issue = [&](int t, unsigned slot) {
         const Src q = stage_src(t, slot);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) issue1(q, i);
+        for (int i = 0; i < 6; ++i)
+            if (!(half_a && (t & 1) && i < 3)) issue1(q, i);
     };
 
     f32x16 acc[4][2];
@@ -269,6 +290,118 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    if constexpr (PAIR) {
+        // ---- pair form: double stage d = K steps 2d (tap j) and 2d + 1 (tap j + s) of a chunk; ring of two slots
+        const int nds = nst >> 1;
+        const unsigned fa_b = lds0 + lane * 16 + wr * 4 * PT_PIECE;                 // A fragments, tap j
+        const unsigned fs_b = fa_b + (r32 == 31 ? PT_PIECE - 31 * 16 : 16);         // tap j + s: one row down (row 31 -> row 0 of the next block)
+        const unsigned fj_b = lds0 + lane * 16 + PP_A + wc * 2 * PT_PIECE;          // B fragments of tap j; tap j + s: + 24 pieces
+        // the ninth A block: every lane the row behind the tile (row m0 + 255 of this sample, + 1), 16 bytes of it
+        const long m8 = m0 + PT_BM - 1, seg8 = m8 / p.A.segv;
+        const unsigned a_vo8 = (unsigned)(32 * (seg8 * p.A.seg_q + (m8 - seg8 * p.A.segv) + 1) + 16 * h);
+        struct SrcP { unsigned dst; const char *ab, *b0, *b1; };
+        auto src_pair = [&](int d, unsigned slot) {
+            SrcP q;
+            q.dst = lds0 + slot + wave * PT_PIECE;
+            q.ab = reinterpret_cast<const char *>(p.A.p) + 32 * chunk0(p.A, ks0 + 2 * d);
+            q.b0 = reinterpret_cast<const char *>(p.B.p) + 32 * chunk0(p.B, ks0 + 2 * d);
+            q.b1 = reinterpret_cast<const char *>(p.B.p) + 32 * chunk0(p.B, ks0 + 2 * d + 1);
+            return q;
+        };
+        // piece i of a double stage as wave `wave` requests it: 0-2 A planes, 3-5 B of tap j, 6-8 B of tap j + s, 9 (waves 0-2) the ninth A block of plane `wave`
+        auto issue_p = [&](const SrcP &q, int i) {
+            if (i < 3) glds16(q.dst + i * 9 * PT_PIECE, a_vo, q.ab + 2 * i * p.A.plane);
+            else if (i < 6) glds16(q.dst + PP_A + (i - 3) * 8 * PT_PIECE, b_vo, q.b0 + 2 * (i - 3) * p.B.plane);
+            else if (i < 9) glds16(q.dst + PP_A + (24 + (i - 6) * 8) * PT_PIECE, b_vo, q.b1 + 2 * (i - 6) * p.B.plane);
+            else if (wave < 3) glds16(lds0 + (q.dst - lds0 - wave * PT_PIECE) + (wave * 9 + 8) * PT_PIECE, a_vo8, q.ab + 2 * wave * p.A.plane);
+        };
+        {
+            const SrcP q0 = src_pair(0, 0);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) issue_p(q0, i);
+        }
+        if (nds > 1) {
+            const SrcP q1 = src_pair(1, PP_DS);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) issue_p(q1, i);
+            if (wave < 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        frag_t b0[2][3], b1[2][3], ax[3], ay[3];
+        read_b<false>(b0, fj_b);
+        read_a_pair<0>(ax, fa_b);
+        lds_wait9(ax, b0);
+        unsigned slot = 0;
+#define PT_SB __builtin_amdgcn_sched_barrier(0)
+        // one half of a double stage: `fa` addresses its A fragments (tap j: fa_b + slot, tap j + s: fs_b + slot), bc its B
+        // fragments; `fan` / `fbn` address the NEXT half's first A block and its B fragments (-> ax, bn).  last: the barrier that
+        // ends the double stage sits in front of row block 3.
+        // Requests: the slot of double stage d is free behind that barrier and has to be full at the next one, a whole double stage
+        // later.  A piece costs the SIMD ~60 cycles of matrix-pipe time wherever it is issued, but ten in a row also stop the wave
+        // that issues them for longer than its partner has MFMAs queued: they are spread -- the A pieces of double stage d + 2 between
+        // the MFMAs of this row block 3, the B pieces two at a time behind row blocks 0, 1, 2 of the next half (d + 1's first one).
+        auto half = [&](int d, unsigned fa, unsigned fan, unsigned fbn, frag_t (&bc)[2][3], frag_t (&bn)[2][3], const bool last) {
+            // first half of double stage d >= 1: the B pieces of double stage d + 1 (its A pieces went out in front of this half)
+            const bool breq = !last && d >= 1 && d + 1 < nds && !noload;
+            const SrcP qb = src_pair(breq ? d + 1 : 0, slot == 0 ? PP_DS : 0);
+            read_a_pair<1>(ay, fa);
+            PT_SB;
+            mma6<TERMS>(acc[0][0], acc[0][1], ax, bc, nomma);
+            PT_SB;
+            if (breq) { issue_p(qb, 3); issue_p(qb, 4); } PT_SB;
+            lds_wait3(ay);
+            read_a_pair<2>(ax, fa);
+            PT_SB;
+            mma6<TERMS>(acc[1][0], acc[1][1], ay, bc, nomma);
+            PT_SB;
+            if (breq) { issue_p(qb, 5); issue_p(qb, 6); } PT_SB;
+            lds_wait3(ax);
+            read_a_pair<3>(ay, fa);
+            PT_SB;
+            mma6<TERMS>(acc[2][0], acc[2][1], ax, bc, nomma);
+            PT_SB;
+            if (breq) { issue_p(qb, 7); issue_p(qb, 8); } PT_SB;
+            lds_wait3(ay);
+            bool req = false;
+            SrcP q = src_pair(0, slot);
+            if (last) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of double stage d + 1 (all it has in flight)
+                __builtin_amdgcn_s_barrier();                         // d + 1 has landed for everyone; everyone has read all of d
+                req = d + 2 < nds && !noload;
+                if (req) q = src_pair(d + 2, slot);
+            }
+            if (!nomma && TERMS == 6) { mma2<0>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+            bn[0][0] = lds_frag<false, 0>(fbn); bn[0][1] = lds_frag<false, 8 * PT_PIECE>(fbn); bn[0][2] = lds_frag<false, 16 * PT_PIECE>(fbn); PT_SB;
+            if (!nomma && TERMS == 6) { mma2<1>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+            bn[1][0] = lds_frag<false, PT_PIECE>(fbn); bn[1][1] = lds_frag<false, 9 * PT_PIECE>(fbn); bn[1][2] = lds_frag<false, 17 * PT_PIECE>(fbn); PT_SB;
+            if (!nomma && TERMS == 6) { mma2<2>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+            read_a_pair<0>(ax, fan); PT_SB;
+            if (req) { issue_p(q, 0); issue_p(q, 9); } PT_SB;
+            if (!nomma) { mma2<3>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+            if (req) { issue_p(q, 1); } PT_SB;
+            if (!nomma) { mma2<4>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+            if (req) { issue_p(q, 2); } PT_SB;
+            if (!nomma) { mma2<5>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
+            lds_wait9(ax, bn);
+        };
+#undef PT_SB
+        unsigned long long c0 = 0, r0 = 0;
+        if (p.dbg & 8) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+        for (int d = 0; d < nds; ++d) {
+            const unsigned nslot = slot == 0 ? PP_DS : 0;
+            half(d, fa_b + slot, fs_b + slot, fj_b + slot + 24 * PT_PIECE, b0, b1, false);
+            half(d, fs_b + slot, fa_b + nslot, fj_b + nslot, b1, b0, true);
+            slot = nslot;
+        }
+        if ((p.dbg & 8) && tid == 0) {
+            p.stamps[blockIdx.x * 8 + 0] = c0; p.stamps[blockIdx.x * 8 + 1] = r0;
+            p.stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            p.stamps[blockIdx.x * 8 + 4] = rentry;
+        }
+    } else {
     // fragment addresses inside a stage: A piece (plane, block wr * 4 + i), B piece 24 + (plane, block wc * 2 + j)
     const unsigned flane = TN ? h * 512 + ((lane >> 4) & 1) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8 : lane * 16;
     const unsigned fa0 = lds0 + flane + wr * 4 * PT_PIECE;
@@ -279,9 +412,11 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
     issue(1, PT_STAGE);
     if (nst > 2) {
         issue(2, 2 * PT_STAGE);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if constexpr (half_a) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (half_a) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     frag_t b0[2][3], b1[2][3], ax[3], ay[3];
@@ -301,7 +436,7 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
     if ((p.opt & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     unsigned slot = 0;                                                   // ring slot of stage t (byte offset)
 #define PT_SB __builtin_amdgcn_sched_barrier(0)
-    auto stage = [&](int t, frag_t (&bc)[2][3], frag_t (&bn)[2][3]) {
+    auto stage = [&](int t, frag_t (&bc)[2][3], frag_t (&bn)[2][3], const bool odd) {
         const unsigned fa = fa0 + slot;
         const unsigned nslot = slot == (PT_RING - 1) * PT_STAGE ? 0 : slot + PT_STAGE;
         const unsigned pslot = slot == 0 ? (PT_RING - 1) * PT_STAGE : slot - PT_STAGE;
@@ -315,21 +450,23 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
         read_a<TN, 2>(ax, fa);
         PT_SB;
         if (!nomma && TERMS == 6) { mma2<0>(acc[1][0], acc[1][1], ay, bc); mma2<1>(acc[1][0], acc[1][1], ay, bc); mma2<2>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
-        if (lreq) { issue1(ql, 0); issue1(ql, 1); } PT_SB;
+        if (lreq && !(half_a && odd)) { issue1(ql, 0); issue1(ql, 1); } PT_SB;    // (late waves request stage t + 2: same parity as t)
         if (!nomma) { mma2<3>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
-        if (lreq) { issue1(ql, 2); issue1(ql, 3); } PT_SB;
+        if (lreq) { if (!(half_a && odd)) issue1(ql, 2); issue1(ql, 3); } PT_SB;
         if (!nomma) { mma2<4>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
         if (lreq) { issue1(ql, 4); issue1(ql, 5); } PT_SB;
         if (!nomma) { mma2<5>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
         lds_wait3(ax);
-        read_a<TN, 3>(ay, fa);
+        if constexpr (!fewer_reads) read_a<TN, 3>(ay, fa);
         PT_SB;
         mma6<TERMS>(acc[2][0], acc[2][1], ax, bc, nomma);
         PT_SB;
         lds_wait3(ay);                          // every LDS read of stage t by this wave is done
         // (no branch may enclose an asm LDS read: hipcc would copy its destination registers at the join, before the wait)
-        if (t + 2 < nst && !noload) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 2 < nst && !noload) {
+            if (half_a && odd) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // (stage t + 2 stays in flight: odd like t, three pieces)
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // stage t + 1 has landed for everyone; everyone has read all of stage t
         // row block 3, with the requests for stage t + 3 and the reads of stage t + 1's first fragments BETWEEN its MFMAs:
         // the eight waves leave the barrier together, and an LDS-DMA piece holds a wave's issue for ~100 cycles
@@ -339,12 +476,12 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
         if (!nomma && TERMS == 6) { mma2<0>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
         bn[0][0] = lds_frag<TN, 0>(fbn); bn[0][1] = lds_frag<TN, 8 * PT_PIECE>(fbn); bn[0][2] = lds_frag<TN, 16 * PT_PIECE>(fbn); PT_SB;
         if (!nomma && TERMS == 6) { mma2<1>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
-        bn[1][0] = lds_frag<TN, PT_PIECE>(fbn); bn[1][1] = lds_frag<TN, 9 * PT_PIECE>(fbn); bn[1][2] = lds_frag<TN, 17 * PT_PIECE>(fbn); PT_SB;
+        if constexpr (!fewer_reads) { bn[1][0] = lds_frag<TN, PT_PIECE>(fbn); bn[1][1] = lds_frag<TN, 9 * PT_PIECE>(fbn); bn[1][2] = lds_frag<TN, 17 * PT_PIECE>(fbn); } PT_SB;
         if (!nomma && TERMS == 6) { mma2<2>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
         read_a<TN, 0>(ax, fan); PT_SB;
-        if (req) { issue1(q, 0); issue1(q, 1); } PT_SB;
+        if (req && !(half_a && !odd)) { issue1(q, 0); issue1(q, 1); } PT_SB;      // (stage t + 3 is odd when t is even)
         if (!nomma) { mma2<3>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
-        if (req) { issue1(q, 2); issue1(q, 3); } PT_SB;
+        if (req) { if (!(half_a && !odd)) issue1(q, 2); issue1(q, 3); } PT_SB;
         if (!nomma) { mma2<4>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
         if (req) { issue1(q, 4); issue1(q, 5); } PT_SB;
         if (!nomma) { mma2<5>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
@@ -355,13 +492,15 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false> __global__ __launc
     unsigned long long c0 = 0, r0 = 0;
     if (p.dbg & 8) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int t = 0; t < nst; t += 2) {
-        stage(t, b0, b1);
-        stage(t + 1, b1, b0);
+        stage(t, b0, b1, false);
+        stage(t + 1, b1, b0, true);
     }
     if ((p.dbg & 8) && tid == 0) {
         p.stamps[blockIdx.x * 8 + 0] = c0; p.stamps[blockIdx.x * 8 + 1] = r0;
         p.stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
         p.stamps[blockIdx.x * 8 + 4] = rentry;
+    }
+
     }
 
     // ---- epilogue: acc[i][j][e] is C[m][n], m = m0 + wr*128 + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wc*64 + j*32 + r32.
@@ -564,6 +703,20 @@ bool gemm_nt_planes_norm_ok(long M, int N, int K)
     return !off && gemm_mode() != 2 && gemm_nt_planes_ok(M, N, K) && N == PT_BN && nt_planes_splits(M, N, K) == 1;   // (mode 2: its own kernels)
 }
 
+// one instantiation: dynamic LDS attribute (once), launch
+template <int DBG, bool TN, int TERMS, bool NORM, bool PAIR> static int launch_planes(dim3 grid, const PlanesNTArgs &a, hipStream_t st)
+{
+    constexpr int bytes = PAIR ? PP_LDS : PT_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<DBG, TN, TERMS, NORM, PAIR>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_planes_kernel<DBG, TN, TERMS, NORM, PAIR>), grid, dim3(512), bytes, st, a);
+    return CPC_OK;
+}
+
 int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
                    const RowMap &map, hipStream_t st, const PlanesNormOut *norm)
 {
@@ -572,20 +725,6 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
                                     map.col_rows == 0 && norm->gamma && norm->beta && norm->rstd && norm->p && gemm_mode() != 2 &&
                                     reinterpret_cast<uintptr_t>(norm->p) % 8 == 0 && norm->plane % 4 == 0),
                 "gemm_nt_planes: the fused norm needs N == 256, no K split and a forward row map");
-    static bool attr_set = false;
-    if (!attr_set) {
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<1, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<2, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false, 3>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, false, 6, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        attr_set = true;
-    }
     PlanesNTArgs a{};
     CPC_TRY(side_of(A, a.A, "A"));
     CPC_TRY(side_of(B, a.B, "B"));
@@ -618,12 +757,31 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
         a.stamps = stamps;
     }
     const long blocks = (long)a.tiles_m * a.tiles_n;
+    // the pair form (A staged once per tap pair): an operand with tap pairs whose tiles do not straddle samples
+    static const bool no_pair = getenv("CPC_PLANES_NO_PAIR") != nullptr;
+    const bool pair = !no_pair && A.kshift >= 1 && a.A.segv % PT_BM == 0 && M % PT_BM == 0 && (a.kchunk / PT_BK) % 2 == 0;
+    const dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_PLANES_NT, st);
-    if ((a.dbg & 3) == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
-    else if ((a.dbg & 3) == 2) hipLaunchKernelGGL((gemm_planes_kernel<2, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
-    else if (norm != nullptr) hipLaunchKernelGGL((gemm_planes_kernel<0, false, 6, true>), dim3((unsigned)blocks, 1u), dim3(512), PT_LDS, st, a);
-    else if (gemm_mode() == 2) hipLaunchKernelGGL((gemm_planes_kernel<0, false, 3>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
-    else hipLaunchKernelGGL((gemm_planes_kernel<0, false>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), PT_LDS, st, a);
+    int rc = CPC_OK;
+    const int mode3 = gemm_mode() == 2;
+    const int sel = (a.dbg & 48) ? ((a.dbg & 48) >> 2) : (a.dbg & 3);                 // DBG template value of the probes
+    if (pair) {
+        if (sel == 1) rc = launch_planes<1, false, 6, false, true>(grid, a, st);
+        else if (sel == 2) rc = launch_planes<2, false, 6, false, true>(grid, a, st);
+        else if (norm != nullptr) rc = launch_planes<0, false, 6, true, true>(grid, a, st);
+        else if (mode3) rc = launch_planes<0, false, 3, false, true>(grid, a, st);
+        else rc = launch_planes<0, false, 6, false, true>(grid, a, st);
+    } else {
+        if (sel == 4) rc = launch_planes<4, false, 6, false, false>(grid, a, st);
+        else if (sel == 8) rc = launch_planes<8, false, 6, false, false>(grid, a, st);
+        else if (sel == 12) rc = launch_planes<12, false, 6, false, false>(grid, a, st);
+        else if (sel == 1) rc = launch_planes<1, false, 6, false, false>(grid, a, st);
+        else if (sel == 2) rc = launch_planes<2, false, 6, false, false>(grid, a, st);
+        else if (norm != nullptr) rc = launch_planes<0, false, 6, true, false>(grid, a, st);
+        else if (mode3) rc = launch_planes<0, false, 3, false, false>(grid, a, st);
+        else rc = launch_planes<0, false, 6, false, false>(grid, a, st);
+    }
+    if (rc != CPC_OK) return rc;
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");
     if (splits > 1) {
         const long total = a.slab_rows * N;
@@ -724,14 +882,6 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
         set_error("gemm_tn_planes: scratch too small (%zu < %zu)", scratch_bytes, (size_t)S * M * N * sizeof(float));
         return CPC_ERR_WORKSPACE;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        CPC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<0, true, 3>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS));
-        attr_set = true;
-    }
     PlanesNTArgs a{};
     a.TA = PlanesTNSide{A.p, A.plane, A.sshift, A.rts, A.tap0, A.C};
     a.TB = PlanesTNSide{B.p, B.plane, B.sshift, B.rts, B.tap0, B.C};
@@ -744,12 +894,9 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     a.xcd_remap = (!no_remap && S % 8 == 0 && (M / PT_BM) * (N / PT_BN) > 1) ? 1 : 0;
     {
         ProfScope prof(PROF_PLANES_TN, st);
-        if (gemm_mode() == 2)
-            hipLaunchKernelGGL((gemm_planes_kernel<0, true, 3>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
-                               st, a);
-        else
-            hipLaunchKernelGGL((gemm_planes_kernel<0, true>), dim3((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S), dim3(512), PT_LDS,
-                               st, a);
+        const dim3 grid((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S);
+        const int rc = gemm_mode() == 2 ? launch_planes<0, true, 3, false, false>(grid, a, st) : launch_planes<0, true, 6, false, false>(grid, a, st);
+        if (rc != CPC_OK) return rc;
     }
     CPC_CHECK_LAUNCH("gemm_planes_kernel (tn)");
     const long total = (long)M * N;
