@@ -666,7 +666,8 @@ class CPCUnsupersivedCriterion(BaseCriterion):
         else:
             losses, acc = _InfoNCEFn.apply(cFeature, zFull if defer is not None else encodedData, extIdx, quality_weighting,
                                            self.negativeSamplingExt, defer, *[p.weight for p in self.wPrediction.predictors])
-        losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
+        if self.nSkipped:                              # (a slice of nothing would still cost its backward a zero-fill and a copy)
+            losses, acc = losses[self.nSkipped:], acc[self.nSkipped:]
         return losses.view(1, -1), acc.view(1, -1)
 
     def _needs_modules(self):

@@ -120,7 +120,7 @@ int coop_error_take(const char *where);         // host: CPC_OK, or CPC_ERR_HIP 
 int coop_fault_injection();                     // tests: CPC_COOP_FAULT=1 makes member 0 of group 0 withhold one publish
 void coop_count_launch();                       // every cooperative recurrent launch is counted (cpc_coop_launches)
 long coop_launches();
-enum { COOP_ERR_FWD_WAIT = 1, COOP_ERR_BWD_WAIT = 2, COOP_ERR_NONFINITE_GRAD = 3 };     // 3: reported by the Adam kernel (rowops.hip)
+enum { COOP_ERR_FWD_WAIT = 1, COOP_ERR_BWD_WAIT = 2, COOP_ERR_NONFINITE_GRAD = 3, COOP_ERR_BAD_INDEX = 4 };     // 3: the Adam kernel (rowops.hip), 4: the criterion's index check (infonce.hip)
 __device__ __forceinline__ void coop_report(int *err, int code)
 {
     if (err != nullptr) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -676,11 +676,18 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
 // (norm_fwd_pl_kernel writes them itself; the product's fused epilogue -- gemm_nt_planes with a PlanesNormOut -- writes frames only.)
 __global__ void zero_plane_rows_kernel(PlaneOut o, long total_rows, int N, long rows_next, int halo, int lout, int chunks)
 {
-    const long r = (long)blockIdx.x * blockDim.y + threadIdx.y;          // signal row; threadIdx.x: (plane, chunk) pairs
-    if (r >= total_rows) return;
-    const long n = r / rows_next;
-    const int t = (int)(r - n * rows_next) - halo;
-    if (n < N && t >= 0 && t < lout) return;
+    // only the rows that are no frame are enumerated: rows_next - lout per sample (halo in front, the rest behind), then the slack
+    const long q = (long)blockIdx.x * blockDim.y + threadIdx.y;
+    const long hr = rows_next - lout, in_samples = (long)N * hr;
+    long r;
+    if (q < in_samples) {
+        const long n = q / hr;
+        const int j = (int)(q - n * hr);
+        r = n * rows_next + (j < halo ? j : lout + j);
+    } else {
+        r = (long)N * rows_next + (q - in_samples);
+        if (r >= total_rows) return;
+    }
     const long smask = (1L << o.sshift) - 1;
     for (int i = threadIdx.x; i < 3 * chunks * 2; i += blockDim.x) {
         const int pl = i / (chunks * 2), rem = i - pl * chunks * 2, c = rem >> 1, half = rem & 1;
@@ -859,8 +866,15 @@ __device__ __forceinline__ float bf16_up(unsigned short v) { return __uint_as_fl
 __global__ __launch_bounds__(256) void bwd_edge_kernel(const unsigned short *dup, long duplane, long durts, const unsigned short *wdp,
                                                        long wplane, float *dy, int H, int s, int p, int Rv, int Lout, int Lin)
 {
-    extern __shared__ float du[];                           // [H]
-    const int n = blockIdx.x / p, j = blockIdx.x - n * p;
+    // one workgroup per (sample n, phase j, 64 output channels); thread = (channel, quarter of the H / 16 chunks of the
+    // reduction): every load of a thread is issued before the first is used (a thread that walks all of K alone spends the
+    // kernel waiting for one dependent load after the other: 12 us per launch for 67 MFLOP), the four partial sums of a
+    // channel meet in LDS and are added in a fixed order
+    extern __shared__ float du[];                           // [H] + [4][64]
+    float *red = du + H;
+    const int quarters = H / 64;
+    const int cq = blockIdx.x % quarters, nj = blockIdx.x / quarters;
+    const int n = nj / p, j = nj - n * p;
     const long R = (long)n * Rv + Lout;                      // dU(L_out - 1) is stored one row down
     for (int c = threadIdx.x; c < H; c += 256) {
         const long off = ((long)(c >> 4) * durts + R) * 16 + (c & 15);
@@ -868,21 +882,37 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const unsigned short *dup
     }
     __syncthreads();
     const int rows = s * H;
-    for (int ci = threadIdx.x; ci < H; ci += 256) {
-        float acc = 0.f;
-        for (int c = 0; c < H / 16; ++c) {
+    const int ci = cq * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
+    const int per = H / 64;                                  // chunks per thread (H / 16 chunks, 4 quarters)
+    float acc = 0.f;
+    for (int c0 = 0; c0 < per; c0 += 4) {
+        uint4 w[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = kq * per + c0 + u;
             const long off = ((long)(2 * c) * rows + (long)j * H + ci) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                w[u][2 * pl] = *reinterpret_cast<const uint4 *>(wdp + pl * wplane + off);
+                w[u][2 * pl + 1] = *reinterpret_cast<const uint4 *>(wdp + pl * wplane + off + 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = kq * per + c0 + u;
             unsigned short w0[16], w1[16], w2[16];
-            *reinterpret_cast<uint4 *>(w0) = *reinterpret_cast<const uint4 *>(wdp + off);
-            *reinterpret_cast<uint4 *>(w0 + 8) = *reinterpret_cast<const uint4 *>(wdp + off + 8);
-            *reinterpret_cast<uint4 *>(w1) = *reinterpret_cast<const uint4 *>(wdp + wplane + off);
-            *reinterpret_cast<uint4 *>(w1 + 8) = *reinterpret_cast<const uint4 *>(wdp + wplane + off + 8);
-            *reinterpret_cast<uint4 *>(w2) = *reinterpret_cast<const uint4 *>(wdp + 2 * wplane + off);
-            *reinterpret_cast<uint4 *>(w2 + 8) = *reinterpret_cast<const uint4 *>(wdp + 2 * wplane + off + 8);
+            *reinterpret_cast<uint4 *>(w0) = w[u][0]; *reinterpret_cast<uint4 *>(w0 + 8) = w[u][1];
+            *reinterpret_cast<uint4 *>(w1) = w[u][2]; *reinterpret_cast<uint4 *>(w1 + 8) = w[u][3];
+            *reinterpret_cast<uint4 *>(w2) = w[u][4]; *reinterpret_cast<uint4 *>(w2 + 8) = w[u][5];
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc = fmaf(du[c * 16 + e], (bf16_up(w0[e]) + bf16_up(w1[e])) + bf16_up(w2[e]), acc);
         }
-        dy[((long)n * Lin + Lin - p + j) * H + ci] = acc;
+    }
+    red[kq * 64 + (threadIdx.x & 63)] = acc;
+    __syncthreads();
+    if (kq == 0) {
+        const int l = threadIdx.x;
+        dy[((long)n * Lin + Lin - p + j) * H + ci] = ((red[l] + red[64 + l]) + red[128 + l]) + red[192 + l];
     }
 }
 
@@ -1133,7 +1163,8 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
                 const PlaneOut o{e.Yp[i], e.Yplane[i], log2i(kConv[i + 1].s), e.Yrts[i]};
                 const PlanesNormOut nf{prm[4 * i + 2], prm[4 * i + 3], eps, e.rstd[i], o.p, o.plane, o.sshift, o.rts, (long)e.R[i], kConv[i + 1].p};
                 const long rows = (long)kConv[i + 1].s * e.Yrts[i];
-                hipLaunchKernelGGL(zero_plane_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(64, 4), 0, st, o, rows, N, (long)e.R[i],
+                const long zrows = (long)N * (e.R[i] - e.L[i + 1]) + (rows - (long)N * e.R[i]);      // rows that are no frame
+                hipLaunchKernelGGL(zero_plane_rows_kernel, dim3((unsigned)cdiv(zrows, 4)), dim3(64, 4), 0, st, o, rows, N, (long)e.R[i],
                                    kConv[i + 1].p, e.L[i + 1], H / 16);
                 CPC_CHECK_LAUNCH("zero_plane_rows_kernel");
                 CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st, &nf));
@@ -1206,7 +1237,7 @@ static int encoder_backward(const float *x, const float *const *prm, const float
             const PlanesOperand A{e.dUp, e.dUplane, 1, 0, e.dUrows, rows, (long)e.Rv[i]};
             CPC_TRY(gemm_nt_planes(A, B, dprev, H, nullptr, (long)N * rows, s * H, 2 * H, map, st));
             if (even) {
-                hipLaunchKernelGGL(bwd_edge_kernel, dim3((unsigned)(N * p)), dim3(256), sizeof(float) * H, st, e.dUp, e.dUplane, e.dUrows,
+                hipLaunchKernelGGL(bwd_edge_kernel, dim3((unsigned)(N * p * (H / 64))), dim3(256), sizeof(float) * (H + 256), st, e.dUp, e.dUplane, e.dUrows,
                                    e.Wdp[i], (long)k * H * H, dprev, H, s, p, e.Rv[i], e.L[i + 1], e.L[i]);
                 CPC_CHECK_LAUNCH("bwd_edge_kernel");
             }

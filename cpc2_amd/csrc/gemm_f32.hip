@@ -24,7 +24,9 @@ namespace cpc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // 0: bf16x6 split kernels (default); 1: native f32-MFMA kernels (the accuracy yardstick; also CPC_GEMM_NATIVE_F32=1)
-static int g_gemm_mode = getenv("CPC_GEMM_NATIVE_F32") != nullptr ? 1 : 0;
+// per THREAD: two callers in one process (a trainer and an evaluation thread, two DataParallel replicas) each hold their own mode;
+// the entry points read it on the calling thread, so nothing they launch depends on what another thread selected
+static thread_local int g_gemm_mode = getenv("CPC_GEMM_NATIVE_F32") != nullptr ? 1 : 0;
 
 constexpr int BN = 128, BK = 32;
 constexpr int BM = 128;          // TN kernel tile; the NT kernel derives its own from MI
@@ -767,6 +769,10 @@ static int tn_splits(int M, int N, long R, long *chunk_out)
     return (int)S;
 }
 
+// (Round 4 measured the large weight-gradient products of CPC-large -- 16384 x 1536 x 512, 8192 x 6144 x 512 -- through the
+//  plane-fed kernel instead, operands split into planes by two streaming passes first: 222 / 344 us against 171 / 332 us for this
+//  family alone, i.e. no gain: 12-48 output tiles of 256 x 256 leave a quarter of the chip idle or cost XCD locality.  Their 380 us
+//  each INSIDE the step is contention with the criterion's sum running beside them, not this kernel: DESIGN.md.)
 size_t gemm_tn_scratch_bytes(int M, int N, long R)
 {
     long chunk;

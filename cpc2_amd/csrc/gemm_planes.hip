@@ -608,39 +608,57 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false>
     }
 }
 
-// x[rows][ld] (f32, `cols` columns used, cols % 16 == 0) -> chunked planes (layout: PlanesOperand)
-__global__ void split_planes_kernel(const float *x, long ld, long rows, int cols, bf16_t *planes, long plane, int sshift, long rts)
+// x[rows][ld] (f32, `cols` columns used, cols % 16 == 0) -> chunked planes (layout: PlanesOperand).
+// One workgroup per tile of 32 rows x 128 columns: the tile is read in whole rows (512 contiguous bytes), split, turned through LDS
+// and written per (plane, chunk) as the 32 rows x 32 bytes that are CONTIGUOUS in the chunk-major layout (1 KiB runs for a plain
+// matrix, 1 KiB / s for the input of a stride-s convolution).  (The first version let every thread store its own half chunk:
+// neighbouring threads were rts * 32 bytes apart, and a 250 MB pass took 160 us instead of 50.)
+constexpr int SP_ROWS = 32, SP_COLS = 128;
+__global__ __launch_bounds__(256) void split_planes_kernel(const float *x, long ld, long rows, int cols, bf16_t *planes, long plane, int sshift,
+                                                           long rts)
 {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    const int chunks = cols / 16;
-    const long total = rows * chunks * 2;                    // one thread per 8 elements (half a chunk)
+    __shared__ __attribute__((aligned(16))) uint2 tile[3][SP_COLS / 16][SP_ROWS + 1][4];  // [plane][chunk][row][4 x 8 bytes]; + 1: the chunks start in different banks
+    const int col_tiles = (cols + SP_COLS - 1) / SP_COLS;
+    const long n_tiles = ((rows + SP_ROWS - 1) / SP_ROWS) * col_tiles;
     const long smask = (1L << sshift) - 1;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int half = (int)(i & 1);
-        const long rc = i >> 1;
-        const int c = (int)(rc % chunks);
-        const long R = rc / chunks;
-        const float4 u = *reinterpret_cast<const float4 *>(x + R * ld + c * 16 + half * 8);
-        const float4 v = *reinterpret_cast<const float4 *>(x + R * ld + c * 16 + half * 8 + 4);
-        float a[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-        uint32_t w[3][4];
+    for (long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const long R0 = (tl / col_tiles) * SP_ROWS;
+        const int c0 = (int)(tl % col_tiles) * SP_COLS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float lo = a[2 * q], hi = a[2 * q + 1];
+            const int idx = q * 256 + threadIdx.x, r = idx >> 5, c4 = idx & 31;            // 32 float4 per tile row
+            const long R = R0 + r;
+            const int col = c0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (R < rows && col < cols) v = *reinterpret_cast<const float4 *>(x + R * ld + col);
+            float lo0 = v.x, hi0 = v.y, lo1 = v.z, hi1 = v.w;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                f2 pr = {lo, hi};
-                const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, b2));
-                w[t][q] = pk;
-                lo -= __uint_as_float(pk << 16);
-                hi -= __uint_as_float(pk & 0xffff0000u);
+                f2 p0 = {lo0, hi0}, p1 = {lo1, hi1};
+                const uint32_t k0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, b2));
+                const uint32_t k1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, b2));
+                tile[t][c4 >> 2][r][c4 & 3] = make_uint2(k0, k1);
+                lo0 -= __uint_as_float(k0 << 16); hi0 -= __uint_as_float(k0 & 0xffff0000u);
+                lo1 -= __uint_as_float(k1 << 16); hi1 -= __uint_as_float(k1 & 0xffff0000u);
             }
         }
-        const long chunk = (((long)c << sshift) + (R & smask)) * rts + (R >> sshift);
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-            *reinterpret_cast<uint4 *>(planes + t * plane + chunk * 16 + half * 8) = make_uint4(w[t][0], w[t][1], w[t][2], w[t][3]);
+        for (int q = 0; q < 6; ++q) {
+            const int piece = q * 256 + threadIdx.x;                 // 3 planes x 8 chunks x 64 half rows
+            const int pc = piece >> 6, j = piece & 63, r = j >> 1, half = j & 1;
+            const int t = pc >> 3, ch = pc & 7;
+            const long R = R0 + r;
+            const int c = (c0 >> 4) + ch;
+            if (R < rows && c * 16 < cols) {
+                const long chunk = (((long)c << sshift) + (R & smask)) * rts + (R >> sshift);
+                *reinterpret_cast<uint4 *>(planes + t * plane + chunk * 16 + half * 8) =
+                    *reinterpret_cast<const uint4 *>(&tile[t][ch][r][2 * half]);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -650,8 +668,8 @@ int split_planes(const float *x, long ld, long rows, int cols, bf16_t *planes, l
                     rts >= cdiv(rows, 1L << sshift) && plane >= (long)(cols / 16) * (rts << sshift) * 16 &&
                     reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(planes) % 16 == 0,
                 "split_planes: bad arguments (rows=%ld cols=%d ld=%ld plane=%ld sshift=%d rts=%ld)", rows, cols, ld, plane, sshift, rts);
-    const long total = rows * (cols / 16) * 2;
-    const long blocks = std::min<long>(cdiv(total, 256), 8192);
+    const long tiles = cdiv(rows, SP_ROWS) * cdiv(cols, SP_COLS);
+    const long blocks = std::min<long>(tiles, 16384);
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, rows, cols, planes, plane, sshift, rts);
     CPC_CHECK_LAUNCH("split_planes_kernel");
     return CPC_OK;

@@ -12,6 +12,7 @@
 // column k of that tile -- computed by the same MFMA chain as the negatives, so a negative that happens
 // to be the positive frame ties EXACTLY, as in the reference) followed by the Nneg gathered negatives.
 #include "common.h"
+#include "coop.h"
 #include "ldsdma.h"
 #include "rowcfg.h"
 
@@ -66,16 +67,21 @@ struct NceArgs {
 // waves -- they start together and do the same amount of work per candidate -- are in the same block at the same time:
 // the working set is a block or two.  One wave per (b,t): stable counting sort of its Nneg indices by block, and the
 // permutation (the logits keep the caller's candidate order; losses and gradients do not depend on the order).
+// Also the ONE place where the caller's indices are looked at before anything gathers with them (criterion.py:264-268's gather;
+// SURVEY section 5's range check): every kernel of both passes walks `sorted`, so an index outside [0, nrows) is replaced by 0
+// here -- no out-of-bounds LDS-DMA gather can follow -- and reported through the asynchronous error word (cpc_async_error_check).
 __global__ __launch_bounds__(64) void nce_block_sort_kernel(const int32_t *ext, int32_t *sorted, unsigned short *perm, int Nneg,
-                                                            int rows_per_block, int nblk)
+                                                            int rows_per_block, int nblk, int nrows, int *err)
 {
     const long base = (long)blockIdx.x * Nneg;
     const int lane = threadIdx.x;
     int pos = 0;
+    bool bad = false;
     for (int blk = 0; blk < nblk; ++blk)
         for (int c = 0; c < Nneg; c += 64) {
             const int j = c + lane;
-            const int row = j < Nneg ? ext[base + j] : -1;
+            int row = j < Nneg ? ext[base + j] : -1;
+            if (j < Nneg && (unsigned)row >= (unsigned)nrows) { bad = true; row = 0; }
             const bool mine = j < Nneg && min(row / rows_per_block, nblk - 1) == blk;
             const unsigned long long m = __ballot(mine);
             if (mine) {
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(64) void nce_block_sort_kernel(const int32_t *ext, 
             }
             pos += __popcll(m);
         }
+    if (bad) coop_report(err, COOP_ERR_BAD_INDEX);
 }
 
 // z row of candidate g of (bb, t): g < 16 -> positive tile (row t+1+g, only g < K), else negative g-16
@@ -1135,7 +1142,7 @@ static int nce_sort_negatives(const NceLayout &l, const int32_t *ext, hipStream_
 {
     CPC_REQUIRE(l.Nneg <= 65535, "infonce: at most 65535 negatives (got %d)", l.Nneg);
     hipLaunchKernelGGL(nce_block_sort_kernel, dim3((unsigned)(l.b * l.W)), dim3(64), 0, st, ext, l.ext_sorted, l.perm, l.Nneg,
-                       l.rows_per_block, l.nblk);
+                       l.rows_per_block, l.nblk, l.b * l.T, coop_error_word());
     CPC_CHECK_LAUNCH("nce_block_sort_kernel");
     return CPC_OK;
 }

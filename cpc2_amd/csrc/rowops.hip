@@ -73,8 +73,14 @@ int coop_error_take(const char *where)
     const int code = __atomic_exchange_n(g_err_host, 0, __ATOMIC_ACQ_REL);
     if (code == 0) return CPC_OK;
     if (code == COOP_ERR_NONFINITE_GRAD) {
-        set_error("%s: the Adam step met non-finite gradient elements and did not apply them (parameters and moments of those "
-                  "elements are unchanged: the weights are those of the last good step)", where);
+        set_error("%s: the Adam step met non-finite gradient elements and skipped THOSE elements (their parameters and moments are "
+                  "unchanged); the finite elements of the same step were applied and the step count advanced -- a partial update, "
+                  "unlike torch.optim.Adam, which would have propagated the NaN: reload the last checkpoint or continue knowingly", where);
+        return CPC_ERR_HIP;
+    }
+    if (code == COOP_ERR_BAD_INDEX) {
+        set_error("%s: the criterion was given negative-sample indices outside [0, batch * frames); they were replaced by row 0 "
+                  "(no out-of-bounds gather took place) -- the loss of that step is meaningless", where);
         return CPC_ERR_HIP;
     }
     set_error("%s: a cooperative recurrent kernel (%s pass) gave up waiting for the other workgroups of its group -- its "

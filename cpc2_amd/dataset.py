@@ -154,31 +154,36 @@ class AudioBatchData:
         rel = os.path.relpath(str(audio_path), str(self.dbPath))
         return self.signal_quality_path / (os.path.splitext(rel)[0] + ".pt")       # dataset.py:166-168
 
-    # ---- pack bookkeeping (dataset.py:147-223)
+    # ---- pack bookkeeping (what dataset.py:147-190 computes, restated on cumulative sizes)
     def prepare(self):
+        """New random order of the files (sessions -- runs of equal speaker index -- stay together when keep_temporality) and the
+        packs [first file, one past the last) of at most MAX_SIZE_LOADED samples.  The reference's rule, kept because its unit
+        tests pin it: a pack is closed by the first file that takes the running size beyond the limit; that file OPENS the next
+        pack but is not counted in the next pack's running size, while totSize counts it with the pack it closed."""
+        import itertools
+        import numpy as np
         if self.keep_temporality:
-            blocks, cur = [], None
-            for seq_id, seq_path in self.seqNames:
-                if cur != seq_id:
-                    blocks.append([])
-                    cur = seq_id
-                blocks[-1].append((seq_id, seq_path))
-            random.shuffle(blocks)
-            self.seqNames = [item for sub in blocks for item in sub]
+            sessions = [list(run) for _spk, run in itertools.groupby(self.seqNames, key=lambda item: item[0])]
+            random.shuffle(sessions)
+            self.seqNames = list(itertools.chain.from_iterable(sessions))
         else:
             random.shuffle(self.seqNames)
-        lengths = [audio.info(p)[2] for _, p in self.seqNames]
+        ends = np.cumsum([audio.info(p)[2] for _, p in self.seqNames], dtype=np.int64)      # samples up to and including file i
+        n_files = len(ends)
         self.packageIndex, self.totSize = [], 0
-        start, packageSize = 0, 0
-        for index, length in enumerate(lengths):
-            packageSize += length
-            if packageSize > self.MAX_SIZE_LOADED:
-                self.packageIndex.append([start, index])
-                self.totSize += packageSize
-                start, packageSize = index, 0
-        if packageSize > 0:
-            self.packageIndex.append([start, len(self.seqNames)])
-            self.totSize += packageSize
+        first, counted_from = 0, 0          # the open pack starts at file `first`; its running size counts files >= counted_from
+        while True:
+            before = int(ends[counted_from - 1]) if counted_from > 0 else 0
+            closing = int(np.searchsorted(ends, before + self.MAX_SIZE_LOADED, side="right"))   # first file that exceeds the limit
+            if closing >= n_files:
+                tail = int(ends[-1]) - before if counted_from < n_files else 0
+                if tail > 0:
+                    self.packageIndex.append([first, n_files])
+                    self.totSize += tail
+                break
+            self.packageIndex.append([first, closing])
+            self.totSize += int(ends[closing]) - before
+            first, counted_from = closing, closing + 1
         self.currentPack = -1
         self.nextPack = 0
 
@@ -198,33 +203,35 @@ class AudioBatchData:
         return items
 
     def loadNextPack(self, first=False):
+        """dataset.py:192-223: make the pack that was read ahead the current one (unless this is the very first call), then read
+        the following pack ahead -- cyclically; when the cycle restarts and there is more than one pack, the files are re-shuffled
+        and re-packed first."""
         if not first:
             self.currentPack = self.nextPack
-            self.parseNextDataBlock(self.nextData)
-            del self.nextData
-        self.nextPack = (self.currentPack + 1) % len(self.packageIndex)
-        if self.nextPack == 0 and len(self.packageIndex) > 1:
+            ahead, self.nextData = self.nextData, None
+            self.parseNextDataBlock(ahead)
+        n_packs = len(self.packageIndex)
+        self.nextPack = (self.currentPack + 1) % n_packs
+        if n_packs > 1 and self.nextPack == 0:
             self.prepare()
         self.nextData = self._load_pack(self.nextPack)
 
     def parseNextDataBlock(self, nextData):
-        """dataset.py:225-268: sort by (speaker, name), concatenate, build the interval tables."""
-        self.speakerLabel, self.seqLabel = [0], [0]
-        speakerSize, indexSpeaker = 0, 0
-        nextData.sort(key=lambda x: (x[0], x[1]))
-        chunks, quality = [], []
-        for speaker, _name, seq, *seq_quality in nextData:
-            while self.speakers[indexSpeaker] < speaker:
-                indexSpeaker += 1
-                self.speakerLabel.append(speakerSize)
-            if self.speakers[indexSpeaker] != speaker:
+        """dataset.py:225-268: the pack's files in (speaker, name) order as ONE flat vector on the device, with the tables of
+        where every sequence (seqLabel) and every speaker index up to the last one present (speakerLabel) begins."""
+        import numpy as np
+        ordered = sorted(nextData, key=lambda item: (item[0], item[1]))
+        sizes = np.array([item[2].size(0) for item in ordered], dtype=np.int64)
+        who = np.array([item[0] for item in ordered], dtype=np.int64)
+        valid = set(self.speakers)
+        for speaker in who.tolist():
+            if speaker not in valid:
                 raise ValueError(f'{speaker} invalid speaker')
-            chunks.append(seq)
-            quality += seq_quality
-            self.seqLabel.append(self.seqLabel[-1] + seq.size(0))
-            speakerSize += seq.size(0)
-        self.speakerLabel.append(speakerSize)
-        self.data = torch.cat(chunks, dim=0).to(self.device)     # ONE flat vector, resident on the device
+        self.seqLabel = [0] + np.cumsum(sizes).tolist()
+        per_speaker = np.bincount(who, weights=sizes, minlength=int(who.max()) + 1 if len(who) else 1).astype(np.int64)
+        self.speakerLabel = [0] + np.cumsum(per_speaker).tolist()
+        self.data = torch.cat([item[2] for item in ordered], dim=0).to(self.device)     # resident on the device
+        quality = [item[3] for item in ordered if len(item) > 3]
         if quality:                                              # dataset.py:257-265: min-max normalised, third column = mean
             q = torch.cat(quality, dim=0)
             q[:, 0] = (q[:, 0] - self.min_snr) / (self.max_snr - self.min_snr)
@@ -233,7 +240,8 @@ class AudioBatchData:
 
     # ---- accessors
     def getSpeakerLabel(self, idx):
-        return next(i for i, v in enumerate(self.speakerLabel) if v > idx) - 1
+        import bisect
+        return bisect.bisect_right(self.speakerLabel, idx) - 1
 
     def getSignalQuality(self, idx):
         """dataset.py:271-281: the window's signal_quality_size estimates of the selected kind."""

@@ -396,13 +396,15 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
             allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
         return allLosses.sum(), allLosses, allAcc
     combined = torch.cat([past, future], dim=0)
-    label = torch.cat([label, label])
-    c_feature, encoded_full, label = cpcModel(combined, label)
+    # (train.py:100,105 concatenate the labels too and take the first half back: CPCModel hands `label` through untouched, so the
+    #  round trip -- two small kernels per step -- is skipped for it; any other model gets the reference's tensors)
+    passthrough = isinstance(getattr(cpcModel, "module", cpcModel), CPCModel)
+    c_feature, encoded_full, label2 = cpcModel(combined, label if passthrough else torch.cat([label, label]))
+    label = label2 if passthrough else label2[:b]
     if dp is not None:
         dp.attach(encoded_full)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
     c_feature = c_feature[:b, :, :]
     encoded_data = carry_join(encoded_full[b:, :, :], encoded_full, b)
-    label = label[:b]
     with _defer_scope(cpcCriterion, encoded_full):
         allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
     return allLosses.sum(), allLosses, allAcc

@@ -76,7 +76,8 @@ int cpc_prof_read(const char *name, double *total_ms, long *count);
  * (v_mfma_f32_32x32x2_f32); mode 2 (opt-in, never the default) makes the encoder's plane-fed convolution products at
  * hidden 256 / 512 multiply only a0 b0 + a0 b1 + a1 b0 of the split (16 bits of product mantissa, f32 accumulation: half the
  * matrix work; TF32 -- what cuDNN gives the reference's convolutions on its own GPUs by default -- keeps 10 bits), everything
- * else as mode 0.  cpc_gemm_set_mode returns the previous mode; other values only query.
+ * else as mode 0.  cpc_gemm_set_mode returns the previous mode; other values only query.  The mode belongs to the CALLING THREAD
+ * (thread-local, default 0): it is the only setting the library keeps between calls, and no thread can change another's.
  * cpc_gemm_nt splits K over workgroups when the output has few tiles and then adds the partial sums with
  * fp32 atomics (C is zeroed first); the module entry points below lend scratch for an ordered reduction instead.
  * ------------------------------------------------------------------------------------------ */
@@ -297,6 +298,8 @@ size_t cpc_infonce_logits_offset(int b, int t, int k, int dim_ar, int dim_enc, i
  * row = the negative in slot g: a tile's columns are then consecutive floats).  byte offset, inside `saved`, of the
  * permutation: uint16 [b, W, n_neg], perm[g] = the caller's number (its position in ext_idx) of the negative in slot g */
 size_t cpc_infonce_perm_offset(int b, int t, int k, int dim_ar, int dim_enc, int n_neg);
+/* (ext_idx is range-checked on the device before anything gathers with it: an index outside [0, b * t) is replaced by 0 and
+ *  reported by the next cpc_async_error_check(stream) -- criterion.py:264-268's gather has no such check.) */
 int cpc_infonce_forward(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
                         const float *weights, float *losses, float *acc, void *saved, void *scratch,
                         int b, int t, int k, int dim_ar, int dim_enc, int n_neg, cpc_stream_t stream);
@@ -351,7 +354,9 @@ int cpc_window_gather(const float *audio, long total_samples, const long *offset
  *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
  * An element whose gradient is not finite is left alone (p, m, v unchanged) and the asynchronous error word is set: the
  * next cpc_async_error_check(stream) returns CPC_ERR_HIP.  A cooperative recurrent kernel that timed out therefore cannot
- * poison the weights; recovery = continue from the current (last good) weights or reload the last checkpoint.
+ * poison the weights.  This is a PARTIAL update when only some elements are non-finite (the finite ones are applied, the step
+ * count advances) and a deviation from the reference, whose torch.optim.Adam (train.py:477-479) propagates the NaN into the
+ * weights; recovery = reload the last checkpoint, or continue knowingly.
  * ------------------------------------------------------------------------------------------ */
 int cpc_adam_step(float *p, const float *g, float *m, float *v, long n, int step, float lr,
                   float beta1, float beta2, float eps, float grad_scale, cpc_stream_t stream);

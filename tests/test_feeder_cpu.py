@@ -143,3 +143,37 @@ def test_signal_quality_side_files(tmp_path):
                        signal_quality_mode="loudness").getSignalQuality(0)
     with pytest.raises(FileNotFoundError):
         AudioBatchData(DB, window, seq_names, None, 9, device="cpu", signal_quality_path=tmp_path / "nowhere")
+
+
+def test_pack_boundaries_follow_the_reference_rule(monkeypatch):
+    """dataset.py:172-186's rule stated as the loop it is (a pack is closed by the first file that takes the running size beyond
+    MAX_SIZE_LOADED; that file opens the next pack uncounted, totSize counts it with the pack it closed) against
+    AudioBatchData.prepare, which computes the same boundaries from cumulative sizes, on random length lists."""
+    import random as rnd
+    from cpc2_amd import audio, dataset
+
+    def rule(lengths, limit):
+        packs, total, start, size = [], 0, 0, 0
+        for index, length in enumerate(lengths):
+            size += length
+            if size > limit:
+                packs.append([start, index])
+                total += size
+                start, size = index, 0
+        if size > 0:
+            packs.append([start, len(lengths)])
+            total += size
+        return packs, total
+
+    gen = rnd.Random(7)
+    for case in range(200):
+        n = gen.randint(1, 40)
+        lengths = [gen.randint(1, 50) for _ in range(n)]
+        limit = gen.choice([1, 5, 30, 60, 100, 10 ** 6]) if case % 7 else max(lengths) - 1
+        monkeypatch.setattr(audio, "info", lambda p, lengths=lengths: (16000, 1, lengths[int(str(p))]))
+        obj = dataset.AudioBatchData.__new__(dataset.AudioBatchData)
+        obj.keep_temporality, obj.MAX_SIZE_LOADED = False, limit
+        obj.seqNames = [(0, str(i)) for i in range(n)]
+        monkeypatch.setattr(dataset.random, "shuffle", lambda x: None)           # the order under test is the given one
+        obj.prepare()
+        assert (obj.packageIndex, obj.totSize) == rule(lengths, limit), (lengths, limit)

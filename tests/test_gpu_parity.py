@@ -1753,6 +1753,42 @@ def test_criterion_backward_is_deferred_only_inside_the_callers_scope(monkeypatc
     assert torch.equal(g_deferred, g_hooked)
 
 
+def test_criterion_index_range_is_checked_on_the_device():
+    """SURVEY section 5 (criterion.py:264-268's gather): a negative-sample index outside [0, b * t) must not become an out-of-bounds
+    gather.  The forward pass replaces it by row 0 and the asynchronous error check reports it; with the same index set to 0 by
+    the caller the losses are the same bit for bit, and a clean call leaves the error word alone."""
+    lib = _lib.load()
+    b, t, k, h, nn = 2, 128, 12, 256, 32
+    g = torch.Generator().manual_seed(3)
+    c = torch.randn(b, t, h, generator=g).to(DEV)
+    z = torch.randn(b, t, h, generator=g).to(DEV)
+    wpred = (0.05 * torch.randn(k, h, h, generator=g)).to(DEV)
+    ext = torch.randint(0, b * t, (b * (t - k) * nn,), generator=g, dtype=torch.int32)
+    st = _lib.stream_ptr(c.device)
+    nsaved = lib.cpc_infonce_saved_bytes(b, t, k, h, h, nn)
+    nscr = lib.cpc_infonce_scratch_bytes(b, t, k, h, h, nn)
+
+    def forward(idx):
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=DEV)
+        scr = torch.empty(nscr, dtype=torch.uint8, device=DEV)
+        losses, acc = torch.empty(k, device=DEV), torch.empty(k, device=DEV)
+        idx = idx.to(DEV)
+        _lib.check(lib.cpc_infonce_forward(_lib.ptr(c), _lib.ptr(z), _lib.ptr(wpred), _lib.ptr(idx), None, _lib.ptr(losses), _lib.ptr(acc),
+                                           _lib.ptr(saved), _lib.ptr(scr), b, t, k, h, h, nn, st), "fwd")
+        return losses.cpu(), lib.cpc_async_error_check(st)
+    clean, rc = forward(ext)
+    assert rc == 0
+    bad = ext.clone()
+    bad[1234], bad[77] = b * t + 5, -3
+    got, rc = forward(bad)
+    assert rc != 0 and "indices outside" in lib.cpc_last_error().decode()
+    fixed = ext.clone()
+    fixed[1234], fixed[77] = 0, 0
+    want, rc = forward(fixed)
+    assert rc == 0 and torch.equal(got, want) and torch.isfinite(got).all()
+    assert not torch.equal(clean, want)
+
+
 def test_infonce_backward_deferred_c_entry_matches_the_immediate_one():
     """The C entry points themselves: deferred + join on the calling stream == cpc_infonce_backward, bit for bit; a second join
     is a no-op."""
