@@ -561,29 +561,55 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false>
             const float4 bt = *reinterpret_cast<const float4 *>(p.norm.beta + nw + c4);
             const int sh = p.norm.sshift;
             const long smask = (1L << sh) - 1;
-            const long chunk_c = (long)((nw + c4) >> 4);
+            const long chunk_c = (long)(nw >> 4);                              // first of the wave's four 16-channel chunks
+            // The next layer's planes leave through a wave-private LDS tile (the wave's staging area: its rows are in registers by
+            // now), 32 rows at a time: [plane][chunk][row][32 bytes], chunks 33 rows apart (the four chunks of a row land in
+            // different banks).  A lane then stores 16 bytes of (plane, chunk, row lane / 2): the rows of a chunk are consecutive
+            // in memory (every s-th one), so a store instruction writes runs of 512 bytes and more -- as 8-byte stores straight
+            // from the registers every instruction wrote sixteen 32-byte pieces, and the epilogue took 28 us per tile instead
+            // of 18 without them (profiles/r04_planes_levers.md).
+            uint2 *const ptile = reinterpret_cast<uint2 *>(stg);
+            constexpr int PCH = 33 * 4;                                        // uint2 per (plane, chunk)
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const float4 q4 = *reinterpret_cast<const float4 *>(rss + (rloc + 4 * it) * 4);
-                const float rstd = rsqrtf(((q4.x + q4.y) + (q4.z + q4.w)) * (1.f / (PT_BN - 1)) + p.norm.eps);
-                const long m = mrow + 4 * it;
-                const long crow = g * p.map.rows_out + t;             // (forward map: out_stride 1, out_off 0)
-                if (m < p.M) {
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) {
+                    const int it = hf * 8 + i8;
+                    const float4 q4 = *reinterpret_cast<const float4 *>(rss + (rloc + 4 * it) * 4);
+                    const float rstd = rsqrtf(((q4.x + q4.y) + (q4.z + q4.w)) * (1.f / (PT_BN - 1)) + p.norm.eps);
+                    const long m = mrow + 4 * it;
+                    const long crow = g * p.map.rows_out + t;             // (forward map: out_stride 1, out_off 0)
                     const float4 xh = make_float4(v[it].x * rstd, v[it].y * rstd, v[it].z * rstd, v[it].w * rstd);
-                    *reinterpret_cast<float4 *>(out + crow * ldo + nw + c4) = xh;
-                    if ((lane & 15) == 0 && wc == 0) p.norm.rstd[crow] = rstd;
+                    if (m < p.M) {
+                        *reinterpret_cast<float4 *>(out + crow * ldo + nw + c4) = xh;
+                        if ((lane & 15) == 0 && wc == 0) p.norm.rstd[crow] = rstd;
+                    }
                     const float y[4] = {fmaxf(fmaf(xh.x, gm.x, bt.x), 0.f), fmaxf(fmaf(xh.y, gm.y, bt.y), 0.f),
                                         fmaxf(fmaf(xh.z, gm.z, bt.z), 0.f), fmaxf(fmaf(xh.w, gm.w, bt.w), 0.f)};
                     uint2 w3[3];
                     split4_terms(y, w3);
-                    const long R = g * p.norm.rows_next + p.norm.halo + t;
-                    const long chunk = ((chunk_c << sh) + (R & smask)) * p.norm.rts + (R >> sh);
-                    unsigned short *dst = p.norm.p + chunk * 16 + ((nw + c4) & 15);
+                    if (i8 == 0) asm volatile("" ::: "memory");
+                    const int prow = i8 * 4 + (lane >> 4), pch = (lane & 15) >> 2, pq = lane & 3;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2 *>(dst + pl * p.norm.plane) = w3[pl];
+                    for (int pl = 0; pl < 3; ++pl) ptile[(pl * 4 + pch) * PCH + prow * 4 + pq] = w3[pl];
+                    t += 4;
+                    while (t >= rv) { t -= rv; ++g; }
                 }
-                t += 4;
-                while (t >= rv) { t -= rv; ++g; }
+                // flush: row lane / 2 of the 32, half lane & 1; twelve (plane, chunk) blocks of one KiB
+                const long mf = m0 + wr * 128 + pass * 64 + hf * 32 + (lane >> 1);
+                const long gf = mf / rv, tf = mf - gf * rv;
+                const long R = gf * p.norm.rows_next + p.norm.halo + tf;
+                const long rowchunk = (R & smask) * p.norm.rts + (R >> sh);
+                if (mf < p.M && !(p.dbg & 64)) {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        const int pl = k >> 2, pch = k & 3;
+                        const uint4 u = *reinterpret_cast<const uint4 *>(ptile + k * PCH + (lane >> 1) * 4 + 2 * (lane & 1));
+                        const long chunk = (((chunk_c + pch) << sh)) * p.norm.rts + rowchunk;
+                        *reinterpret_cast<uint4 *>(p.norm.p + pl * p.norm.plane + chunk * 16 + 8 * (lane & 1)) = u;
+                    }
+                }
+                asm volatile("" ::: "memory");       // (the tile is the staging area under another type: keep the next writes behind these reads)
             }
             continue;
         }
