@@ -980,7 +980,12 @@ __device__ __forceinline__ float4 nt_load4(const float4 *p)
 
 // dz[r][:] = sum of the stored contributions that point at z row r = (bb, t'): the positives of steps k = 0..K-1
 // come from (bb, t' - 1 - k), the negatives from the row's reference list.  One wave per row, 16 bytes per lane.
-template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel(const float *vbuf, const int *offsets,
+#ifdef NCE_GATHER_WIDE                       /* (A/B build: the 68-register kernel of rounds 1-3, which cannot sit beside the matrix-pipe GRU backward) */
+#define NCE_GATHER_BOUNDS __launch_bounds__(256)
+#else
+#define NCE_GATHER_BOUNDS __launch_bounds__(256, 8)
+#endif
+template <int H> __global__ NCE_GATHER_BOUNDS void infonce_dz_gather_kernel(const float *vbuf, const int *offsets,
                                                                                    const int *entries, float *dz, int b, int T,
                                                                                    int W, int K, int Nneg, int pos_rows)
 {
@@ -1009,18 +1014,20 @@ template <int H> __global__ __launch_bounds__(256) void infonce_dz_gather_kernel
     const int beg = offsets[r], end = offsets[r + 1];
     int e = end;
     for (; e - 8 >= beg; e -= 8) {                   // eight rows in flight
-        long src[8];
+        // (row numbers as 32-bit values -- b * W * (16 + Nneg) rows < 2^31 -- and the kernel held to 64 registers: the matrix-pipe
+        //  recurrent backward it is meant to run beside leaves exactly 64 per SIMD free, 2 x 222 of 512)
+        unsigned src[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int o = entries[e - 1 - i];
-            src[i] = (long)(o / Nneg) * vrows + pos_rows + o % Nneg;
+            const unsigned o = (unsigned)entries[e - 1 - i];
+            src[i] = (o / (unsigned)Nneg) * (unsigned)vrows + (unsigned)pos_rows + o % (unsigned)Nneg;
         }
         float4 v[8][PER];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int c = 0; c < PER; ++c)
-                v[i][c] = lane + 64 * c < C4 ? nt_load4(v4 + src[i] * C4 + lane + 64 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[i][c] = lane + 64 * c < C4 ? nt_load4(v4 + (long)src[i] * C4 + lane + 64 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
