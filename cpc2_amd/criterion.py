@@ -215,6 +215,54 @@ def carry_join(view, parent, start):
     return view
 
 
+# ---- gradients that are zero by construction, without materialising the zeros every step ----------------------------------------
+# train.py:102-103 slices the model's outputs (context of the first b windows, targets of the last b): autograd turns each slice's
+# gradient back into the full tensor with a zero fill plus a copy (16.8 MB + 8.4 MB per slice at the benchmark shape, two small
+# launches each).  The halves that are zero are zero EVERY step, so they live in buffers that are allocated and zeroed once per
+# (device, shape, slot): the criterion's backward writes dc / dz straight into the other half and hands the whole buffer on.
+# Nothing ever writes the zero half (autograd only reads gradients it does not own: this cache holds a reference), and a buffer is
+# reused only after the backward pass that read it has been enqueued on the same stream.
+_grad_cache = {}
+
+
+def _cached_grad_buffer(shape, device, slot):
+    key = (tuple(shape), str(device), slot)
+    buf = _grad_cache.get(key)
+    if buf is None:
+        if len(_grad_cache) > 8:
+            _grad_cache.clear()
+        buf = _grad_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return buf
+
+
+class _FirstWindows(torch.autograd.Function):
+    """x[:n] (windows) whose backward does not fill and copy: the gradient of the slice is written by its producer straight into
+    the first n windows of a cached buffer whose other windows stay zero (see above); any other gradient is copied into it."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.full_shape, ctx.n = tuple(x.shape), n
+        out = x[:n]
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf = _cached_grad_buffer(ctx.full_shape, g.device, "context")
+        if not (g.data_ptr() == buf.data_ptr() and g.is_contiguous() and g.dtype == torch.float32):
+            buf[:ctx.n].copy_(g)
+        return buf, None
+
+
+def first_windows(x, n):
+    """x[:n] for the context features in cpcStep (train.py:102); marks the result so that the criterion's backward writes its
+    gradient where _FirstWindows.backward expects it."""
+    if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.is_contiguous() and x.dtype == torch.float32):
+        return x[:n]
+    out = _FirstWindows.apply(x, n)
+    out._cpc_first_of = tuple(x.shape)
+    return out
+
+
 class _DeferScope:
     def __init__(self, criterion, encoded_full):
         self.criterion, self.tensor = criterion, encoded_full
@@ -237,6 +285,7 @@ class _InfoNCEFn(torch.autograd.Function):
     def forward(ctx, c, z, ext_idx, weights, n_neg, defer, *wk):
         require_gpu(c, z, ext_idx, *wk)
         lib = _lib.load()
+        ctx.c_first_of = getattr(c, "_cpc_first_of", None) if (c.is_contiguous() and c.dtype == torch.float32) else None
         c = f32c(c)
         ctx.z_full_shape = None
         if defer is not None:
@@ -276,10 +325,14 @@ class _InfoNCEFn(torch.autograd.Function):
         c, z, wpred, ext_idx, w, saved = ctx.saved_tensors
         b, t, k, dim_ar, dim_enc, n_neg = ctx.dims
         dlosses = f32c(dlosses)
-        dc = torch.empty_like(c)
+        if ctx.c_first_of is not None:       # (first_windows: dc goes where the slice's backward looks for it, the rest stays zero)
+            dc = _cached_grad_buffer(ctx.c_first_of, c.device, "context")[:c.shape[0]]
+        else:
+            dc = torch.empty_like(c)
         defer = ctx.z_full_shape is not None
         if defer and ctx.z_full_shape != tuple(z.shape):
-            dz_out = torch.zeros(ctx.z_full_shape, dtype=z.dtype, device=z.device)
+            # (windows outside start .. start + n get no gradient from the criterion: zero once, see _cached_grad_buffer)
+            dz_out = _cached_grad_buffer(ctx.z_full_shape, z.device, ("targets", ctx.z_start))
             dz = dz_out[ctx.z_start:ctx.z_start + z.shape[0]]
         else:
             dz_out = dz = torch.empty_like(z)

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join
+from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join, first_windows
 from .model import CPCAR, CPCEncoder, CPCModel
 
 
@@ -403,7 +403,7 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     label = label2 if passthrough else label2[:b]
     if dp is not None:
         dp.attach(encoded_full)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
-    c_feature = c_feature[:b, :, :]
+    c_feature = first_windows(c_feature, b)
     encoded_data = carry_join(encoded_full[b:, :, :], encoded_full, b)
     with _defer_scope(cpcCriterion, encoded_full):
         allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)

@@ -1676,6 +1676,57 @@ def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch
     assert torch.equal(results[0][1], results[1][1])
 
 
+_DEFER_LAYERS_SCRIPT = """
+import sys, torch
+sys.path.insert(0, {root!r})
+import cpc2_amd
+from cpc2_amd import _lib
+from cpc2_amd import criterion as crit_mod
+from cpc2_amd.train import buildOptimizer, cpcStep
+from oracle import synth
+hidden, b, mode = 512, 32, {mode!r}
+torch.manual_seed(3)
+model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 2, mode=mode)).to("cuda:0")
+crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 256, rnnMode="linear", sizeInputSeq=128).to("cuda:0")
+opt = buildOptimizer(model, crit, lr=2e-4)
+crit.seed(5)
+x = synth.audio_windows(b, 20480, 24).to("cuda:0")
+label = torch.zeros(b, dtype=torch.long, device="cuda:0")
+for _ in range(2):
+    tot, _l, _a = cpcStep(x, x, label, model, crit)
+    tot.backward()
+    assert not crit_mod._deferred
+    opt.step()
+    opt.zero_grad()
+_lib.check(_lib.load().cpc_async_error_check(_lib.stream_ptr(torch.device("cuda:0"))), "async error check")
+torch.save(opt.flat.detach().cpu(), {dst!r})
+"""
+
+
+@pytest.mark.parametrize("mode", ["GRU", "LSTM"])
+def test_deferred_backward_with_two_recurrent_layers_at_many_windows(tmp_path, mode):
+    """Round-3 advisor finding: with two recurrent layers (CPC-large: hidden 512) the deferred dz sum and predictor weight gradient
+    start on the side stream behind layer 1's cooperative backward kernel and can still hold CUs when layer 0's -- which needs
+    every workgroup resident -- is launched.  64 windows through the context network (b = 32, reference semantics), GRU and LSTM:
+    two deferred training steps end with a clean asynchronous error word and the same parameters, bit for bit, as the immediate
+    form (CPC_NCE_NO_DEFER=1, its own process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form, env in (("deferred", {}), ("immediate", {"CPC_NCE_NO_DEFER": "1"})):
+        dst = str(tmp_path / f"{form}.pt")
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        if form == "deferred":
+            e.pop("CPC_NCE_NO_DEFER", None)
+        r = subprocess.run([sys.executable, "-c", _DEFER_LAYERS_SCRIPT.format(root=root, mode=mode, dst=dst)], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = torch.load(dst)
+    assert torch.isfinite(res["deferred"]).all()
+    assert torch.equal(res["deferred"], res["immediate"]), f"{mode} x2: parameters differ between the deferred and the immediate backward"
+
+
 def _spied_criterion_calls(monkeypatch, run):
     """Runs `run()` with _InfoNCEFn.apply spied: the `defer` argument of every call."""
     from cpc2_amd import criterion as crit_mod
