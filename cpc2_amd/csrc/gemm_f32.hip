@@ -16,6 +16,7 @@
 // in flight while the current one is multiplied); LDS rows are padded to 36 floats so the
 // ds_read_b128 fragment reads are bank-conflict free.
 #include "common.h"
+#include <atomic>
 
 #include <algorithm>
 
@@ -24,9 +25,11 @@ namespace cpc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // 0: bf16x6 split kernels (default); 1: native f32-MFMA kernels (the accuracy yardstick; also CPC_GEMM_NATIVE_F32=1)
-// per THREAD: two callers in one process (a trainer and an evaluation thread, two DataParallel replicas) each hold their own mode;
-// the entry points read it on the calling thread, so nothing they launch depends on what another thread selected
-static thread_local int g_gemm_mode = getenv("CPC_GEMM_NATIVE_F32") != nullptr ? 1 : 0;
+// Process-wide, deliberately: the one setting the library keeps between calls.  (Round 4 made it thread-local for a day -- and the
+// backward pass stopped seeing it: autograd runs backward on its own worker thread, so a mode selected on the thread that calls
+// forward never reached the weight-gradient products.  A mode is a property of a RUN -- the accuracy yardstick of the tests, the
+// labelled three-product entry of bench.py -- not of a call; it is an atomic so that a concurrent reader sees one value or the other.)
+static std::atomic<int> g_gemm_mode{getenv("CPC_GEMM_NATIVE_F32") != nullptr ? 1 : 0};
 
 constexpr int BN = 128, BK = 32;
 constexpr int BM = 128;          // TN kernel tile; the NT kernel derives its own from MI
@@ -409,7 +412,7 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     a.M = M; a.N = N; a.K = K; a.map = map;
     a.aligned = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
-    const bool native = g_gemm_mode == 1;
+    const bool native = g_gemm_mode.load() == 1;
     const bool split_kernels = a.aligned && !native;
     // segmented row tiling (split kernels): never multiply the junk rows at the end of a sample
     a.seg_rows = 0; a.seg_valid = 0;
@@ -799,7 +802,7 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
     a.xcd_remap = (!no_remap && S % 8 == 0 && grid.x * grid.y > 1) ? 1 : 0;
     ProfScope prof(PROF_GEMM_TN, st);
-    const bool native = g_gemm_mode == 1;
+    const bool native = g_gemm_mode.load() == 1;
     if (a.aligned && !native) hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, dim3(256), 0, st, a);
     else if (a.aligned) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
@@ -813,15 +816,15 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
 
 int gemm_set_mode(int mode)
 {
-    const int prev = g_gemm_mode;
-    if (mode == 0 || mode == 1 || mode == 2) g_gemm_mode = mode;
+    const int prev = g_gemm_mode.load();
+    if (mode == 0 || mode == 1 || mode == 2) g_gemm_mode.store(mode);
     return prev;
 }
 
 }  // namespace cpc
 
 // ------------------------------------------------------------------------------------------------
-namespace cpc { int gemm_mode() { return g_gemm_mode; } }
+namespace cpc { int gemm_mode() { return g_gemm_mode.load(); } }
 extern "C" int cpc_gemm_set_mode(int mode) { return cpc::gemm_set_mode(mode); }
 
 extern "C" int cpc_gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc,

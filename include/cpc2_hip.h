@@ -76,8 +76,10 @@ int cpc_prof_read(const char *name, double *total_ms, long *count);
  * (v_mfma_f32_32x32x2_f32); mode 2 (opt-in, never the default) makes the encoder's plane-fed convolution products at
  * hidden 256 / 512 multiply only a0 b0 + a0 b1 + a1 b0 of the split (16 bits of product mantissa, f32 accumulation: half the
  * matrix work; TF32 -- what cuDNN gives the reference's convolutions on its own GPUs by default -- keeps 10 bits), everything
- * else as mode 0.  cpc_gemm_set_mode returns the previous mode; other values only query.  The mode belongs to the CALLING THREAD
- * (thread-local, default 0): it is the only setting the library keeps between calls, and no thread can change another's.
+ * else as mode 0.  cpc_gemm_set_mode returns the previous mode; other values only query.  The mode is PROCESS-WIDE (atomic, default
+ * 0) and the only setting the library keeps between calls: it selects the arithmetic of a whole run (the tests' yardstick, the
+ * benchmark's labelled entry) and has to reach the backward pass, which autograd runs on a thread of its own -- a per-thread mode
+ * does not (tried in round 4).  Select it before the first call of a run, not concurrently with one.
  * cpc_gemm_nt splits K over workgroups when the output has few tiles and then adds the partial sums with
  * fp32 atomics (C is zeroed first); the module entry points below lend scratch for an ordered reduction instead.
  * ------------------------------------------------------------------------------------------ */
