@@ -992,8 +992,9 @@ template <int H> __global__ NCE_GATHER_BOUNDS void infonce_dz_gather_kernel(cons
     constexpr int C4 = H / 4;                        // float4 per row
     constexpr int PER = (C4 + 63) / 64;              // per lane
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= b * T) return;
+    // (a wave walks rows blockIdx.x * 4 + wave, + 4 gridDim.x, ...: the launcher may cap the grid so that only a few waves per CU
+    //  stream beside a recurrent kernel, whose hand-off latency grows with the streaming waves on its CU)
+    for (int r = blockIdx.x * 4 + wave; r < b * T; r += gridDim.x * 4) {
     const int bb = r / T, tp = r - bb * T;
     const int vrows = pos_rows + Nneg;              // pos_rows = K (one-wave store kernel) or 16 (fused kernel)
     const float4 *v4 = reinterpret_cast<const float4 *>(vbuf);
@@ -1044,6 +1045,7 @@ template <int H> __global__ NCE_GATHER_BOUNDS void infonce_dz_gather_kernel(cons
 #pragma unroll
     for (int c = 0; c < PER; ++c)
         if (lane + 64 * c < C4) reinterpret_cast<float4 *>(dz)[(long)r * C4 + lane + 64 * c] = acc[c];
+    }
 }
 
 // raw[0..n) -> batchIdx = raw % b, raw[n..2n) -> seqIdx = raw % (T-1) + 1 (draw order i = (bb*Nneg + nn)*W + t);
@@ -1258,7 +1260,11 @@ static int nce_side(NceSide **out)
 static int nce_launch_gather(const NceLayout &l, float *dz, bool fused, hipStream_t st)
 {
     const int rows = l.b * l.T;
-    NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_gather_kernel<HH>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, l.vbuf,
+    // (one workgroup per four rows.  Fewer, persistent workgroups -- so that only a few waves per CU stream beside the recurrent
+    //  backward -- were measured again in round 4: 256 / 512 / 1024 workgroups cost CPC-large +1.2 / +0.35 / 0 ms per step and
+    //  CPC-small 0 .. +0.15, as in round 3)
+    const unsigned wgs = (unsigned)cdiv(rows, 4);
+    NCE_DISPATCH(l.Henc, hipLaunchKernelGGL(infonce_dz_gather_kernel<HH>, dim3(wgs), dim3(256), 0, st, l.vbuf,
                                              l.offsets, l.entries, dz, l.b, l.T, l.W, l.K, l.Nneg, fused ? NCE_POS : l.K));
     CPC_CHECK_LAUNCH("infonce_dz_gather_kernel");
     return CPC_OK;
