@@ -466,6 +466,31 @@ def test_encoder_with_and_without_the_fused_norm_epilogue(tmp_path):
     assert not torch.equal(res["fused"]["out"], res["plain"]["out"]), "the switch selected the same kernels twice"
 
 
+@pytest.mark.parametrize("hidden,n", [(256, 128), (512, 16)])
+def test_pair_form_of_the_plane_fed_kernel_is_bit_identical_to_the_one_tap_form(tmp_path, hidden, n):
+    """The pair form (A tile of a tap pair staged once, second tap's fragments read one row down; conv1-3 forward and backward
+    data at the training window length, with and without a K split, with and without the fused norm epilogue) multiplies the
+    same fragments in the same order as the one-tap-per-stage form (CPC_PLANES_NO_PAIR=1, its own process): the encoder's output
+    and every gradient are equal bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    script = _ENC_FORMS_SCRIPT.replace("hidden, n = 256, {n}", "hidden, n = {hidden}, {n}")
+    for form, env in (("pair", {}), ("one_tap", {"CPC_PLANES_NO_PAIR": "1"})):
+        dst = str(tmp_path / f"{form}.pt")
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        if form == "pair":
+            e.pop("CPC_PLANES_NO_PAIR", None)
+        r = subprocess.run([sys.executable, "-c", script.format(root=root, hidden=hidden, n=n, dst=dst)], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = torch.load(dst)
+    for key in res["one_tap"]:
+        assert torch.equal(res["pair"][key], res["one_tap"][key]), f"{key}: the two forms differ (max {float((res['pair'][key] - res['one_tap'][key]).abs().max()):.3e})"
+    assert float(res["pair"]["out"].abs().max()) > 0
+
+
 _ENC_SAVED_SCRIPT = """
 import ctypes, sys, torch
 sys.path.insert(0, {root!r})
