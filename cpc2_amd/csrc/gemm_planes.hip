@@ -76,7 +76,6 @@ struct PlanesNTArgs {
     long slab_rows;                               // output rows (after the row map)
     PlanesNormOut norm;                           // NORM kernels only (N == 256, no K split)
     int dbg;                                      // probes: 1 no loads after the prologue, 2 no MFMAs, 8 clock stamps, 16 half the A requests, 32 a third fewer fragment reads
-    int opt;                                      // schedule switches (planes_opt()): 1 waves 4-7 request half a stage later, 2 s_setprio 1 for waves 4-7
     unsigned long long *stamps;                   // dbg & 8: [workgroup][8] = memtime, memrealtime at loop start and end, ...
 };
 
@@ -426,22 +425,14 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false>
 
     // one stage; bc: B fragments of this stage, bn: of the next one; ax holds block 0 on entry (and on exit)
     //
-    // Who requests when (opt & 1).  The two waves of a SIMD (w and w + 4) run the same program between the same barriers; if both
-    // issue their six LDS-DMA pieces right behind the barrier, the SIMD's matrix pipe waits for both (a piece holds its wave's
-    // issue for ~60-100 cycles).  Waves 4-7 therefore request stage t + 2 half an interval later -- between the MFMAs of row block
-    // 1 of stage t, into the slot of stage t - 1, which everyone left at the barrier that precedes stage t -- while their SIMD
-    // partners are in pure MFMA + LDS-read code, and vice versa behind the barrier.  Nothing else changes: a wave's pieces of stage
-    // t + 1 are still its second-youngest six at the wait in front of the barrier of stage t (vmcnt(6)).
-    const bool late = (p.opt & 1) && wave >= 4;
-    if ((p.opt & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // (Round 4 measured two schedule variants here and removed them again: waves 4-7 requesting half a stage later than their SIMD
+    //  partners, and a static s_setprio 1 for waves 4-7 -- no effect in any arm, profiles/r04_planes_levers.md: an LDS-DMA piece
+    //  costs the SIMD's matrix pipe ~60 cycles whichever wave issues it.)
     unsigned slot = 0;                                                   // ring slot of stage t (byte offset)
 #define PT_SB __builtin_amdgcn_sched_barrier(0)
     auto stage = [&](int t, frag_t (&bc)[2][3], frag_t (&bn)[2][3], const bool odd) {
         const unsigned fa = fa0 + slot;
         const unsigned nslot = slot == (PT_RING - 1) * PT_STAGE ? 0 : slot + PT_STAGE;
-        const unsigned pslot = slot == 0 ? (PT_RING - 1) * PT_STAGE : slot - PT_STAGE;
-        const bool lreq = late && t >= 1 && t + 2 < nst && !noload;
-        const Src ql = stage_src(lreq ? t + 2 : t, pslot);
         read_a<TN, 1>(ay, fa);
         PT_SB;
         mma6<TERMS>(acc[0][0], acc[0][1], ax, bc, nomma);
@@ -449,13 +440,8 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false>
         lds_wait3(ay);
         read_a<TN, 2>(ax, fa);
         PT_SB;
-        if (!nomma && TERMS == 6) { mma2<0>(acc[1][0], acc[1][1], ay, bc); mma2<1>(acc[1][0], acc[1][1], ay, bc); mma2<2>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
-        if (lreq && !(half_a && odd)) { issue1(ql, 0); issue1(ql, 1); } PT_SB;    // (late waves request stage t + 2: same parity as t)
-        if (!nomma) { mma2<3>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
-        if (lreq) { if (!(half_a && odd)) issue1(ql, 2); issue1(ql, 3); } PT_SB;
-        if (!nomma) { mma2<4>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
-        if (lreq) { issue1(ql, 4); issue1(ql, 5); } PT_SB;
-        if (!nomma) { mma2<5>(acc[1][0], acc[1][1], ay, bc); } PT_SB;
+        mma6<TERMS>(acc[1][0], acc[1][1], ay, bc, nomma);
+        PT_SB;
         lds_wait3(ax);
         if constexpr (!fewer_reads) read_a<TN, 3>(ay, fa);
         PT_SB;
@@ -470,7 +456,7 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false>
         __builtin_amdgcn_s_barrier();          // stage t + 1 has landed for everyone; everyone has read all of stage t
         // row block 3, with the requests for stage t + 3 and the reads of stage t + 1's first fragments BETWEEN its MFMAs:
         // the eight waves leave the barrier together, and an LDS-DMA piece holds a wave's issue for ~100 cycles
-        const bool req = t + 3 < nst && !noload && !late;
+        const bool req = t + 3 < nst && !noload;
         const Src q = stage_src(req ? t + 3 : t, slot);
         const unsigned fbn = fb0 + nslot, fan = fa0 + nslot;
         if (!nomma && TERMS == 6) { mma2<0>(acc[3][0], acc[3][1], ay, bc); } PT_SB;
@@ -703,13 +689,6 @@ int split_planes(const float *x, long ld, long rows, int cols, bf16_t *planes, l
 
 __global__ void planes_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k);
 
-// schedule switches of the plane-fed kernels (A/B: CPC_PLANES_OPT=<bits>, read once)
-static int planes_opt()
-{
-    static const int v = getenv("CPC_PLANES_OPT") ? atoi(getenv("CPC_PLANES_OPT")) : 0;
-    return v;
-}
-
 bool gemm_nt_planes_ok(long M, int N, int K)
 {
     return N % PT_BN == 0 && K % (2 * PT_BK) == 0 && K >= 4 * PT_BK && M >= 1;
@@ -794,7 +773,6 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     }
     static const int dbg_env = getenv("CPC_PLANES_DBG") ? atoi(getenv("CPC_PLANES_DBG")) : 0;
     a.dbg = dbg_env;
-    a.opt = planes_opt();
     static unsigned long long *stamps = nullptr;
     if (a.dbg & 8) {
         if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 65536 * 8 * sizeof(unsigned long long)));
@@ -933,7 +911,6 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     a.rchunk = chunk;
     a.M = M; a.N = N; a.K = 0; a.slabs = static_cast<float *>(scratch);
     a.dbg = 0;
-    a.opt = planes_opt();
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
     a.xcd_remap = (!no_remap && S % 8 == 0 && (M / PT_BM) * (N / PT_BN) > 1) ? 1 : 0;
     {
