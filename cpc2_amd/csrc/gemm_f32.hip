@@ -23,6 +23,7 @@
 namespace cpc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // 0: bf16x6 split kernels (default); 1: native f32-MFMA kernels (the accuracy yardstick; also CPC_GEMM_NATIVE_F32=1)
 // Process-wide, deliberately: the one setting the library keeps between calls.  (Round 4 made it thread-local for a day -- and the
@@ -50,6 +51,8 @@ struct GemmNTArgs {
     int seg_rows, seg_valid;
     float *slabs;      // K split with ordered reduction: partial product of blockIdx.y goes to slabs + blockIdx.y * M * N
     int xcd_remap;     // split kernels: column panels of a row tile on one XCD (row tile count % 8 == 0, several panels)
+    int vec_out;       // x6 kernels: dense output in 16-byte pieces through LDS (no row map, no atomics; N, ldc % 4 == 0)
+    int dbg;           // -DX6_PROBE builds only: 1 no epilogue, 2 no split arithmetic, 4 no MFMAs, 8 no loads after the first K step
 };
 
 // acc[i][j][e] is C[m][n], m = m0 + wm*32*MI + i*32 + (e&3) + 8*(e>>2) + 4h, n = n0 + wn*64 + j*32 + r32
@@ -93,6 +96,57 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[M
             }
         }
     }
+}
+
+// Dense output tiles through LDS: the wave's 32-row blocks are staged one at a time in its own corner of the (by now idle)
+// operand tiles and leave as 16-byte stores of whole row segments -- 8 or 16 store instructions per 32-row block instead of 32
+// four-byte ones per MFMA tile.  With K = 256 the four-byte form was HALF of the NT kernel's time (predictor product 108 us, 59
+// without its epilogue; the FFN's first product 126 / 41: profiles/r04_x6_ladder.txt).
+// The wave's tile starts at (row0, col0); rows < row_end and columns < ncols (% 4 == 0) are stored; NT: non-temporal stores.
+template <int MI, int NJ>
+__device__ __forceinline__ void store_tile_staged(f32x16 (&acc)[MI][NJ], char *lds, int wave, int lane, float *outb, long ldo, long row0, long row_end,
+                                                  int col0, int ncols, const float *bias, bool nt)
+{
+    constexpr int W = 32 * NJ;              // columns of a wave
+    constexpr int LDW = W + 4;              // floats per staged row
+    constexpr int LPR = W / 4;              // lanes per row of 16-byte pieces
+    constexpr int RPI = 64 / LPR;           // rows per store instruction
+    float *const stg = reinterpret_cast<float *>(lds) + wave * 32 * LDW;
+    const int r32 = lane & 31, h = lane >> 5;
+    float bias_v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ncol = col0 + j * 32 + r32;
+        bias_v[j] = (bias != nullptr && ncol < ncols) ? bias[ncol] : 0.f;
+    }
+    const int c4 = (lane % LPR) * 4, rr = lane / LPR;
+    const int col = col0 + c4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * h) * LDW + j * 32 + r32] = acc[i][j][e] + bias_v[j];
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + rr;
+            const long m = row0 + i * 32 + row;
+            const float4 v = *reinterpret_cast<const float4 *>(stg + row * LDW + c4);
+            if (m < row_end && col < ncols) {
+                if (nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x4_t, v), reinterpret_cast<f32x4_t *>(outb + m * ldo + col));
+                else *reinterpret_cast<float4 *>(outb + m * ldo + col) = v;
+            }
+        }
+    }
+}
+
+template <int MI, int NJ>
+__device__ __forceinline__ void nt_epilogue_staged(const GemmNTArgs &p, f32x16 (&acc)[MI][NJ], char *lds, long m0, long m_end, int n0, int wave,
+                                                   int wm, int wn, int lane)
+{
+    float *const outb = p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.M * p.N : p.C;
+    store_tile_staged<MI, NJ>(acc, lds, wave, lane, outb, p.slabs != nullptr ? p.N : p.ldc, m0 + wm * 32 * MI, m_end, n0 + wn * 32 * NJ, p.N,
+                              blockIdx.y == 0 ? p.bias : nullptr, p.vec_out == 2);
 }
 
 // 4 consecutive elements k..k+3 of row `row` (k < K or zero).  Rows beyond row_max are CLAMPED, not zeroed:
@@ -262,12 +316,22 @@ __device__ __forceinline__ void split8_store(const float4 &u, const float4 &v, c
     *reinterpret_cast<uint4 *>(plane0 + 2 * plane_bytes + off) = w2;
 }
 
+// (-DX6_PROBE, dbg & 2: the same stores without the split's arithmetic)
+__device__ __forceinline__ void raw8_store(const float4 &u, const float4 &v, char *plane0, int plane_bytes, int off)
+{
+    uint4 w0 = make_uint4(__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(v.x), __float_as_uint(v.y));
+    uint4 w1 = make_uint4(__float_as_uint(u.z), __float_as_uint(u.w), __float_as_uint(v.z), __float_as_uint(v.w));
+    *reinterpret_cast<uint4 *>(plane0 + off) = w0;
+    *reinterpret_cast<uint4 *>(plane0 + plane_bytes + off) = w1;
+    *reinterpret_cast<uint4 *>(plane0 + 2 * plane_bytes + off) = w0;
+}
+
 __device__ __forceinline__ int x6_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 // MI x NJ 32x32 MFMA tiles per wave, waves 2 x 2: block tile (64 MI) x (64 NJ).  (2, 2): 128 x 128, three workgroups
 // per CU; (2, 4): 128 x 256 -- for N = 256 the A panel is then read, split and staged once -- two per CU; (1, 2)
 // for small problems.
-template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_x6_kernel(GemmNTArgs p)
+template <int MI, int NJ, int DBG = 0> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_x6_kernel(GemmNTArgs p)
 {
     constexpr int BM = 64 * MI, BNX = 64 * NJ;
     constexpr int PA = BM * 64, PB = BNX * 64;             // bytes per plane
@@ -340,14 +404,22 @@ template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) voi
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    constexpr int dbg = DBG;
     load_tiles(0);
     for (int kt = 0; kt < nk; ++kt) {
+        if constexpr ((dbg & 2) != 0) {
+#pragma unroll
+            for (int q = 0; q < MI; ++q) raw8_store(ra[q][0], ra[q][1], As, PA, x6_off(lrow + 64 * q, lchunk));
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) raw8_store(rb[q][0], rb[q][1], Bs, PB, x6_off(lrow + 64 * q, lchunk));
+        } else {
 #pragma unroll
         for (int q = 0; q < MI; ++q) split8_store(ra[q][0], ra[q][1], As, PA, x6_off(lrow + 64 * q, lchunk));
 #pragma unroll
         for (int q = 0; q < NJ; ++q) split8_store(rb[q][0], rb[q][1], Bs, PB, x6_off(lrow + 64 * q, lchunk));
+        }
         __syncthreads();
-        if (kt + 1 < nk) load_tiles(kt + 1);
+        if (kt + 1 < nk && !(dbg & 8)) load_tiles(kt + 1);
 
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -371,6 +443,7 @@ template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) voi
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         f32x16 &c = acc[i][jp + j];
+                        if constexpr ((dbg & 4) != 0) { c[0] += (float)fa[i][0][0] + (float)fb[j][1][0] + (float)fa[i][2][1] + (float)fb[j][2][0] + (float)fa[i][1][0] + (float)fb[j][0][0]; continue; }
                         // smallest terms first
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
@@ -383,7 +456,10 @@ template <int MI, int NJ> __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) voi
         }
         __syncthreads();
     }
-    nt_epilogue<MI, NJ>(p, acc, m0, m_end, n0, wm, wn, r32, h);
+    if constexpr ((dbg & 1) != 0) { if (acc[0][0][0] == 123.456f) p.C[0] = acc[MI - 1][NJ - 1][3]; return; }
+    static_assert(4 * 32 * (32 * NJ + 4) * 4 <= 3 * (PA + PB), "the staged epilogue lives in the operand tiles");
+    if (p.vec_out) nt_epilogue_staged<MI, NJ>(p, acc, lds, m0, m_end, n0, wave, wm, wn, lane);      // (behind the loop's last barrier)
+    else nt_epilogue<MI, NJ>(p, acc, m0, m_end, n0, wm, wn, r32, h);
 }
 
 __global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k);
@@ -412,6 +488,10 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     a.M = M; a.N = N; a.K = K; a.map = map;
     a.aligned = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                 ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0);
+    a.dbg = 0;
+#ifdef X6_PROBE
+    if (getenv("X6_DBG")) a.dbg = atoi(getenv("X6_DBG"));
+#endif
     const bool native = g_gemm_mode.load() == 1;
     const bool split_kernels = a.aligned && !native;
     // segmented row tiling (split kernels): never multiply the junk rows at the end of a sample
@@ -448,11 +528,22 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
         reinterpret_cast<uintptr_t>(map.splitk_scratch) % 16 == 0 && M <= 2147483647L)
         a.slabs = static_cast<float *>(map.splitk_scratch);
     if (splits > 1 && a.slabs == nullptr) CPC_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st));
+    // dense outputs leave in 16-byte pieces through LDS (nt_epilogue_staged); non-temporal once the output is larger than the L2s
+    // together (it is read back from the memory side either way: measured -0.03 .. -0.05 ms per step on the transformer / large
+    // configurations, nothing at CPC-small)
+    a.vec_out = (!map.enabled && (splits == 1 || a.slabs != nullptr) && N % 4 == 0 && ldc % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0)
+                    ? ((size_t)M * N * sizeof(float) >= (32u << 20) ? 2 : 1) : 0;
     dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);
     if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
     else if (native && mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
     else if (native) hipLaunchKernelGGL((gemm_nt_kernel<true, 2>), grid, dim3(256), 0, st, a);
+#ifdef X6_PROBE
+#define X6_CASE(D) else if (a.dbg == D && nj == 4) hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 4, D>), grid, dim3(256), 0, st, a); \
+    else if (a.dbg == D && mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1, 2, D>), grid, dim3(256), 0, st, a); \
+    else if (a.dbg == D) hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 2, D>), grid, dim3(256), 0, st, a);
+    X6_CASE(1) X6_CASE(2) X6_CASE(4) X6_CASE(8) X6_CASE(3) X6_CASE(6) X6_CASE(14) X6_CASE(15)
+#endif
     else if (nj == 4) hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 4>), grid, dim3(256), 0, st, a);
     else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 2>), grid, dim3(256), 0, st, a);
@@ -696,6 +787,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_x6_kernel(GemmTNArgs p)
 
     // slab[z][i][j]: i = i0 + wm*64 + it*32 + (e&3) + 8*(e>>2) + 4h ; j = j0 + wn*64 + jt*32 + r32
     float *slab = p.slab + (long)bz * p.M * p.N;
+    // (16-byte pieces through LDS as in the NT kernel were measured here too: no difference -- tools/scratch/ab_tn_out.sh)
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
