@@ -78,6 +78,30 @@ private:
 struct ConvGeom { int k, s, p; };
 static const ConvGeom kConv[5] = {{10, 5, 3}, {8, 4, 2}, {4, 2, 1}, {4, 2, 1}, {4, 2, 1}};
 
+// ---- dropout: counter-based hash keyed by (seed, element index) -- the same mask wherever it is recomputed ----
+#ifdef __HIPCC__
+// (32-bit arithmetic throughout: the murmur3 finaliser over the index, keyed by two words derived from the seed -- those are wave
+//  uniform, i.e. scalar-unit work.  The splitmix64 finaliser used until round 4 cost three 64-bit multiplies per element: a third
+//  of the FFN activation's product once the mask moved into its epilogue.)
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t idx)
+{
+    const uint32_t s1 = fmix32((uint32_t)seed ^ 0x9E3779B9u), s2 = fmix32((uint32_t)(seed >> 32) + 0x7F4A7C15u + s1);
+    return fmix32((((uint32_t)idx ^ s1) * 0x9E3779B1u) + ((uint32_t)(idx >> 32) ^ s2) * 0x85EBCA77u + s2);
+}
+// multiplier applied to a kept/dropped element: 1/(1-p) or 0 (thresh = p * 2^32; thresh == 0 -> always 1)
+__device__ __forceinline__ float drop_mul(uint64_t seed, uint64_t idx, uint32_t thresh, float scale)
+{
+    return (thresh == 0u || hash32(seed, idx) >= thresh) ? scale : 0.f;
+}
+#endif
+
 // ---- row mapping of a GEMM epilogue: virtual row m -> output row (or skip) ----
 struct RowMap {
     int enabled;      // 0: crow = m
@@ -96,7 +120,16 @@ struct RowMap {
     // atomics, in whatever order the workgroups arrive.  Size: gemm_nt_scratch_bytes(M, N, K)
     void *splitk_scratch;
     size_t splitk_bytes;
+    // elementwise work fused into the store of a DENSE output (no row map, ldc == N, no K split; gemm_nt refuses otherwise):
+    //   EPI_RELU_DROPOUT: c = v > 0 ? v * drop_mul(seed, m * N + n) : 0      (the FFN's activation, transformers.py:112-116)
+    //   EPI_GATE:         c = gate[m * N + n] > 0 ? v * scale : 0            (its adjoint: gate = the activation's output)
+    int epi;
+    unsigned long long epi_seed;
+    unsigned epi_thresh;
+    float epi_scale;
+    const float *epi_gate;
 };
+enum { EPI_NONE = 0, EPI_RELU_DROPOUT = 1, EPI_GATE = 2 };
 
 // ---- internal launchers (defined in gemm_f32.hip / rowops.hip) ----
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,

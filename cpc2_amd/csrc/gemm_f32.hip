@@ -103,41 +103,75 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs &p, f32x16 (&acc)[M
 // four-byte ones per MFMA tile.  With K = 256 the four-byte form was HALF of the NT kernel's time (predictor product 108 us, 59
 // without its epilogue; the FFN's first product 126 / 41: profiles/r04_x6_ladder.txt).
 // The wave's tile starts at (row0, col0); rows < row_end and columns < ncols (% 4 == 0) are stored; NT: non-temporal stores.
-template <int MI, int NJ>
-__device__ __forceinline__ void store_tile_staged(f32x16 (&acc)[MI][NJ], char *lds, int wave, int lane, float *outb, long ldo, long row0, long row_end,
-                                                  int col0, int ncols, const float *bias, bool nt)
+// one 32-row block of the wave's tile: registers -> the wave's staging rows -> memory
+template <int NJ>
+__device__ __forceinline__ void store_block_staged(const f32x16 (&acc)[NJ], const float (&bias_v)[NJ], float *stg, int lane, float *outb, long ldo,
+                                                   long row0, long row_end, int col0, int ncols, bool nt, const RowMap *epi)
 {
     constexpr int W = 32 * NJ;              // columns of a wave
     constexpr int LDW = W + 4;              // floats per staged row
     constexpr int LPR = W / 4;              // lanes per row of 16-byte pieces
     constexpr int RPI = 64 / LPR;           // rows per store instruction
-    float *const stg = reinterpret_cast<float *>(lds) + wave * 32 * LDW;
     const int r32 = lane & 31, h = lane >> 5;
-    float bias_v[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int ncol = col0 + j * 32 + r32;
-        bias_v[j] = (bias != nullptr && ncol < ncols) ? bias[ncol] : 0.f;
-    }
     const int c4 = (lane % LPR) * 4, rr = lane / LPR;
     const int col = col0 + c4;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * h) * LDW + j * 32 + r32] = acc[i][j][e] + bias_v[j];
+        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * h) * LDW + j * 32 + r32] = acc[j][e] + bias_v[j];
+    if (epi == nullptr) {
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
             const int row = it * RPI + rr;
-            const long m = row0 + i * 32 + row;
+            const long m = row0 + row;
             const float4 v = *reinterpret_cast<const float4 *>(stg + row * LDW + c4);
             if (m < row_end && col < ncols) {
                 if (nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x4_t, v), reinterpret_cast<f32x4_t *>(outb + m * ldo + col));
                 else *reinterpret_cast<float4 *>(outb + m * ldo + col) = v;
             }
         }
+        return;
     }
+    // with elementwise work (a real loop: nothing here indexes the accumulators)
+#pragma unroll 1
+    for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + rr;
+        const long m = row0 + row;
+        float4 v = *reinterpret_cast<const float4 *>(stg + row * LDW + c4);
+        if (m < row_end && col < ncols) {
+            if (epi->epi == EPI_RELU_DROPOUT) {
+                const uint64_t idx = (uint64_t)(m * ldo + col);
+                v.x = v.x > 0.f ? v.x * drop_mul(epi->epi_seed, idx, epi->epi_thresh, epi->epi_scale) : 0.f;
+                v.y = v.y > 0.f ? v.y * drop_mul(epi->epi_seed, idx + 1, epi->epi_thresh, epi->epi_scale) : 0.f;
+                v.z = v.z > 0.f ? v.z * drop_mul(epi->epi_seed, idx + 2, epi->epi_thresh, epi->epi_scale) : 0.f;
+                v.w = v.w > 0.f ? v.w * drop_mul(epi->epi_seed, idx + 3, epi->epi_thresh, epi->epi_scale) : 0.f;
+            } else {
+                const float4 g = *reinterpret_cast<const float4 *>(epi->epi_gate + m * ldo + col);
+                v.x = g.x > 0.f ? v.x * epi->epi_scale : 0.f;
+                v.y = g.y > 0.f ? v.y * epi->epi_scale : 0.f;
+                v.z = g.z > 0.f ? v.z * epi->epi_scale : 0.f;
+                v.w = g.w > 0.f ? v.w * epi->epi_scale : 0.f;
+            }
+            if (nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x4_t, v), reinterpret_cast<f32x4_t *>(outb + m * ldo + col));
+            else *reinterpret_cast<float4 *>(outb + m * ldo + col) = v;
+        }
+    }
+}
+
+template <int MI, int NJ>
+__device__ __forceinline__ void store_tile_staged(f32x16 (&acc)[MI][NJ], char *lds, int wave, int lane, float *outb, long ldo, long row0, long row_end,
+                                                  int col0, int ncols, const float *bias, bool nt, const RowMap *epi = nullptr)
+{
+    static_assert(MI == 1 || MI == 2, "row blocks are spelled out so that the accumulators are never indexed by a loop variable");
+    float *const stg = reinterpret_cast<float *>(lds) + wave * 32 * (32 * NJ + 4);
+    float bias_v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ncol = col0 + j * 32 + (lane & 31);
+        bias_v[j] = (bias != nullptr && ncol < ncols) ? bias[ncol] : 0.f;
+    }
+    store_block_staged<NJ>(acc[0], bias_v, stg, lane, outb, ldo, row0, row_end, col0, ncols, nt, epi);
+    if constexpr (MI == 2) store_block_staged<NJ>(acc[1], bias_v, stg, lane, outb, ldo, row0 + 32, row_end, col0, ncols, nt, epi);
 }
 
 template <int MI, int NJ>
@@ -146,7 +180,7 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNTArgs &p, f32x16 (
 {
     float *const outb = p.slabs != nullptr ? p.slabs + (long)blockIdx.y * p.M * p.N : p.C;
     store_tile_staged<MI, NJ>(acc, lds, wave, lane, outb, p.slabs != nullptr ? p.N : p.ldc, m0 + wm * 32 * MI, m_end, n0 + wn * 32 * NJ, p.N,
-                              blockIdx.y == 0 ? p.bias : nullptr, p.vec_out == 2);
+                              blockIdx.y == 0 ? p.bias : nullptr, p.vec_out == 2, p.map.epi != EPI_NONE ? &p.map : nullptr);
 }
 
 // 4 consecutive elements k..k+3 of row `row` (k < K or zero).  Rows beyond row_max are CLAMPED, not zeroed:
@@ -479,6 +513,16 @@ size_t gemm_nt_scratch_bytes(long M, int N, int K)
     return s > 1 ? align_up(sizeof(float) * (size_t)(s + 1) * M * N, 256) : 0;
 }
 
+// RowMap::epi as a pass of its own, for the kernels whose epilogue does not do it (f32-MFMA yardstick, unaligned shapes)
+__global__ void epi_pass_kernel(float *c, long n, RowMap map)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = c[i];
+        if (map.epi == EPI_RELU_DROPOUT) c[i] = v > 0.f ? v * drop_mul(map.epi_seed, (uint64_t)i, map.epi_thresh, map.epi_scale) : 0.f;
+        else c[i] = map.epi_gate[i] > 0.f ? v * map.epi_scale : 0.f;
+    }
+}
+
 int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long ldc, const float *bias,
             long M, int N, int K, const RowMap &map, hipStream_t st)
 {
@@ -516,7 +560,7 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     // few tiles but a long K (e.g. dC = dP . W, K = 12 H): split K over blockIdx.y, partial products are
     // atomically added into a zeroed C (dense, unmapped outputs only)
     int splits = 1;
-    if (a.aligned && !map.enabled && ldc == N) splits = nt_splits(blocks, K);
+    if (a.aligned && !map.enabled && ldc == N && map.epi == EPI_NONE) splits = nt_splits(blocks, K);
     a.kchunk = (int)(cdiv(cdiv(K, splits), BK) * BK);
     splits = (int)cdiv(K, a.kchunk);
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
@@ -533,6 +577,9 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     // configurations, nothing at CPC-small)
     a.vec_out = (!map.enabled && (splits == 1 || a.slabs != nullptr) && N % 4 == 0 && ldc % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0)
                     ? ((size_t)M * N * sizeof(float) >= (32u << 20) ? 2 : 1) : 0;
+    CPC_REQUIRE(map.epi == EPI_NONE || (!map.enabled && splits == 1 && ldc == N),
+                "gemm_nt: a fused elementwise epilogue needs a dense output (M=%ld N=%d K=%d ldc=%ld)", M, N, K, ldc);
+    const bool epi_pass = map.epi != EPI_NONE && !(a.vec_out != 0 && split_kernels);     // (only the staged store does it in place)
     dim3 grid((unsigned)blocks, (unsigned)splits);
     ProfScope prof(PROF_GEMM_NT, st);
     if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
@@ -548,6 +595,10 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
     else if (mi == 1) hipLaunchKernelGGL((gemm_nt_x6_kernel<1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_nt_x6_kernel<2, 2>), grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_nt_kernel");
+    if (epi_pass) {
+        hipLaunchKernelGGL(epi_pass_kernel, dim3((unsigned)std::min<long>(cdiv(M * N, 256), 4096)), dim3(256), 0, st, C, M * N, map);
+        CPC_CHECK_LAUNCH("epi_pass_kernel");
+    }
     if (a.slabs != nullptr) {
         const long total = M * N;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, a.slabs,

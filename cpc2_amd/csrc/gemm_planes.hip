@@ -744,6 +744,7 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
                    const RowMap &map, hipStream_t st, const PlanesNormOut *norm)
 {
     CPC_REQUIRE(gemm_nt_planes_ok(M, N, K), "gemm_nt_planes: shape M=%ld N=%d K=%d not supported", M, N, K);
+    CPC_REQUIRE(map.epi == EPI_NONE, "gemm_nt_planes: no fused elementwise epilogue in this kernel");
     CPC_REQUIRE(norm == nullptr || (gemm_nt_planes_norm_ok(M, N, K) && map.enabled && map.out_stride == 1 && map.out_off == 0 &&
                                     map.col_rows == 0 && norm->gamma && norm->beta && norm->rstd && norm->p && gemm_mode() != 2 &&
                                     reinterpret_cast<uintptr_t>(norm->p) % 8 == 0 && norm->plane % 4 == 0),

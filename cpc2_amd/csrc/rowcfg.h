@@ -31,6 +31,16 @@ template <int G> __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
+// max over an aligned group of 32 lanes, left in every lane (same hops as group_sum)
+__device__ __forceinline__ float group_max32(float v)
+{
+    v = fmaxf(v, row_dpp<0xB1>(v));
+    v = fmaxf(v, row_dpp<0x4E>(v));
+    v = fmaxf(v, row_dpp<0x141>(v));
+    v = fmaxf(v, row_dpp<0x140>(v));
+    return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+
 static inline bool supported_row_width(int H) { return H == 32 || H == 64 || H == 128 || H == 256 || H == 512; }
 static inline int rows_per_wave(int H) { return 64 / (H / 4 < 64 ? H / 4 : 64); }
 

@@ -15,26 +15,13 @@
 #include "rowcfg.h"
 
 #include <algorithm>
+#include <vector>
 #include <cmath>
 
 namespace cpc {
 
 constexpr int TR_HEADS = 8;          // transformers.py:120 (nheads=8)
 constexpr int TR_QT = 32;            // query rows per attention tile
-
-__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t idx)
-{
-    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;          // splitmix64 finaliser
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 32);
-}
-// multiplier applied to a kept/dropped element: 1/(1-p) or 0 (thresh = p * 2^32; thresh == 0 -> always 1)
-__device__ __forceinline__ float drop_mul(uint64_t seed, uint64_t idx, uint32_t thresh, float scale)
-{
-    return (thresh == 0u || hash32(seed, idx) >= thresh) ? scale : 0.f;
-}
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 struct LnArgs {
@@ -163,21 +150,6 @@ template <int D> __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
-__global__ void relu_dropout_fwd_kernel(float *h, long n, uint64_t seed, uint32_t thresh, float scale)
-{
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float v = h[i];
-        h[i] = v > 0.f ? v * drop_mul(seed, (uint64_t)i, thresh, scale) : 0.f;
-    }
-}
-
-// h holds relu(.)*mask*scale: an element carries gradient iff it is > 0
-__global__ void relu_dropout_bwd_kernel(float *dh, const float *h, long n, float scale)
-{
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dh[i] = h[i] > 0.f ? dh[i] * scale : 0.f;
-}
-
 __global__ void add2_kernel(float *out, const float *a, const float *b, long n4)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -235,6 +207,7 @@ struct AttnArgs {
     const float *dctx;     // [N*S][D]
     float *dqkv;           // [N*S][3D]
     float *dkrel_part;     // [N*heads*chunks][dk][SS]
+    unsigned long long *stamps;   // -DAT_STAMPS builds (probes): [workgroup][wave][8] s_memrealtime at the phase boundaries
 };
 
 // one workgroup per (sequence chunk of one head, 32-row query tile)
@@ -348,6 +321,79 @@ __device__ __forceinline__ void at_mfma4(at_f32x16 &acc, const float4 &a4, const
 __device__ __forceinline__ int at_row(int e, int h2) { return (e & 3) + 8 * (e >> 2) + 4 * h2; }   // C/D row of register e
 __device__ __forceinline__ void at_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
+#ifdef AT_STAMPS
+#define AT_STAMP(i) do { if ((threadIdx.x & 63) == 0) a.stamps[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AT_STAMP(i) do { } while (0)
+#endif
+// Softmax of the wave's 32 query rows over the column tiles jt <= w, the probabilities to memory and their dropped-out copy to the
+// wave's LDS tile.  In sweeps over the 16 rows a lane holds -- row maxima, exponentials + row sums, normalisation + stores -- with
+// the tile loop outside and no per-element branch: with one wave per SIMD (121 KB of LDS per workgroup) nothing hides the latency
+// of a dependent chain or the bubble of a branch, and the first form of this code (a branch per element for the tile bound, the
+// sequence bound and the dropout switch, five crossbar hops per reduction) took 18 us of the wave's 41 (stamps: -DAT_STAMPS).
+// Base-2 exponentials: the scores are scaled by log2(e) / sqrt(dk) in the one multiplication they get anyway.
+// FULL: sizeSeq == 128 (no bound checks); DROP: dropout on.
+template <bool FULL, bool DROP>
+__device__ __forceinline__ void at_softmax_store(const AttnArgs &a, at_f32x16 (&sc)[4], float *Pw, int cid, int w, int r32, int h2)
+{
+    const int SS = a.SS;
+    const float c2 = a.inv_sqrt_dk * 1.44269504088896341f;
+    float mx[16], sm[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = 32 * w + at_row(e, h2);
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = 32 * jt + r32;
+            const bool ok = jt <= w && j <= i && (FULL || i < SS);
+            sc[jt][e] = ok ? sc[jt][e] * c2 : -INFINITY;
+            m = fmaxf(m, sc[jt][e]);
+        }
+        mx[e] = m;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        mx[e] = group_max32(mx[e]);
+        if (!FULL) mx[e] = mx[e] == -INFINITY ? 0.f : mx[e];      // (a row past the sequence: every exponential below is exp2(-inf) = 0)
+        sm[e] = 0.f;
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+        if (jt <= w) {                                             // (wave uniform)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sc[jt][e] = __builtin_amdgcn_exp2f(sc[jt][e] - mx[e]);
+                sm[e] += sc[jt][e];
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float t = group_sum<32>(sm[e]);
+        float r = __builtin_amdgcn_rcpf(t);
+        r = r * (2.f - t * r);                                      // one Newton step: the quotient is as good as a division's
+        sm[e] = t > 0.f ? r : 0.f;
+    }
+    AT_STAMP(7);
+    float *const pb = a.probs + (long)cid * SS * SS;                // (uniform)
+    const uint64_t ib = (uint64_t)cid * SS * SS;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+        if (jt <= w) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int il = at_row(e, h2), i = 32 * w + il, j = 32 * jt + r32;
+                const float p = sc[jt][e] * sm[e];
+                const int off = i * SS + j;
+                float pd = DROP ? p * drop_mul(a.seed, ib + (uint64_t)off, a.thresh, a.scale) : p;
+                if (FULL) pb[off] = p;
+                else if (i < SS && j < SS) pb[off] = p;
+                else pd = 0.f;
+                Pw[il * AT_LP + j] = pd;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -361,34 +407,54 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
     const int head = nh % TR_HEADS, n = nh / TR_HEADS;
     const long row0 = (long)n * a.S + (long)c * SS;
     const int tid = threadIdx.x;
-
-    for (int i = tid; i < 128 * 8; i += 256) {
-        const int j = i >> 3, d4 = (i & 7) * 4;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (j < SS) {
-            const float *src = a.qkv + (row0 + j) * 3 * a.D + head * 32 + d4;
-            kv = *reinterpret_cast<const float4 *>(src + a.D);
-            vv = *reinterpret_cast<const float4 *>(src + 2 * a.D);
-        }
-        *reinterpret_cast<float4 *>(&Ks[j * AT_LD + d4]) = kv;
-        VsT[(d4 + 0) * AT_LP + j] = vv.x; VsT[(d4 + 1) * AT_LP + j] = vv.y;
-        VsT[(d4 + 2) * AT_LP + j] = vv.z; VsT[(d4 + 3) * AT_LP + j] = vv.w;
-    }
-    if (a.krel != nullptr)
-        for (int i = tid; i < 32 * 128; i += 256) {
-            const int d = i >> 7, m = i & 127;
-            RsT[m * AT_LD + d] = m < SS ? a.krel[d * SS + m] : 0.f;
-        }
-    __syncthreads();
-
+    AT_STAMP(0);
     const int lane = tid & 63, w = tid >> 6, r32 = lane & 31, h2 = lane >> 5;
     float *Pw = Ps + w * 32 * AT_LP;
-    const int iq = 32 * w + r32;                                 // this lane's A-operand row
+    const int iq = 32 * w + r32;                                 // this lane's A-operand row (requested first: in flight under the staging)
     float4 qf[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         qf[q] = iq < SS ? *reinterpret_cast<const float4 *>(a.qkv + (row0 + iq) * 3 * a.D + head * 32 + 8 * q + 4 * h2)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    {   // staging: every load requested before the first LDS store (see attn_bwd_mfma_kernel)
+        float4 kv[4], vv[4], r4[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it, j = i >> 3, d4 = (i & 7) * 4;
+            kv[it] = make_float4(0.f, 0.f, 0.f, 0.f); vv[it] = kv[it];
+            if (j < SS) {
+                const float *src = a.qkv + (row0 + j) * 3 * a.D + head * 32 + d4;
+                kv[it] = *reinterpret_cast<const float4 *>(src + a.D);
+                vv[it] = *reinterpret_cast<const float4 *>(src + 2 * a.D);
+            }
+        }
+        if (a.krel != nullptr) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {                     // thread: position m, four head channels (one 16-byte LDS store)
+                const int i = tid + 256 * it, d4 = (i >> 7) * 4, m = i & 127;
+                r4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < SS) r4[it] = make_float4(a.krel[d4 * SS + m], a.krel[(d4 + 1) * SS + m], a.krel[(d4 + 2) * SS + m], a.krel[(d4 + 3) * SS + m]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it, j = i >> 3, d4 = (i & 7) * 4;
+            *reinterpret_cast<float4 *>(&Ks[j * AT_LD + d4]) = kv[it];
+            VsT[(d4 + 0) * AT_LP + j] = vv[it].x; VsT[(d4 + 1) * AT_LP + j] = vv[it].y;
+            VsT[(d4 + 2) * AT_LP + j] = vv[it].z; VsT[(d4 + 3) * AT_LP + j] = vv[it].w;
+        }
+        if (a.krel != nullptr) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int i = tid + 256 * it, d4 = (i >> 7) * 4, m = i & 127;
+                *reinterpret_cast<float4 *>(&RsT[m * AT_LD + d4]) = r4[it];
+            }
+        }
+    }
+    __syncthreads();
+    AT_STAMP(1);
+
     at_f32x16 sc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -400,6 +466,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
                 at_mfma4(sc[jt], qf[q], *reinterpret_cast<const float4 *>(&Ks[(32 * jt + r32) * AT_LD + 8 * q + 4 * h2]));
         }
     }
+    AT_STAMP(2);
     if (a.krel != nullptr) {
         const int m_min = SS - 32 * w - 32 > 0 ? SS - 32 * w - 32 : 0;
         for (int mt = m_min >> 5; mt <= (SS - 1) >> 5; ++mt) {
@@ -413,55 +480,36 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
             for (int e = 0; e < 16; ++e) Pw[at_row(e, h2) * AT_LP + 32 * mt + r32] = racc[e];
         }
         at_wave_sync();
+        // (every read unconditional, at a clamped position, and selected afterwards: sixteen reads of a tile are then in flight
+        //  together instead of one branch and one wait per element)
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
             if (jt <= w) {
+                float rv[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int il = at_row(e, h2), i = 32 * w + il, j = 32 * jt + r32;
-                    if (j <= i && i < SS) sc[jt][e] += Pw[il * AT_LP + SS - 1 - i + j];
+                    rv[e] = Pw[il * AT_LP + min(SS - 1 - i + j, AT_LP - 1)];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = 32 * w + at_row(e, h2), j = 32 * jt + r32;
+                    sc[jt][e] += (j <= i && i < SS) ? rv[e] : 0.f;
                 }
             }
         at_wave_sync();                                          // Pw is reused for Pd below
     }
-    // softmax over j <= i, row by row (a row lives in one 32-lane half, over the tiles jt <= w)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int il = at_row(e, h2), i = 32 * w + il;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = 32 * jt + r32;
-            const bool ok = jt <= w && j <= i && i < SS;
-            sc[jt][e] = ok ? sc[jt][e] * a.inv_sqrt_dk : -INFINITY;
-            mx = fmaxf(mx, sc[jt][e]);
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            sc[jt][e] = sc[jt][e] == -INFINITY ? 0.f : expf(sc[jt][e] - mx);
-            sum += sc[jt][e];
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        const float inv = sum > 0.f ? 1.f / sum : 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            if (jt > w) continue;
-            const int j = 32 * jt + r32;
-            const float p = sc[jt][e] * inv;
-            float pd = 0.f;
-            if (i < SS && j < SS) {
-                const long idx = ((long)cid * SS + i) * SS + j;
-                a.probs[idx] = p;
-                pd = p * drop_mul(a.seed, (uint64_t)idx, a.thresh, a.scale);
-            }
-            Pw[il * AT_LP + j] = pd;
-        }
+    AT_STAMP(3);
+    // softmax over j <= i (a row lives in one 32-lane half, over the tiles jt <= w): at_softmax_store
+    if (SS == 128) {
+        if (a.thresh != 0u) at_softmax_store<true, true>(a, sc, Pw, cid, w, r32, h2);
+        else at_softmax_store<true, false>(a, sc, Pw, cid, w, r32, h2);
+    } else {
+        if (a.thresh != 0u) at_softmax_store<false, true>(a, sc, Pw, cid, w, r32, h2);
+        else at_softmax_store<false, false>(a, sc, Pw, cid, w, r32, h2);
     }
     at_wave_sync();
+    AT_STAMP(4);
     // ctx = Pd V over j < 32 (w + 1)
     at_f32x16 cx;
 #pragma unroll
@@ -474,6 +522,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a)
         const int i = 32 * w + at_row(e, h2);
         if (i < SS) a.ctx[(row0 + i) * a.D + head * 32 + r32] = cx[e];
     }
+    AT_STAMP(5);
+#ifdef AT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AT_STAMP(6);
+#endif
 }
 
 // Backward twin (head size 32, sizeSeq <= 128), same workgroup / wave decomposition.  Wave w owns query rows 32w.. for
@@ -502,24 +555,43 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
     const int tid = threadIdx.x;
     const bool rel = a.krel != nullptr;
 
-    for (int i = tid; i < 128 * 8; i += 256) {
-        const int j = i >> 3, d4 = (i & 7) * 4;
-        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, o4 = q4;
-        if (j < SS) {
-            const float *src = a.qkv + (row0 + j) * 3 * a.D + head * 32 + d4;
-            q4 = *reinterpret_cast<const float4 *>(src);
-            k4 = *reinterpret_cast<const float4 *>(src + a.D);
-            v4 = *reinterpret_cast<const float4 *>(src + 2 * a.D);
-            o4 = *reinterpret_cast<const float4 *>(a.dctx + (row0 + j) * a.D + head * 32 + d4);
+    AT_STAMP(0);
+    // staging: every load of the thread requested before the first LDS store (a `for (i = tid; ...; i += 256)` loop is not unrolled --
+    // its trip count depends on tid -- and then waits for the loads of one iteration before it requests the next: four, resp. sixteen,
+    // round trips to memory in a row, 7.5 of this workgroup's 37 us)
+    {
+        float4 q4[4], k4[4], v4[4], o4[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it, j = i >> 3, d4 = (i & 7) * 4;
+            q4[it] = make_float4(0.f, 0.f, 0.f, 0.f); k4[it] = q4[it]; v4[it] = q4[it]; o4[it] = q4[it];
+            if (j < SS) {
+                const float *src = a.qkv + (row0 + j) * 3 * a.D + head * 32 + d4;
+                q4[it] = *reinterpret_cast<const float4 *>(src);
+                k4[it] = *reinterpret_cast<const float4 *>(src + a.D);
+                v4[it] = *reinterpret_cast<const float4 *>(src + 2 * a.D);
+                o4[it] = *reinterpret_cast<const float4 *>(a.dctx + (row0 + j) * a.D + head * 32 + d4);
+            }
         }
-        *reinterpret_cast<float4 *>(&Vs[j * AT_LD + d4]) = v4;
-        QT[(d4 + 0) * AT_LP + j] = q4.x; QT[(d4 + 1) * AT_LP + j] = q4.y; QT[(d4 + 2) * AT_LP + j] = q4.z; QT[(d4 + 3) * AT_LP + j] = q4.w;
-        KT[(d4 + 0) * AT_LP + j] = k4.x; KT[(d4 + 1) * AT_LP + j] = k4.y; KT[(d4 + 2) * AT_LP + j] = k4.z; KT[(d4 + 3) * AT_LP + j] = k4.w;
-        OT[(d4 + 0) * AT_LP + j] = o4.x; OT[(d4 + 1) * AT_LP + j] = o4.y; OT[(d4 + 2) * AT_LP + j] = o4.z; OT[(d4 + 3) * AT_LP + j] = o4.w;
-    }
-    for (int i = tid; i < 32 * 128; i += 256) {
-        const int d = i >> 7, m = i & 127;
-        Rk[d * AT_LP + m] = (rel && m < SS) ? a.krel[d * SS + m] : 0.f;
+        float rk[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int i = tid + 256 * it, d = i >> 7, m = i & 127;
+            rk[it] = (rel && m < SS) ? a.krel[d * SS + m] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it, j = i >> 3, d4 = (i & 7) * 4;
+            *reinterpret_cast<float4 *>(&Vs[j * AT_LD + d4]) = v4[it];
+            QT[(d4 + 0) * AT_LP + j] = q4[it].x; QT[(d4 + 1) * AT_LP + j] = q4[it].y; QT[(d4 + 2) * AT_LP + j] = q4[it].z; QT[(d4 + 3) * AT_LP + j] = q4[it].w;
+            KT[(d4 + 0) * AT_LP + j] = k4[it].x; KT[(d4 + 1) * AT_LP + j] = k4[it].y; KT[(d4 + 2) * AT_LP + j] = k4[it].z; KT[(d4 + 3) * AT_LP + j] = k4[it].w;
+            OT[(d4 + 0) * AT_LP + j] = o4[it].x; OT[(d4 + 1) * AT_LP + j] = o4[it].y; OT[(d4 + 2) * AT_LP + j] = o4[it].z; OT[(d4 + 3) * AT_LP + j] = o4[it].w;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int i = tid + 256 * it, d = i >> 7, m = i & 127;
+            Rk[d * AT_LP + m] = rk[it];
+        }
     }
 
     const int lane = tid & 63, w = tid >> 6, r32 = lane & 31, h2 = lane >> 5;
@@ -530,7 +602,24 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
     for (int q = 0; q < 4; ++q)
         of[q] = iq < SS ? *reinterpret_cast<const float4 *>(a.dctx + (row0 + iq) * a.D + head * 32 + 8 * q + 4 * h2)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    // the probabilities of this wave's rows, requested before anything needs them (the first form read each one inside the branch that
+    // used it: 64 exposed round trips to memory, 33 of the workgroup's 60 us -- stamps, -DAT_STAMPS); masked positions read element 0
+    float pv[4][16];
+    const float *const pb = a.probs + (long)cid * SS * SS;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pv[jt][e] = 0.f;
+        if (jt <= w) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = 32 * w + at_row(e, h2), j = 32 * jt + r32;
+                pv[jt][e] = pb[(j <= i && i < SS) ? i * SS + j : 0];
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (the staging only: __syncthreads would also wait for the loads above)
+    AT_STAMP(1);
     at_f32x16 ds[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -542,42 +631,46 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
                 at_mfma4(ds[jt], of[q], *reinterpret_cast<const float4 *>(&Vs[(32 * jt + r32) * AT_LD + 8 * q + 4 * h2]));
         }
     }
+    {
+        float rs[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int il = at_row(e, h2), i = 32 * w + il;
-        float pv[4], rs = 0.f;
+        for (int e = 0; e < 16; ++e) rs[e] = 0.f;
+        const uint64_t ib = (uint64_t)cid * SS * SS;
+        const bool drop = a.thresh != 0u;                        // (uniform)
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = 32 * jt + r32;
-            pv[jt] = 0.f;
-            float da = 0.f;
+        for (int jt = 0; jt < 4; ++jt)
             if (jt <= w) {
-                float pd = 0.f;
-                if (j <= i && i < SS) {
-                    const long idx = ((long)cid * SS + i) * SS + j;
-                    const float mul = drop_mul(a.seed, (uint64_t)idx, a.thresh, a.scale);
-                    pv[jt] = a.probs[idx];
-                    pd = pv[jt] * mul;
-                    da = ds[jt][e] * mul;                   // d loss / d P (through the dropout)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = 32 * w + at_row(e, h2), j = 32 * jt + r32;
+                    const bool ok = j <= i && i < SS;
+                    const float mul = drop ? drop_mul(a.seed, ib + (uint64_t)(i * SS + j), a.thresh, a.scale) : 1.f;
+                    const float pr = ok ? pv[jt][e] : 0.f;
+                    const float da = ok ? ds[jt][e] * mul : 0.f;          // d loss / d P (through the dropout)
+                    PS[i * AT_LP + j] = pr * mul;
+                    pv[jt][e] = pr;
+                    ds[jt][e] = da;
+                    rs[e] = fmaf(da, pr, rs[e]);
                 }
-                PS[i * AT_LP + j] = pd;
             }
-            ds[jt][e] = da;
-            rs = fmaf(da, pv[jt], rs);
-        }
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+        for (int e = 0; e < 16; ++e) rs[e] = group_sum<32>(rs[e]);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) ds[jt][e] = pv[jt] * (ds[jt][e] - rs) * a.inv_sqrt_dk;      // 0 where masked
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ds[jt][e] = pv[jt][e] * (ds[jt][e] - rs[e]) * a.inv_sqrt_dk;      // 0 where masked
     }
     __syncthreads();
+    AT_STAMP(2);
     // ---- phase 2: dV[j][d] = sum_{i >= j} Pd[i][j] dO[i][d] for key rows j = 32w + r32
     const int jk = 32 * w + r32;
     {
         at_f32x16 dv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dv[e] = 0.f;
-        for (int kq = 4 * w; kq < 16; ++kq) {
+#pragma unroll
+        for (int kq = 0; kq < 16; ++kq) {
+            if (kq < 4 * w) continue;                                  // (wave uniform)
             const int i0 = 8 * kq + 4 * h2;
             const float4 a4 = make_float4(PS[(i0 + 0) * AT_LP + jk], PS[(i0 + 1) * AT_LP + jk], PS[(i0 + 2) * AT_LP + jk], PS[(i0 + 3) * AT_LP + jk]);
             at_mfma4(dv, a4, *reinterpret_cast<const float4 *>(&OT[r32 * AT_LP + i0]));
@@ -589,6 +682,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
         }
     }
     __syncthreads();
+    AT_STAMP(3);
     // ---- phase 3: dS -> PS
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
@@ -597,12 +691,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
             for (int e = 0; e < 16; ++e) PS[(32 * w + at_row(e, h2)) * AT_LP + 32 * jt + r32] = ds[jt][e];
         }
     __syncthreads();
+    AT_STAMP(4);
     // ---- phase 4a: dK[j][d] = sum_{i >= j} dS[i][j] Q[i][d]
     {
         at_f32x16 dkk;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dkk[e] = 0.f;
-        for (int kq = 4 * w; kq < 16; ++kq) {
+#pragma unroll
+        for (int kq = 0; kq < 16; ++kq) {
+            if (kq < 4 * w) continue;                                  // (wave uniform)
             const int i0 = 8 * kq + 4 * h2;
             const float4 a4 = make_float4(PS[(i0 + 0) * AT_LP + jk], PS[(i0 + 1) * AT_LP + jk], PS[(i0 + 2) * AT_LP + jk], PS[(i0 + 3) * AT_LP + jk]);
             at_mfma4(dkk, a4, *reinterpret_cast<const float4 *>(&QT[r32 * AT_LP + i0]));
@@ -613,6 +710,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
             if (j < SS) a.dqkv[(row0 + j) * 3 * a.D + a.D + head * 32 + r32] = dkk[e];
         }
     }
+    AT_STAMP(5);
     // ---- phase 4b: dQ[i][d] = sum_{j <= i} dS[i][j] K[j][d]  (+ sum_m T[i][m] Krelpos[d][m])
     {
         at_f32x16 dq;
@@ -625,13 +723,17 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
             // T[i][m] = dS[i][m - (SS-1-i)] for 0 <= m - (SS-1-i) <= i, else 0; m ranges over [SS-1-i, SS-1]
             const int m_min = SS - 32 * w - 32 > 0 ? SS - 32 * w - 32 : 0;
             const int sh = SS - 1 - iq;                           // this lane's row shift
-            for (int kq = m_min >> 3; kq <= (SS - 1) >> 3; ++kq) {
+#pragma unroll
+            for (int kq = 0; kq < 16; ++kq) {
+                if (kq < (m_min >> 3) || kq > ((SS - 1) >> 3)) continue;      // (wave uniform)
                 const int mb = 8 * kq + 4 * h2;
                 float tv[4];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const int j = mb + x - sh;
-                    tv[x] = (j >= 0 && j <= iq && iq < SS) ? PS[iq * AT_LP + j] : 0.f;
+                    // (read at a clamped position, selected afterwards: no branch per element.  j <= iq is m < SS)
+                    const int m = mb + x, j = m - sh;
+                    const float v = PS[iq * AT_LP + max(j, 0)];
+                    tv[x] = (m >= sh && m < SS && iq < SS) ? v : 0.f;
                 }
                 at_mfma4(dq, make_float4(tv[0], tv[1], tv[2], tv[3]), *reinterpret_cast<const float4 *>(&Rk[r32 * AT_LP + mb]));
             }
@@ -642,19 +744,22 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
             if (i < SS) a.dqkv[(row0 + i) * 3 * a.D + head * 32 + r32] = dq[e];
         }
     }
+    AT_STAMP(6);
     // ---- phase 4c: dKrelpos^T[m][d] = sum_i T[i][m] Q[i][d] for m = 32w + r32
     if (rel) {
         at_f32x16 dr;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dr[e] = 0.f;
         const int mk = 32 * w + r32;
+#pragma unroll
         for (int kq = 0; kq < 16; ++kq) {
             const int i0 = 8 * kq + 4 * h2;
             float tv[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const int i = i0 + x, j = mk - (SS - 1 - i);
-                tv[x] = (i < SS && mk < SS && j >= 0 && j <= i) ? PS[i * AT_LP + j] : 0.f;
+                const int i = i0 + x, j = mk - (SS - 1 - i);            // (j <= i is mk < SS)
+                const float v = PS[i * AT_LP + max(j, 0)];
+                tv[x] = (j >= 0 && i < SS && mk < SS) ? v : 0.f;
             }
             at_mfma4(dr, make_float4(tv[0], tv[1], tv[2], tv[3]), *reinterpret_cast<const float4 *>(&QT[r32 * AT_LP + i0]));
         }
@@ -664,6 +769,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a)
             if (m < SS) a.dkrel_part[((long)cid * 32 + r32) * SS + m] = dr[e];
         }
     }
+    AT_STAMP(7);
 }
 
 // one workgroup per sequence chunk of one head; loops over its query tiles.  dK, dV and dKrelpos accumulate
@@ -860,6 +966,7 @@ static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int lay
     L.cs = sc.take<float>(colsum_rows_scratch_bytes(std::max(TR_DFF, nc * D)) / sizeof(float));
     L.tn_bytes = std::max(gemm_tn_scratch_bytes(TR_DFF, dmax, L.rows), gemm_tn_scratch_bytes(dmax * nc, TR_DFF, L.rows));
     L.tn_bytes = std::max(L.tn_bytes, gemm_tn_scratch_bytes(dmax, dmax, L.rows * nc));
+    L.tn_bytes = std::max(L.tn_bytes, gemm_tn_scratch_bytes(3 * D, D, L.rows));                // (Q | K | V weight gradients as one product)
     // the same room serves an ordered K split of the layer's products when they have few tiles
     L.tn_bytes = std::max(L.tn_bytes, std::max(gemm_nt_scratch_bytes(L.rows * nc, dmax, TR_DFF), gemm_nt_scratch_bytes(L.rows, dmax, 3 * dmax)));
     L.tn = sc.take<float>(L.tn_bytes / sizeof(float));
@@ -921,8 +1028,13 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
         const float *const *p = prm + (size_t)l * P_COUNT;
         const uint64_t lseed = seed + 0x1000ull * (uint64_t)l;
         // Q | K | V = x [Wq; Wk; Wv]^T                                     (transformers.py:99-102)
-        for (int i = 0; i < 3; ++i)
-            CPC_TRY(gemm_nt(xin, D, p[P_WQ + i], D, L.qkv[l] + (size_t)i * D, 3L * D, nullptr, R, D, D, none, st));
+        // (one product when the three weights sit back to back -- FlatAdam's buffer keeps them in registration order)
+        if (p[P_WK] == p[P_WQ] + (size_t)D * D && p[P_WV] == p[P_WK] + (size_t)D * D) {
+            CPC_TRY(gemm_nt(xin, D, p[P_WQ], D, L.qkv[l], 3L * D, nullptr, R, 3 * D, D, none, st));
+        } else {
+            for (int i = 0; i < 3; ++i)
+                CPC_TRY(gemm_nt(xin, D, p[P_WQ + i], D, L.qkv[l] + (size_t)i * D, 3L * D, nullptr, R, D, D, none, st));
+        }
         AttnArgs aa{};
         aa.qkv = L.qkv[l]; aa.krel = p[P_KREL]; aa.probs = L.probs[l]; aa.ctx = L.ctx[l];
         aa.N = N; aa.S = S; aa.D = D; aa.dk = L.dk; aa.SS = SS; aa.chunks = L.chunks;
@@ -930,8 +1042,34 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
         static const bool attn_valu = getenv("CPC_ATTN_VALU") != nullptr;       // the VALU kernels, for A/B tests
         if (L.dk == 32 && !attn_valu) {
             CPC_TRY(allow_lds_tr(attn_fwd_mfma_kernel, AT_FWD_LDS));
+#ifdef AT_STAMPS
+            static unsigned long long *stamps = nullptr;
+            const int nwg = N * TR_HEADS * L.chunks;
+            if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 65536 * 32 * sizeof(unsigned long long)));
+            aa.stamps = stamps;
+#endif
             hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(N * TR_HEADS * L.chunks)), dim3(256), AT_FWD_LDS, st, aa);
             CPC_CHECK_LAUNCH("attn_fwd_mfma_kernel");
+#ifdef AT_STAMPS
+            {
+                static std::vector<unsigned long long> host(65536 * 32);
+                CPC_CHECK_HIP(hipStreamSynchronize(st));
+                const int nb = std::min(nwg, 65536);
+                CPC_CHECK_HIP(hipMemcpy(host.data(), stamps, (size_t)nb * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                for (int w = 0; w < 4; ++w) {
+                    double ph[6] = {0, 0, 0, 0, 0, 0};
+                    for (int b = 0; b < nb; ++b)
+                        for (int i = 0; i < 6; ++i) ph[i] += (double)(host[((size_t)b * 4 + w) * 8 + i + 1] - host[((size_t)b * 4 + w) * 8 + i]);
+                    double sw = 0;
+                    for (int b = 0; b < nb; ++b) sw += (double)(host[((size_t)b * 4 + w) * 8 + 7] - host[((size_t)b * 4 + w) * 8 + 3]);
+                    fprintf(stderr, "attn fwd stamps wave %d (us): load %.2f | q+S %.2f | R+skew %.2f | softmax %.2f (max, exp, sum sweeps %.2f) | PV + ctx %.2f | drain %.2f\n", w,
+                            ph[0] / nb * 0.01, ph[1] / nb * 0.01, ph[2] / nb * 0.01, ph[3] / nb * 0.01, sw / nb * 0.01, ph[4] / nb * 0.01, ph[5] / nb * 0.01);
+                }
+                unsigned long long first = ~0ull, last = 0;
+                for (int b = 0; b < nb; ++b) { first = std::min(first, host[(size_t)b * 32]); for (int w = 0; w < 4; ++w) last = std::max(last, host[((size_t)b * 4 + w) * 8 + 6]); }
+                fprintf(stderr, "attn fwd: %d workgroups, span %.1f us\n", nb, (double)(last - first) * 0.01);
+            }
+#endif
         } else {
             CPC_TRY(allow_lds_tr(attn_fwd_kernel, L.lds_fwd));
             const int tiles = (SS + TR_QT - 1) / TR_QT;
@@ -940,9 +1078,12 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
         }
         CPC_TRY(gemm_nt(L.ctx[l], D, p[P_WO], D, L.o, D, nullptr, R, D, D, none, st));                       // Wo (:104)
         CPC_TRY(launch_ln_fwd(xin, L.o, p[P_LN1W], p[P_LN1B], L.y[l], L.xh1[l], L.rstd1[l], R, D, 1e-5f, st));  // :133
-        CPC_TRY(gemm_nt(L.y[l], D, p[P_W1], D, L.hdrop[l], TR_DFF, p[P_B1], R, TR_DFF, D, none, st));           // lin1 (:116)
-        hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(4096), dim3(256), 0, st, L.hdrop[l], R * TR_DFF, lseed ^ 0xFFull, thresh, scale);
-        CPC_CHECK_LAUNCH("relu_dropout_fwd_kernel");
+        {   // lin1 (:116) with ReLU + dropout (:112-116) in the product's epilogue (the separate pass read and wrote 134 MB at C4's shape)
+            RowMap act = none;
+            act.epi = EPI_RELU_DROPOUT; act.epi_seed = lseed ^ 0xFFull; act.epi_thresh = thresh; act.epi_scale = scale;
+            act.splitk_scratch = nullptr; act.splitk_bytes = 0;
+            CPC_TRY(gemm_nt(L.y[l], D, p[P_W1], D, L.hdrop[l], TR_DFF, p[P_B1], R, TR_DFF, D, act, st));
+        }
         const int k = (l + 1 == layers) ? nc : 1;          // classifiers of this layer's head: lin2 is [k*D][dff]
         CPC_TRY(gemm_nt(L.hdrop[l], TR_DFF, p[P_W2], TR_DFF, L.u, (long)k * D, p[P_B2], R, k * D, TR_DFF, none, st));   // lin2
         if (k == 1) {
@@ -988,9 +1129,12 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         CPC_TRY(gemm_tn(L.db, (long)k * D, L.hdrop[l], TR_DFF, g[P_W2], TR_DFF, k * D, TR_DFF, R, L.tn, L.tn_bytes, 0, 0, st));
         CPC_TRY(colsum_rows(L.db, (long)k * D, R, k * D, g[P_B2], L.cs, st));
         CPC_TRY(transpose2d(p[P_W2], L.wt, k * D, TR_DFF, st));                                      // [dff][k*D]
-        CPC_TRY(gemm_nt(L.db, (long)k * D, L.wt, (long)k * D, L.dh, TR_DFF, nullptr, R, TR_DFF, k * D, none, st));
-        hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(4096), dim3(256), 0, st, L.dh, L.hdrop[l], R * TR_DFF, scale);
-        CPC_CHECK_LAUNCH("relu_dropout_bwd_kernel");
+        {   // (the adjoint of ReLU + dropout in the epilogue: h holds relu(.) * mask * scale, an element carries gradient iff it is > 0)
+            RowMap gate = none;
+            gate.epi = EPI_GATE; gate.epi_gate = L.hdrop[l]; gate.epi_scale = scale;
+            gate.splitk_scratch = nullptr; gate.splitk_bytes = 0;
+            CPC_TRY(gemm_nt(L.db, (long)k * D, L.wt, (long)k * D, L.dh, TR_DFF, nullptr, R, TR_DFF, k * D, gate, st));
+        }
         // lin1: h = y W1^T + b1
         CPC_TRY(gemm_tn(L.dh, TR_DFF, L.y[l], D, g[P_W1], D, TR_DFF, D, R, L.tn, L.tn_bytes, 0, 0, st));
         CPC_TRY(colsum_rows(L.dh, TR_DFF, R, TR_DFF, g[P_B1], L.cs, st));
@@ -1020,7 +1164,30 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         static const bool attn_valu = getenv("CPC_ATTN_VALU") != nullptr;
         if (L.dk == 32 && !attn_valu) {
             status = allow_lds_tr(attn_bwd_mfma_kernel, AT_BWD_LDS);
+#ifdef AT_STAMPS
+            static unsigned long long *bstamps = nullptr;
+            if (bstamps == nullptr) CPC_CHECK_HIP(hipMalloc(&bstamps, 65536 * 32 * sizeof(unsigned long long)));
+            aa.stamps = bstamps;
+#endif
             if (status == CPC_OK) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)nchunk), dim3(256), AT_BWD_LDS, st, aa);
+#ifdef AT_STAMPS
+            {
+                static std::vector<unsigned long long> host(65536 * 32);
+                CPC_CHECK_HIP(hipStreamSynchronize(st));
+                const int nb = std::min(nchunk, 65536);
+                CPC_CHECK_HIP(hipMemcpy(host.data(), bstamps, (size_t)nb * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                for (int w = 0; w < 4; ++w) {
+                    double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+                    for (int b = 0; b < nb; ++b)
+                        for (int i = 0; i < 7; ++i) ph[i] += (double)(host[((size_t)b * 4 + w) * 8 + i + 1] - host[((size_t)b * 4 + w) * 8 + i]);
+                    fprintf(stderr, "attn bwd stamps wave %d (us): load %.2f | dPd + dS %.2f | dV %.2f | dS -> LDS %.2f | dK %.2f | dQ %.2f | dKrel %.2f\n", w,
+                            ph[0] / nb * 0.01, ph[1] / nb * 0.01, ph[2] / nb * 0.01, ph[3] / nb * 0.01, ph[4] / nb * 0.01, ph[5] / nb * 0.01, ph[6] / nb * 0.01);
+                }
+                unsigned long long first = ~0ull, last = 0;
+                for (int b = 0; b < nb; ++b) { first = std::min(first, host[(size_t)b * 32]); for (int w = 0; w < 4; ++w) last = std::max(last, host[((size_t)b * 4 + w) * 8 + 7]); }
+                fprintf(stderr, "attn bwd: %d workgroups, span %.1f us\n", nb, (double)(last - first) * 0.01);
+            }
+#endif
         } else
         switch (L.dk / 2) {
 #define TR_CASE(X) case X: status = allow_lds_tr(attn_bwd_kernel<X>, L.lds_bwd); \
@@ -1033,13 +1200,21 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         CPC_CHECK_LAUNCH("attn_bwd_kernel");
         if (p[P_KREL] != nullptr) CPC_TRY(colsum(L.krel_part, nchunk, (long)L.dk * SS, L.dk * SS, g[P_KREL], st));
         // Q/K/V projections
-        for (int i = 0; i < 3; ++i)
-            CPC_TRY(gemm_tn(L.dqkv + (size_t)i * D, 3L * D, xin, D, g[P_WQ + i], D, D, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        if (g[P_WK] == g[P_WQ] + (size_t)D * D && g[P_WV] == g[P_WK] + (size_t)D * D) {            // (back to back: one product)
+            CPC_TRY(gemm_tn(L.dqkv, 3L * D, xin, D, g[P_WQ], D, 3 * D, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        } else {
+            for (int i = 0; i < 3; ++i)
+                CPC_TRY(gemm_tn(L.dqkv + (size_t)i * D, 3L * D, xin, D, g[P_WQ + i], D, D, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        }
         float *dxl = (l == 0) ? dx : L.dc;
         if (dxl != nullptr) {
-            for (int i = 0; i < 3; ++i) CPC_CHECK_HIP(hipMemcpyAsync(L.wqkv + (size_t)i * D * D, p[P_WQ + i], sizeof(float) * D * D,
-                                                                     hipMemcpyDeviceToDevice, st));
-            CPC_TRY(transpose2d(L.wqkv, L.wt, 3 * D, D, st));                                         // [D][3D]
+            const float *wqkv = p[P_WQ];
+            if (!(p[P_WK] == p[P_WQ] + (size_t)D * D && p[P_WV] == p[P_WK] + (size_t)D * D)) {
+                for (int i = 0; i < 3; ++i) CPC_CHECK_HIP(hipMemcpyAsync(L.wqkv + (size_t)i * D * D, p[P_WQ + i], sizeof(float) * D * D,
+                                                                         hipMemcpyDeviceToDevice, st));
+                wqkv = L.wqkv;
+            }
+            CPC_TRY(transpose2d(wqkv, L.wt, 3 * D, D, st));                                           // [D][3D]
             CPC_TRY(gemm_nt(L.dqkv, 3L * D, L.wt, 3L * D, L.u, D, nullptr, R, D, 3 * D, none, st));
             CPC_TRY(launch_add2(dxl, L.u, L.da, R * D, st));                                           // + residual path
         }
