@@ -27,6 +27,12 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
     dist = _bench({"CPC_BENCH_FORCE_DIST": "1"})
     assert dist["comm"]["process_group"] == "nccl" and plain["comm"]["process_group"] is None
     ratio = dist["ms_per_step"] / plain["ms_per_step"]
+    if ratio >= 1.2:
+        # one 16-step run on a box that has just come up can be off by itself (seen once: 6.31 against 5.23 ms, then 5.17 against
+        # 5.09 on the next box); the defect this test exists for does not go away on a second measurement
+        plain = _bench({})
+        dist = _bench({"CPC_BENCH_FORCE_DIST": "1"})
+        ratio = dist["ms_per_step"] / plain["ms_per_step"]
     # measured 1.02-1.03 (hooks + two collectives of one rank); the defect this guards against measured 1.45
     assert ratio < 1.2, f"process-group mode {dist['ms_per_step']} ms per step against {plain['ms_per_step']} plain"
     # the fields an 8-GPU run will be read by (there is no multi-GPU node to measure a scaling curve on): what the exchange holds
