@@ -244,7 +244,7 @@ def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_se
 
 def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, warmup, cpu_seconds):
     from cpc2_amd import _lib
-    from cpc2_amd.train import DataParallelContext, cpcStep
+    from cpc2_amd.train import DataParallelContext, backward, cpcStep
     model, crit, opt = build(cfg, device)
     dedup = bool(args.dedup or cfg.get("dedup"))
     # N > 1: the criterion / context-network gradient slices are all-reduced under the encoder's backward (train.py)
@@ -258,7 +258,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
 
     def step():
         tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup, dp=dp)
-        tot.backward()
+        backward(tot)                                       # (train.py:109; cpc2_amd.train.backward seeds it with a cached 1.0)
         dp.reduce_and_step()
         opt.zero_grad()
         return losses

@@ -515,8 +515,19 @@ __global__ void infonce_reduce_kernel(const float *lossp, const float *hit, long
     const int k = blockIdx.x;
     const float *src = k < K ? lossp : hit;
     const int kk = k < K ? k : k - K;
+    // eight loads requested before the first is used (a plain `for (r = tid; r < rows; r += 256) s += ...` waits for every load
+    // before it requests the next: 29 round trips in a row at the headline shape, 12-33 us for 360 KB); fixed order per thread
     float s = 0.f;
-    for (long r = threadIdx.x; r < rows; r += blockDim.x) s += src[r * K + kk];
+    for (long r0 = threadIdx.x; r0 < rows; r0 += 8L * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long r = r0 + (long)u * blockDim.x;
+            v[u] = src[(r < rows ? r : rows - 1) * K + kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (r0 + (long)u * blockDim.x < rows) ? v[u] : 0.f;
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {

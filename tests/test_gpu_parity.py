@@ -1829,6 +1829,45 @@ def test_criterion_backward_is_deferred_only_inside_the_callers_scope(monkeypatc
     assert torch.equal(g_deferred, g_hooked)
 
 
+def test_seeded_backward_of_the_summed_losses_is_the_plain_one():
+    """cpc2_amd.train.backward(totLoss) (train.py:106,109 without the one-element kernels autograd puts between the criterion's
+    forward and backward: a cached 1.0 as the root gradient, a cached vector of ones out of the sum's backward) gives every
+    gradient of `allLosses.sum().backward()` bit for bit -- and a caller who scales the loss still gets the scaled gradient."""
+    from cpc2_amd.train import backward as seeded_backward, sum_losses
+    hidden, b = 256, 2
+    mp = synth.encoder_params(hidden, 31)
+    mp.update(synth.gru_params(hidden, hidden, 1, 32))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
+    model.load_state_dict(mp)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 33))
+    model, crit = model.to(DEV), crit.to(DEV)
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    x = synth.audio_windows(b, 20480, 34).to(DEV)
+    label = torch.zeros(b, dtype=torch.long, device=DEV)
+
+    def grads(how):
+        crit.seed(5)
+        opt.zero_grad()
+        tot, losses, _a = cpcStep(x, x, label, model, crit)
+        if how == "plain":
+            losses.sum().backward()
+        elif how == "seeded":
+            assert tot.grad_fn is not None and type(tot.grad_fn).__name__.startswith("_SumLosses")
+            seeded_backward(tot)
+        else:
+            (3.0 * sum_losses(losses)).backward()
+        opt._gather_stray_grads()
+        return opt.flat_grad.detach().clone(), float(tot)
+    g_plain, t_plain = grads("plain")
+    g_seeded, t_seeded = grads("seeded")
+    g_scaled, _t = grads("scaled")
+    assert t_plain == t_seeded and torch.equal(g_plain, g_seeded)
+    assert float(g_plain.abs().max()) > 0
+    # (a factor of 3 in front of every product moves f32 roundings: 1e-5 of the largest gradient measured, the usual step-level bar)
+    assert float((g_scaled.double() - 3.0 * g_plain.double()).abs().max()) <= 5e-5 * float(g_plain.abs().max()) * 3.0
+
+
 def test_criterion_index_range_is_checked_on_the_device():
     """SURVEY section 5 (criterion.py:264-268's gather): a negative-sample index outside [0, b * t) must not become an out-of-bounds
     gather.  The forward pass replaces it by row 0 and the asynchronous error check reports it; with the same index set to 0 by
