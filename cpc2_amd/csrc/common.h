@@ -188,8 +188,10 @@ struct PlanesNormOut {
     int halo;
 };
 bool gemm_nt_planes_norm_ok(long M, int N, int K);
+// left_slabs (optional): a K split then leaves its partial products in RowMap::splitk_scratch (slab s at s * out_rows * N floats,
+// bias in slab 0) and reports their number instead of summing them into C -- for a consumer that sums as it reads; 0: C is written
 int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
-                   const RowMap &map, hipStream_t st, const PlanesNormOut *norm = nullptr);
+                   const RowMap &map, hipStream_t st, const PlanesNormOut *norm = nullptr, int *left_slabs = nullptr);
 // weight-gradient form: C[i][j] = sum_{r < R} X(r, i) * Y(r, j); column x of an operand is channel x % C of tap tap0 + x / C,
 // i.e. element x % C of signal row r * s + tap.  Rows R .. round_up(R, 32) - 1 of A must be ZERO and those of B finite.
 struct PlanesTNOperand {

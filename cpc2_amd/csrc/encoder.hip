@@ -380,7 +380,25 @@ struct NormArgs {
     const float *dy;       // [N][Lout][H]
     float *du;             // [N*Rv + 1][H], shifted by one row
     float *part;           // [slots][3][H]: dgamma, dbeta, dbias
+    // fwd: the conv output as the partial products of a K split (nslabs > 0): row m is the sum, in slab order, of
+    // slabs[s * slab_stride + m * H ..] -- the sum the split's own reduction pass would have written to u
+    const float *slabs;
+    int nslabs;
+    long slab_stride;
 };
+
+// 16 bytes of row m of the conv output: from u, or summed over the K split's slabs in their order (bit-identical to the
+// reduction pass: 0 + s0 + s1 + ...)
+__device__ __forceinline__ float4 norm_in4(const NormArgs &a, long m, int H, int c4)
+{
+    if (a.nslabs == 0) return reinterpret_cast<const float4 *>(a.u + m * H)[c4];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sl = 0; sl < a.nslabs; ++sl) {
+        const float4 v = reinterpret_cast<const float4 *>(a.slabs + sl * a.slab_stride + m * H)[c4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    return acc;
+}
 
 template <int H> __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs a)
 {
@@ -410,7 +428,7 @@ template <int H> __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             x4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) x4[v] = reinterpret_cast<const float4 *>(a.u + m * H)[v * G + gl];
+            if (valid) x4[v] = norm_in4(a, m, H, v * G + gl);
             s += (x4[v].x + x4[v].y) + (x4[v].z + x4[v].w);
         }
         const float mean = group_sum<G>(s) * (1.f / H);
@@ -728,7 +746,7 @@ template <int H> __global__ __launch_bounds__(256) void norm_fwd_pl_kernel(NormA
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 x4[pass][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[pass]) x4[pass][v] = reinterpret_cast<const float4 *>(a.u + mrow[pass] * H)[v * G + gl];
+                if (ok[pass]) x4[pass][v] = norm_in4(a, mrow[pass], H, v * G + gl);
             }
         }
 #pragma unroll
@@ -1150,6 +1168,7 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
     }
     for (int i = 1; i < 5; ++i) {
         const int k = kConv[i].k, s = kConv[i].s;
+        int left_slabs = 0;
         if (e.planes) {
             // GEMM row m = (sample, frame) over the valid frames only; output row = virtual row of Xh
             const PlanesOperand A{e.Yp[i - 1], e.Yplane[i - 1], log2i(k), log2i(s), e.Yrts[i - 1], e.L[i + 1], (long)e.Rv[i]};
@@ -1170,7 +1189,8 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
                 CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st, &nf));
                 continue;
             }
-            CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st));
+            // (a K split leaves its partial products where they are: the norm kernel below sums them as it reads its rows)
+            CPC_TRY(gemm_nt_planes(A, B, e.Xh[i], H, prm[4 * i + 1], (long)N * e.L[i + 1], H, k * H, out, st, nullptr, &left_slabs));
         } else {
             RowMap vrows{};                                  // output rows = virtual rows; rows t >= L of a sample are junk
             vrows.seg_rows = e.Rv[i]; vrows.seg_valid = e.L[i + 1];
@@ -1181,6 +1201,7 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
         NormArgs na{};
         na.u = e.Xh[i]; na.gamma = prm[4 * i + 2]; na.beta = prm[4 * i + 3]; na.rstd = e.rstd[i];
         na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;
+        if (left_slabs > 0) { na.slabs = e.tn; na.nslabs = left_slabs; na.slab_stride = (long)N * e.Rv[i] * H; }
         if (i < 4) { na.y = e.Y[i]; na.Rnext = e.R[i]; na.halo = kConv[i + 1].p; }
         else { na.y = z; na.Rnext = e.L[5]; na.halo = 0; }
         if (e.planes && i < 4) {

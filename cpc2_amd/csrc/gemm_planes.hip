@@ -741,8 +741,9 @@ template <int DBG, bool TN, int TERMS, bool NORM, bool PAIR> static int launch_p
 }
 
 int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, long ldc, const float *bias, long M, int N, int K,
-                   const RowMap &map, hipStream_t st, const PlanesNormOut *norm)
+                   const RowMap &map, hipStream_t st, const PlanesNormOut *norm, int *left_slabs)
 {
+    if (left_slabs != nullptr) *left_slabs = 0;
     CPC_REQUIRE(gemm_nt_planes_ok(M, N, K), "gemm_nt_planes: shape M=%ld N=%d K=%d not supported", M, N, K);
     CPC_REQUIRE(map.epi == EPI_NONE, "gemm_nt_planes: no fused elementwise epilogue in this kernel");
     CPC_REQUIRE(norm == nullptr || (gemm_nt_planes_norm_ok(M, N, K) && map.enabled && map.out_stride == 1 && map.out_off == 0 &&
@@ -806,7 +807,9 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     }
     if (rc != CPC_OK) return rc;
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");
-    if (splits > 1) {
+    if (splits > 1 && left_slabs != nullptr && ldc == N) {
+        *left_slabs = splits;
+    } else if (splits > 1) {
         const long total = a.slab_rows * N;
         hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total / 4, 256), 4096)), dim3(256), 0, st, a.slabs, splits,
                            (int)a.slab_rows, N, C, ldc, 0, 0);
