@@ -215,5 +215,9 @@ int gemm_mode();        // gemm_f32.hip: 0 exact bf16 split (six products), 1 f3
 // points right behind their first kernel.
 int infonce_deferred_mark(hipStream_t st);      // the point of `st` the side stream waits for (first call after the backward wins)
 int infonce_deferred_start(hipStream_t st);
+// work of a backward entry point that nothing on its stream needs (weight gradients): on the library's side stream, joined later
+int side_tail_begin(hipStream_t st, hipStream_t *side_stream);
+int side_tail_end();
+int side_tail_join(hipStream_t st);
 
 }  // namespace cpc

@@ -1026,7 +1026,8 @@ struct GruLayout {
     float *gates[8], *hn[8], *hall[8], *outl[8];
     size_t saved_bytes;
     // scratch
-    float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn;
+    float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn, *tn2;
+    size_t tn2_bytes;
     float4 *wpack;
     unsigned long long *comm;
     size_t comm_bytes;
@@ -1065,6 +1066,9 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     // the same room serves an ordered K split of the projections (GI = X W_ih^T, dX = dGI W_ih) when they have few tiles
     g.tn_bytes = std::max(g.tn_bytes, std::max(gemm_nt_scratch_bytes((long)N * T, 3 * H, dmax), gemm_nt_scratch_bytes((long)N * T, dmax, 3 * H)));
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
+    // (the input-gradient product's K split when the weight-gradient products run beside it on the side stream: gru_backward, defer_tail)
+    g.tn2_bytes = gemm_nt_scratch_bytes((long)N * T, dmax, 3 * H);
+    g.tn2 = sc.take<float>(g.tn2_bytes / sizeof(float));
     g.scratch_bytes = sc.used();
     return CPC_OK;
 }
@@ -1083,8 +1087,6 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         RowMap none{};
         none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
         CPC_TRY(gemm_nt(xin, din, w_ih, din, g.gi, 3L * H, b_ih, (long)N * T, 3 * H, din, none, st));
-        hipLaunchKernelGGL(gru_pack_fwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);
-        CPC_CHECK_LAUNCH("gru_pack_fwd_kernel");
         GruArgs a{};
         a.gi = g.gi; a.wpack = g.wpack; a.bhh = b_hh;
         a.h0 = h0 ? h0 + (size_t)l * N * H : nullptr;
@@ -1120,6 +1122,8 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
             CPC_TRY(gru_print_stamps("fwd: math | (barrier+) gates+publish | wait | lds+barrier", stamps, ca.groups * G, H, nb, T, st));
 #endif
         } else {
+            hipLaunchKernelGGL(gru_pack_fwd_kernel, dim3(256), dim3(256), 0, st, w_hh, g.wpack, H);      // (the streaming kernel's weight layout only)
+            CPC_CHECK_LAUNCH("gru_pack_fwd_kernel");
             ProfScope prof(PROF_GRU_FWD, st);
             const size_t lds = sizeof(float) * (cdiv(H, 4) * 4 + (size_t)kq * 3 * hp);
             hipLaunchKernelGGL(gru_fwd_kernel, dim3((unsigned)N), dim3(kq * hp), lds, st, a);
@@ -1131,8 +1135,11 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
     return CPC_OK;
 }
 
+// defer_tail: the weight gradients of the last layer handled (layer 0: nothing on `st` needs them before the optimiser) are produced
+// on the library's side stream, beside what the caller enqueues next (the encoder's backward: its normalisation / reduction kernels
+// leave the matrix pipe idle for ~0.3 ms per step); cpc_side_tail_join makes a stream wait for them
 static int gru_backward(const float *x, const float *const *prm, const float *dout, void *saved, void *scratch, float *dx,
-                        float *const *grads, int N, int T, int Din, int H, int layers, hipStream_t st)
+                        float *const *grads, int N, int T, int Din, int H, int layers, hipStream_t st, bool defer_tail = false)
 {
     GruLayout g;
     CPC_TRY(gru_layout(g, N, T, Din, H, layers, saved, scratch));
@@ -1184,18 +1191,23 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         CPC_CHECK_LAUNCH("gru_bwd_kernel");
         CPC_TRY(infonce_deferred_start(st));      // (no-op unless a deferred criterion backward is waiting to run beside this)
 
+        hipStream_t wst = st;
+        const bool tail = defer_tail && l == 0;
+        if (tail) CPC_TRY(side_tail_begin(st, &wst));
         // dW_hh[g][k] = sum_{n,t} dGH[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)
-        CPC_TRY(gemm_tn(g.dgh, 3L * H, g.hall[l], H, grads[4 * l + 1], H, 3 * H, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(g.dgh, 3L * H, (long)N * (T + 1), 3 * H, grads[4 * l + 3], g.cs, st));
+        CPC_TRY(gemm_tn(g.dgh, 3L * H, g.hall[l], H, grads[4 * l + 1], H, 3 * H, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(g.dgh, 3L * H, (long)N * (T + 1), 3 * H, grads[4 * l + 3], g.cs, wst));
         // dW_ih[g][k] = sum dGI[n,t][g] * x[n,t][k]
-        CPC_TRY(gemm_tn(g.dgi, 3L * H, xin, din, grads[4 * l], din, 3 * H, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(g.dgi, 3L * H, (long)N * T, 3 * H, grads[4 * l + 2], g.cs, st));
+        CPC_TRY(gemm_tn(g.dgi, 3L * H, xin, din, grads[4 * l], din, 3 * H, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(g.dgi, 3L * H, (long)N * T, 3 * H, grads[4 * l + 2], g.cs, wst));
+        if (tail) CPC_TRY(side_tail_end());
         // dX = dGI . W_ih
         float *dxl = (l == 0) ? dx : ((l % 2) ? g.dxa : g.dxb);
         if (dxl != nullptr) {
             CPC_TRY(transpose2d(w_ih, g.wt, 3 * H, din, st));                      // [din][3H]
             RowMap none{};
-        none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
+            if (tail) { none.splitk_scratch = g.tn2; none.splitk_bytes = g.tn2_bytes; }        // (g.tn is the side stream's now)
+            else { none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes; }
             CPC_TRY(gemm_nt(g.dgi, 3L * H, g.wt, 3L * H, dxl, din, nullptr, (long)N * T, din, 3 * H, none, st));
         }
         dcur = dxl;
@@ -1234,3 +1246,14 @@ extern "C" int cpc_gru_backward(const float *x, const float *const *params, cons
     return cpc::gru_backward(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                              static_cast<hipStream_t>(stream));
 }
+
+extern "C" int cpc_gru_backward_deferred(const float *x, const float *const *params, const float *dout, void *saved, void *scratch,
+                                         float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
+                                         cpc_stream_t stream)
+{
+    CPC_TRY(cpc::coop_error_take("cpc_gru_backward_deferred"));
+    return cpc::gru_backward(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
+                             static_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int cpc_side_tail_join(cpc_stream_t stream) { return cpc::side_tail_join(static_cast<hipStream_t>(stream)); }

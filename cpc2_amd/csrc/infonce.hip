@@ -1235,6 +1235,8 @@ struct NceSide {
     // deferred form of the backward (cpc_infonce_backward_deferred): `mid` = the fused backward kernel has run on the caller's
     // stream, `late` = dz and the predictor weight gradients are complete on the side stream; `pending` until cpc_infonce_join
     hipEvent_t mid = nullptr, late = nullptr;
+    hipEvent_t tail_fork = nullptr, tail = nullptr;     // side_tail_*: work of another backward entry point finishing on this stream
+    bool tail_pending = false;
     std::atomic<bool> pending{false};
     // what is left to launch of the pending backward (infonce_deferred_start): it is started by the NEXT backward entry point
     // called on the caller's stream (the context network's, right behind its first kernel) or, failing that, by the join
@@ -1261,6 +1263,8 @@ static int nce_side(NceSide **out)
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.mid, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.late, hipEventDisableTiming));
+        CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.tail_fork, hipEventDisableTiming));
+        CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.tail, hipEventDisableTiming));
     }
     *out = &sd;
     return CPC_OK;
@@ -1450,6 +1454,36 @@ int infonce_deferred_start(hipStream_t st)
                     0, side->stream));
     CPC_CHECK_HIP(hipEventRecord(side->late, side->stream));
     side->started = true;
+    return CPC_OK;
+}
+
+// ---- "tail" work of a backward entry point on the library's side stream: ordered behind what `st` holds now (and behind whatever
+// the side stream already has queued); whoever reads its results waits at side_tail_join
+int side_tail_begin(hipStream_t st, hipStream_t *side_stream)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    CPC_CHECK_HIP(hipEventRecord(side->tail_fork, st));
+    CPC_CHECK_HIP(hipStreamWaitEvent(side->stream, side->tail_fork, 0));
+    *side_stream = side->stream;
+    return CPC_OK;
+}
+int side_tail_end()
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    CPC_CHECK_HIP(hipEventRecord(side->tail, side->stream));
+    side->tail_pending = true;
+    return CPC_OK;
+}
+int side_tail_join(hipStream_t st)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    if (side->tail_pending) {
+        CPC_CHECK_HIP(hipStreamWaitEvent(st, side->tail, 0));
+        side->tail_pending = false;
+    }
     return CPC_OK;
 }
 

@@ -9,6 +9,8 @@ Parameter containers are the same torch modules the reference instantiates (nn.C
 nn.GRU) so that default initialisation under a given torch seed is identical; their own
 forward() is never called.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -160,16 +162,32 @@ class CPCEncoder(nn.Module):
 
 
 # --------------------------------------------------------------------------- CPCAR (GRU / LSTM)
+_tail = {}              # device index -> tensors a deferred recurrent backward's side-stream work still uses
+
+
+def join_tail(device):
+    """Make the current stream of `device` wait for the weight gradients a deferred recurrent backward left on the library's side
+    stream (no-op when none is pending).  Called at the end of the backward pass (autograd callback) and by whoever reads those
+    gradients earlier (DataParallelContext's early all-reduce)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if _tail.pop(idx, None) is not None:
+        check(_lib.load().cpc_side_tail_join(stream_ptr(device)), "side_tail_join")
+
+
 class _GruFn(torch.autograd.Function):
     """kind = "gru" or "rnn" (tanh): the two single-state recurrences share one calling convention."""
 
     @staticmethod
-    def forward(ctx, x, h0, n_layers, want_hidden, kind, *params):
+    def forward(ctx, x, h0, n_layers, want_hidden, kind, defer_tail, *params):
         require_gpu(x, *params)
         lib = _lib.load()
         x = f32c(x)
         ctx.param_refs = params
         ctx.kind = kind
+        ctx.defer_tail = bool(defer_tail) and kind == "gru"
         params = tuple(f32c(p) for p in params)
         n, t, dim_in = x.shape
         hidden = params[1].shape[1]
@@ -202,11 +220,32 @@ class _GruFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
         kind = ctx.kind
-        sc = scratch(getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers), x.device)
-        check(getattr(lib, f"cpc_{kind}_backward")(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
-                                                   ptr_array(grads), n, t, dim_in, hidden, n_layers,
-                                                   stream_ptr(x.device)), f"{kind}_backward")
-        return (dx, None, None, None, None) + tuple(grads)
+        # The deferred form (cpc2_hip.h, cpc_gru_backward_deferred): layer 0's weight gradients finish on a stream of the library's
+        # while the encoder's backward runs.  Only inside the caller's scope (CPCAR.deferred_weight_gradients: nothing reads these
+        # gradients before the backward pass has ended) and only when every one of them is written IN PLACE into the flat gradient
+        # buffer -- a private buffer would be added to .grad by autograd the moment this function returns.
+        n_l0 = 4
+        direct = all(getattr(p, "_cpc_flat", None) is not None and g.data_ptr() == p._cpc_flat[0].data_ptr() + 4 * p._cpc_flat[1]
+                     for p, g in zip(ctx.param_refs[:n_l0], grads[:n_l0]))
+        defer = ctx.defer_tail and direct
+        nscratch = getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers)
+        if defer:
+            join_tail(x.device)                                   # (one pending tail per device)
+            sc = scratch(nscratch, x.device, tag="gru_tail")      # a buffer of its own: the side stream outlives this call
+            check(lib.cpc_gru_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
+                                                n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "gru_backward_deferred")
+            idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+            # alive until the join.  NOT `grads`: autograd adopts a returned gradient as .grad only while nobody else holds it -- with a
+            # second reference it CLONES it on the spot (the flat buffer's not yet written bytes) and the clone becomes .grad
+            _tail[idx] = (x, saved, params, dout, sc)
+            device = x.device
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: join_tail(device))
+        else:
+            sc = scratch(nscratch, x.device)
+            check(getattr(lib, f"cpc_{kind}_backward")(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
+                                                       ptr_array(grads), n, t, dim_in, hidden, n_layers,
+                                                       stream_ptr(x.device)), f"{kind}_backward")
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
 class _LstmFn(torch.autograd.Function):
@@ -267,9 +306,25 @@ class CPCAR(nn.Module):
         self.hidden = None
         self.keepHidden = keepHidden
         self.reverse = reverse
+        self._defer_tail = False       # set by deferred_weight_gradients() for the duration of the caller's scope
 
     def getDimOutput(self):
         return self.baseNet.hidden_size
+
+    def deferred_weight_gradients(self):
+        """Context manager around the FORWARD call: the backward of a forward pass made inside may leave layer 0's weight gradients
+        on the library's side stream until the end of the backward pass (cpc_gru_backward_deferred).  The caller promises that
+        nothing reads those gradients earlier -- no wrapper whose reducer copies a gradient the moment autograd has accumulated it
+        (DistributedDataParallel / DataParallel around the model), no tensor hook on them; cpcStep opens it for the bare model."""
+        return _TailScope(self)
+
+    def _may_defer(self):
+        if os.environ.get("CPC_NO_GRU_TAIL"):                     # A/B switch
+            return False
+        for p in self._param_list()[:4]:
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        return True
 
     def _param_list(self):
         out = []
@@ -288,13 +343,27 @@ class CPCAR(nn.Module):
                 self.hidden = (h.detach(), c.detach())
         else:
             kind = "rnn" if isinstance(self.baseNet, nn.RNN) else "gru"
-            x, h = _GruFn.apply(x, self.hidden, layers, keep, kind, *self._param_list())
+            x, h = _GruFn.apply(x, self.hidden, layers, keep, kind, self._defer_tail and self._may_defer(), *self._param_list())
             if self.keepHidden:
                 self.hidden = h.detach()
         # a sequence's order is preserved by each module (model.py:203-206)
         if self.reverse:
             x = torch.flip(x, [1])
         return x
+
+
+class _TailScope:
+    def __init__(self, ar):
+        self.ar = ar
+
+    def __enter__(self):
+        self.prev = self.ar._defer_tail
+        self.ar._defer_tail = True
+        return self
+
+    def __exit__(self, *exc):
+        self.ar._defer_tail = self.prev
+        return False
 
 
 class NoAr(nn.Module):
@@ -326,8 +395,8 @@ class BiDIRARTangled(nn.Module):
 
     def forward(self, x):
         for layer in range(self.ARNet.num_layers):
-            xf = _GruFn.apply(x, None, 1, False, "gru", *_gru_layer_params(self.ARNet, layer))[0]
-            xb = _GruFn.apply(torch.flip(x, [1]), None, 1, False, "gru", *_gru_layer_params(self.ARNet, layer, "_reverse"))[0]
+            xf = _GruFn.apply(x, None, 1, False, "gru", False, *_gru_layer_params(self.ARNet, layer))[0]
+            xb = _GruFn.apply(torch.flip(x, [1]), None, 1, False, "gru", False, *_gru_layer_params(self.ARNet, layer, "_reverse"))[0]
             x = torch.cat([xf, torch.flip(xb, [1])], dim=2)
         return x
 
@@ -346,7 +415,7 @@ class BiDIRAR(nn.Module):
 
     def _run(self, gru, x):
         params = [p for layer in range(gru.num_layers) for p in _gru_layer_params(gru, layer)]
-        return _GruFn.apply(x, None, gru.num_layers, False, "gru", *params)[0]
+        return _GruFn.apply(x, None, gru.num_layers, False, "gru", False, *params)[0]
 
     def forward(self, x):
         xf = self._run(self.netForward, x)
@@ -375,7 +444,7 @@ class RNNPredictor(nn.RNN):
             raise NotImplementedError("RNNPredictor: time-major, unidirectional tanh RNN with zero initial state only")
         params = [getattr(self, f"{n}_l{layer}") for layer in range(self.num_layers)
                   for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
-        out = _GruFn.apply(x.transpose(0, 1).contiguous(), None, self.num_layers, False, "rnn", *params)[0]
+        out = _GruFn.apply(x.transpose(0, 1).contiguous(), None, self.num_layers, False, "rnn", False, *params)[0]
         return out.transpose(0, 1).contiguous(), None
 
 

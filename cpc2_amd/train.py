@@ -17,7 +17,7 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join, first_windows
-from .model import CPCAR, CPCEncoder, CPCModel
+from .model import CPCAR, CPCEncoder, CPCModel, join_tail
 
 
 # --------------------------------------------------------------------------- factories
@@ -130,6 +130,8 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None, grad_scale=1.0):
         if closure is not None:
             raise NotImplementedError("FlatAdam.step does not re-evaluate a closure")
+        if self.flat.is_cuda:
+            join_tail(self.flat.device)          # (a deferred recurrent backward's weight gradients: normally joined at the end of backward)
         if self.direct_grads:
             self._gather_stray_grads()
         self.step_count += 1
@@ -335,6 +337,8 @@ class DataParallelContext:
                     raise RuntimeError("DataParallelContext: the early all-reduce would be issued BEFORE the cooperative recurrent "
                                        "backward of this step (a collective's kernels beside a kernel that needs every "
                                        "workgroup resident): attach() must be given the encoder output, upstream of the context network")
+                if on_gpu:
+                    join_tail(self.opt.flat_grad.device)         # (a context network's weight gradients still on the side stream)
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.early)     # a gradient autograd did not write in place (accumulation)
                 self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
@@ -389,7 +393,8 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     window, so one pass over b windows gives bit-identical c_feature / encoded_data at half the work."""
     b = past.size(0)
     if dedup and (future is past or (future.data_ptr() == past.data_ptr() and future.shape == past.shape)):
-        c_feature, encoded_data, label = cpcModel(past, label)
+        with _ar_scope(cpcModel):
+            c_feature, encoded_data, label = cpcModel(past, label)
         if dp is not None:
             dp.attach(encoded_data)
         with _defer_scope(cpcCriterion, encoded_data):
@@ -399,7 +404,8 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     # (train.py:100,105 concatenate the labels too and take the first half back: CPCModel hands `label` through untouched, so the
     #  round trip -- two small kernels per step -- is skipped for it; any other model gets the reference's tensors)
     passthrough = isinstance(getattr(cpcModel, "module", cpcModel), CPCModel)
-    c_feature, encoded_full, label2 = cpcModel(combined, label if passthrough else torch.cat([label, label]))
+    with _ar_scope(cpcModel):
+        c_feature, encoded_full, label2 = cpcModel(combined, label if passthrough else torch.cat([label, label]))
     label = label2 if passthrough else label2[:b]
     if dp is not None:
         dp.attach(encoded_full)             # data parallel: the criterion / context gradients are reduced under the encoder's backward
@@ -454,6 +460,17 @@ def backward(totLoss):
         totLoss.backward(gradient=_ones(totLoss.device, 1).view(()))
     else:
         totLoss.backward()
+
+
+def _ar_scope(cpcModel):
+    """The context network's deferred weight gradients (model.py, CPCAR.deferred_weight_gradients) are cpcStep's to allow for the
+    BARE model only: the gradients are read by the optimiser after the backward pass (and by DataParallelContext's early
+    all-reduce, which joins first) -- a DistributedDataParallel / DataParallel wrapper would read them as they are accumulated."""
+    import contextlib
+    ar = getattr(cpcModel, "gAR", None) if isinstance(cpcModel, CPCModel) else None
+    if isinstance(ar, CPCAR):
+        return ar.deferred_weight_gradients()
+    return contextlib.nullcontext()
 
 
 def _defer_scope(cpcCriterion, encoded_full):

@@ -1829,6 +1829,60 @@ def test_criterion_backward_is_deferred_only_inside_the_callers_scope(monkeypatc
     assert torch.equal(g_deferred, g_hooked)
 
 
+def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(monkeypatch):
+    """cpc_gru_backward_deferred (layer 0's weight gradients finish on the library's side stream under the encoder's backward):
+    (1) cpcStep on the bare model defers them, and every gradient of the step is bit-identical to the immediate form's;
+    (2) model called directly (the reference's train.py), or a tensor hook on one of those weights: not deferred;
+    (3) two GRU layers: layer 1's gradients on the caller's stream, layer 0's deferred -- same bits again."""
+    from cpc2_amd import model as model_mod
+    for layers, hidden, b in ((1, 256, 2), (2, 256, 2)):
+        mp = synth.encoder_params(hidden, 41)
+        mp.update(synth.gru_params(hidden, hidden, layers, 42))
+        model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, layers))
+        model.load_state_dict(mp)
+        crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128)
+        crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 43))
+        model, crit = model.to(DEV), crit.to(DEV)
+        opt = buildOptimizer(model, crit, lr=2e-4)
+        x = synth.audio_windows(b, 20480, 44).to(DEV)
+        label = torch.zeros(b, dtype=torch.long, device=DEV)
+        lib = _lib.load()
+        calls = []
+        real = lib.cpc_gru_backward_deferred
+
+        def spy(*a):
+            calls.append(1)
+            return real(*a)
+        monkeypatch.setattr(lib, "cpc_gru_backward_deferred", spy)
+
+        def grads(how):
+            crit.seed(5)
+            opt.zero_grad()
+            del calls[:]
+            if how == "step":
+                tot, _l, _a = cpcStep(x, x, label, model, crit)
+            elif how == "direct":                          # the reference's own sequence of calls: no scope
+                c, z, _ = model(torch.cat([x, x]), label)
+                losses, _a = crit(c[:b], z[b:], label)
+                tot = losses.sum()
+            tot.backward()
+            assert not model_mod._tail                     # joined by the end of the backward pass
+            opt._gather_stray_grads()
+            torch.cuda.synchronize()
+            return opt.flat_grad.detach().clone(), len(calls)
+        g_step, n_step = grads("step")
+        g_direct, n_direct = grads("direct")
+        assert n_step == 1 and n_direct == 0, (n_step, n_direct)
+        assert torch.equal(g_step, g_direct) and float(g_step.abs().max()) > 0
+        touched = []
+        handle = model.gAR.baseNet.weight_hh_l0.register_hook(lambda g: touched.append(float(g.abs().sum())))
+        g_hooked, n_hooked = grads("step")
+        handle.remove()
+        assert n_hooked == 0 and len(touched) == 1 and touched[0] > 0
+        assert torch.equal(g_step, g_hooked)
+        monkeypatch.setattr(lib, "cpc_gru_backward_deferred", real)
+
+
 def test_seeded_backward_of_the_summed_losses_is_the_plain_one():
     """cpc2_amd.train.backward(totLoss) (train.py:106,109 without the one-element kernels autograd puts between the criterion's
     forward and backward: a cached 1.0 as the root gradient, a cached vector of ones out of the sum's backward) gives every
