@@ -41,6 +41,7 @@ SIGNATURES = {
     "cpc_encoder_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cpc_encoder_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_encoder_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_encoder_backward_deferred": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_coop_launches": (c_long, []),
     "cpc_encoder_saved_layout": (c_int, [c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_gru_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -1025,6 +1025,8 @@ struct EncLayout {
     float *Wf[5];    // index 1..4: forward GEMM operand of layer i, [H][k*H]
     float *dYa, *dYb, *dU, *part, *sums, *cs, *tn;
     size_t tn_bytes;
+    float *part_l[5], *cs_l[5], *tn_l[5];      // per-layer copies for the deferred backward
+    size_t tn_l_bytes[5];
     size_t scratch_bytes;
     // plane-fed GEMMs (H = 256, 512): Y_i, dU and the weights live as chunked bf16 planes instead of f32
     int planes;
@@ -1115,6 +1117,17 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
                                                         gemm_nt_planes_scratch_bytes((long)N * e.L[i + 1], H, kConv[i].k * H, (long)N * e.Rv[i])));
     }
     e.tn = sc.take<float>(e.tn_bytes / sizeof(float));
+    // deferred form of the backward (encoder_backward, defer_small): each layer's partial sums and weight-gradient slabs stay
+    // where they are until the side stream has summed them, so every layer has its own
+    for (int i = 1; i < 5; ++i) {
+        e.part_l[i] = nullptr; e.cs_l[i] = nullptr; e.tn_l[i] = nullptr; e.tn_l_bytes[i] = 0;
+        if (e.planes) {
+            e.part_l[i] = sc.take<float>((size_t)NORM_BWD_BLOCKS * 3 * H);
+            e.cs_l[i] = sc.take<float>(colsum_split_scratch_bytes(3 * H) / sizeof(float));
+            e.tn_l_bytes[i] = gemm_tn_planes_scratch_bytes(H, kConv[i].k * H, (long)N * e.Rv[i]);
+            e.tn_l[i] = sc.take<float>(e.tn_l_bytes[i] / sizeof(float));
+        }
+    }
     e.scratch_bytes = sc.used();
     return CPC_OK;
 }
@@ -1219,8 +1232,11 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
     return CPC_OK;
 }
 
+// defer_small: the passes of layers 1-4 that only produce parameter gradients from what a big kernel has left behind -- the two-stage
+// column sums of dgamma / dbeta / dbias and the sum of the weight-gradient product's K-split slabs, eight to ten launches of 5-10 us
+// that nothing on `st` needs -- run on the library's side stream (side_tail_*), each layer with buffers of its own
 static int encoder_backward(const float *x, const float *const *prm, const float *dz, void *saved, void *scratch,
-                            float *const *grads, int N, int length, int H, float eps, hipStream_t st)
+                            float *const *grads, int N, int length, int H, float eps, hipStream_t st, bool defer_small = false)
 {
     EncLayout e;
     CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
@@ -1234,17 +1250,26 @@ static int encoder_backward(const float *x, const float *const *prm, const float
         na.N = N; na.Lout = e.L[i + 1]; na.Rv = e.Rv[i]; na.eps = eps;
         na.dy = dy; na.du = e.dU; na.part = e.part;
         float *dprev = (i % 2 == 0) ? e.dYb : e.dYa;         // i=4 -> dYb, 3 -> dYa, 2 -> dYb, 1 -> dYa
+        const bool side = defer_small && e.planes;
+        if (side) na.part = e.part_l[i];
         if (e.planes) {
             // dU of layer i as planes: rows of the layer, + the zero rows the weight-gradient product's last step reads
             const long durows = (cdiv((long)N * e.Rv[i], 32) * 32 + 4 + 15) / 16 * 16;
             const PlaneOut o{e.dUp, e.dUplane, 0, e.dUrows};
             CPC_DISPATCH_HP(H, hipLaunchKernelGGL(norm_bwd_pl_kernel<HH>, dim3(NORM_BWD_BLOCKS), dim3(256), 0, st, na, o, durows / 16));
             CPC_CHECK_LAUNCH("norm_bwd_pl_kernel");
-            CPC_TRY(colsum_split(e.part, NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1], H, e.cs, st));
+            {
+                hipStream_t cst = st;
+                if (side) CPC_TRY(side_tail_begin(st, &cst));
+                CPC_TRY(colsum_split(na.part, NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1], H,
+                                     side ? e.cs_l[i] : e.cs, cst));
+                if (side) CPC_TRY(side_tail_end());
+            }
             // weight gradient over the virtual rows (dU is zero on a sample's border rows): dW[co][j*H+ci] = sum_m dU(m+1)[co] Y(m s + j)[ci]
             const PlanesTNOperand TA{e.dUp, e.dUplane, 0, e.dUrows, 1, H};
             const PlanesTNOperand TB{e.Yp[i - 1], e.Yplane[i - 1], log2i(s), e.Yrts[i - 1], 0, H};
-            CPC_TRY(gemm_tn_planes(TA, TB, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], e.tn, e.tn_bytes, H, k, st));
+            CPC_TRY(gemm_tn_planes(TA, TB, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], side ? e.tn_l[i] : e.tn, side ? e.tn_l_bytes[i] : e.tn_bytes,
+                                   H, k, st, side));
             // backward data.  Lengths that divide by the stride (training windows): rows t_hi = 0 .. L_out - 1 of every sample
             // in whole tiles, and a small kernel for the boundary row t_hi = L_out; otherwise all L_out + 1 rows in the product
             // (the trailing input rows no output frame reads get a zero gradient)
@@ -1388,4 +1413,11 @@ extern "C" int cpc_encoder_backward(const float *x, const float *const *params, 
 {
     return cpc::encoder_backward(x, params, dz, saved, scratch, grads, n_windows, length, hidden, eps,
                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_encoder_backward_deferred(const float *x, const float *const *params, const float *dz, void *saved, void *scratch,
+                                             float *const *grads, int n_windows, int length, int hidden, float eps, cpc_stream_t stream)
+{
+    return cpc::encoder_backward(x, params, dz, saved, scratch, grads, n_windows, length, hidden, eps,
+                                 static_cast<hipStream_t>(stream), true);
 }

@@ -894,7 +894,7 @@ size_t gemm_tn_planes_scratch_bytes(int M, int N, long R)
 }
 
 int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
-                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st)
+                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st, bool reduce_on_side)
 {
     CPC_REQUIRE(gemm_tn_planes_ok(M, N, R), "gemm_tn_planes: shape M=%d N=%d R=%ld not supported", M, N, R);
     auto bad = [](const PlanesTNOperand &o) {
@@ -925,9 +925,12 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     }
     CPC_CHECK_LAUNCH("gemm_planes_kernel (tn)");
     const long total = (long)M * N;
-    hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total / 4, 256), 2048)), dim3(256), 0, st, a.slabs, S, M, N, C,
+    hipStream_t rst = st;
+    if (reduce_on_side) CPC_TRY(side_tail_begin(st, &rst));      // (the slabs are the caller's to keep until cpc_side_tail_join)
+    hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total / 4, 256), 2048)), dim3(256), 0, rst, a.slabs, S, M, N, C,
                        ldc, conv_cin, conv_k);
     CPC_CHECK_LAUNCH("planes_tn_reduce_kernel");
+    if (reduce_on_side) CPC_TRY(side_tail_end());
     return CPC_OK;
 }
 

@@ -76,6 +76,63 @@ class ChannelNorm(nn.Module):
         return _ChannelNormFn.apply(x, self.weight, self.bias, float(self.epsilon))
 
 
+# --------------------------------------------------------------------------- deferred parameter-gradient work
+# cpc_gru_backward_deferred / cpc_encoder_backward_deferred leave work that only finishes PARAMETER gradients on a stream of the
+# library's, under the kernels the backward pass enqueues next.  Whoever reads those gradients sits behind join_tail(): the end of
+# the backward pass (autograd callback), DataParallelContext's all-reduces, FlatAdam.step.
+_tail = {}              # device index -> [tensors the side stream still uses, one tuple per deferred backward]
+
+
+def join_tail(device):
+    """Make the current stream of `device` wait for the parameter-gradient work deferred backward calls left on the library's side
+    stream (no-op when none is pending)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if _tail.pop(idx, None) is not None:
+        check(_lib.load().cpc_side_tail_join(stream_ptr(device)), "side_tail_join")
+
+
+def _keep_for_tail(device, tensors):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    first = idx not in _tail
+    _tail.setdefault(idx, []).append(tensors)
+    if first:
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_tail(device))
+
+
+def _all_in_place(params, grads):
+    """Every gradient buffer is the parameter's own piece of FlatAdam's flat gradient buffer (grad_buffers): autograd then adopts
+    it as .grad without reading it.  A private buffer would be ADDED to .grad the moment backward() returns."""
+    return all(getattr(p, "_cpc_flat", None) is not None and g.data_ptr() == p._cpc_flat[0].data_ptr() + 4 * p._cpc_flat[1]
+               for p, g in zip(params, grads))
+
+
+def _no_hooks(params):
+    if os.environ.get("CPC_NO_GRAD_TAIL"):                        # A/B switch
+        return False
+    return not any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params)
+
+
+class _TailScope:
+    """`with module.deferred_weight_gradients():` around the FORWARD call -- the caller's promise that nothing reads the module's
+    parameter gradients before the backward pass has ended: no wrapper whose reducer copies a gradient the moment autograd has
+    accumulated it (DistributedDataParallel / DataParallel), no tensor hook on them.  cpcStep opens it for the bare model."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __enter__(self):
+        self.prev = self.module._defer_tail
+        self.module._defer_tail = True
+        return self
+
+    def __exit__(self, *exc):
+        self.module._defer_tail = self.prev
+        return False
+
+
 # --------------------------------------------------------------------------- CPCEncoder
 _ENC_GEOMETRY = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
@@ -84,11 +141,12 @@ class _EncoderFn(torch.autograd.Function):
     """relu(norm_i(conv_i(.))) x5 in one call; returns the channel-LAST output [N, T, H]."""
 
     @staticmethod
-    def forward(ctx, x, eps, *params):
+    def forward(ctx, x, eps, defer_tail, *params):
         require_gpu(x, *params)
         lib = _lib.load()
         x = f32c(x)
         ctx.param_refs = params
+        ctx.defer_tail = bool(defer_tail)
         params = tuple(f32c(p) for p in params)
         n, cin, length = x.shape
         if cin != 1:
@@ -116,10 +174,19 @@ class _EncoderFn(torch.autograd.Function):
         n, length, hidden = ctx.dims
         dz = f32c(dz)
         grads = grad_buffers(ctx.param_refs)
-        sc = scratch(lib.cpc_encoder_scratch_bytes(n, length, hidden), x.device)
-        check(lib.cpc_encoder_backward(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
-                                       n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward")
-        return (None, None) + tuple(grads)
+        nscratch = lib.cpc_encoder_scratch_bytes(n, length, hidden)
+        # the deferred form (cpc2_hip.h): inside the caller's scope (CPCEncoder.deferred_weight_gradients) and with every gradient
+        # of conv1-4 written in place into the flat gradient buffer
+        if ctx.defer_tail and _all_in_place(ctx.param_refs[4:], grads[4:]):
+            sc = scratch(nscratch, x.device, tag="enc_tail")      # a buffer of its own: the side stream outlives this call
+            check(lib.cpc_encoder_backward_deferred(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
+                                                    n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward_deferred")
+            _keep_for_tail(x.device, (x, saved, params, dz, sc))  # (not `grads`: see _GruFn.backward)
+        else:
+            sc = scratch(nscratch, x.device)
+            check(lib.cpc_encoder_backward(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
+                                           n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward")
+        return (None, None, None) + tuple(grads)
 
 
 class CPCEncoder(nn.Module):
@@ -141,9 +208,15 @@ class CPCEncoder(nn.Module):
             setattr(self, f"batchNorm{i}", ChannelNorm(sizeHidden))
             cin = sizeHidden
         self.DOWNSAMPLING = 160
+        self._defer_tail = False       # set by deferred_weight_gradients() for the duration of the caller's scope
 
     def getDimOutput(self):
         return self.conv4.out_channels
+
+    def deferred_weight_gradients(self):
+        """Context manager around the FORWARD call (see _TailScope): the backward of a forward pass made inside may leave the small
+        passes that finish conv1-4's parameter gradients on the library's side stream (cpc_encoder_backward_deferred)."""
+        return _TailScope(self)
 
     def _param_list(self):
         out = []
@@ -154,7 +227,8 @@ class CPCEncoder(nn.Module):
 
     def forward_channel_last(self, x):
         """[N, 1, L] -> [N, T, H] (what CPCModel consumes); eps taken from batchNorm0."""
-        return _EncoderFn.apply(x, float(self.batchNorm0.epsilon), *self._param_list())
+        params = self._param_list()
+        return _EncoderFn.apply(x, float(self.batchNorm0.epsilon), self._defer_tail and _no_hooks(params[4:]), *params)
 
     def forward(self, x):
         # reference layout [N, H, T]; a permuted view of the channel-last buffer
@@ -162,21 +236,6 @@ class CPCEncoder(nn.Module):
 
 
 # --------------------------------------------------------------------------- CPCAR (GRU / LSTM)
-_tail = {}              # device index -> tensors a deferred recurrent backward's side-stream work still uses
-
-
-def join_tail(device):
-    """Make the current stream of `device` wait for the weight gradients a deferred recurrent backward left on the library's side
-    stream (no-op when none is pending).  Called at the end of the backward pass (autograd callback) and by whoever reads those
-    gradients earlier (DataParallelContext's early all-reduce)."""
-    device = torch.device(device)
-    if device.type != "cuda":
-        return
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if _tail.pop(idx, None) is not None:
-        check(_lib.load().cpc_side_tail_join(stream_ptr(device)), "side_tail_join")
-
-
 class _GruFn(torch.autograd.Function):
     """kind = "gru" or "rnn" (tanh): the two single-state recurrences share one calling convention."""
 
@@ -224,22 +283,15 @@ class _GruFn(torch.autograd.Function):
         # while the encoder's backward runs.  Only inside the caller's scope (CPCAR.deferred_weight_gradients: nothing reads these
         # gradients before the backward pass has ended) and only when every one of them is written IN PLACE into the flat gradient
         # buffer -- a private buffer would be added to .grad by autograd the moment this function returns.
-        n_l0 = 4
-        direct = all(getattr(p, "_cpc_flat", None) is not None and g.data_ptr() == p._cpc_flat[0].data_ptr() + 4 * p._cpc_flat[1]
-                     for p, g in zip(ctx.param_refs[:n_l0], grads[:n_l0]))
-        defer = ctx.defer_tail and direct
+        defer = ctx.defer_tail and _all_in_place(ctx.param_refs[:4], grads[:4])
         nscratch = getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers)
         if defer:
-            join_tail(x.device)                                   # (one pending tail per device)
             sc = scratch(nscratch, x.device, tag="gru_tail")      # a buffer of its own: the side stream outlives this call
             check(lib.cpc_gru_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
                                                 n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "gru_backward_deferred")
-            idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
             # alive until the join.  NOT `grads`: autograd adopts a returned gradient as .grad only while nobody else holds it -- with a
             # second reference it CLONES it on the spot (the flat buffer's not yet written bytes) and the clone becomes .grad
-            _tail[idx] = (x, saved, params, dout, sc)
-            device = x.device
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: join_tail(device))
+            _keep_for_tail(x.device, (x, saved, params, dout, sc))
         else:
             sc = scratch(nscratch, x.device)
             check(getattr(lib, f"cpc_{kind}_backward")(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
@@ -319,12 +371,7 @@ class CPCAR(nn.Module):
         return _TailScope(self)
 
     def _may_defer(self):
-        if os.environ.get("CPC_NO_GRU_TAIL"):                     # A/B switch
-            return False
-        for p in self._param_list()[:4]:
-            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
-                return False
-        return True
+        return _no_hooks(self._param_list()[:4])
 
     def _param_list(self):
         out = []
@@ -350,20 +397,6 @@ class CPCAR(nn.Module):
         if self.reverse:
             x = torch.flip(x, [1])
         return x
-
-
-class _TailScope:
-    def __init__(self, ar):
-        self.ar = ar
-
-    def __enter__(self):
-        self.prev = self.ar._defer_tail
-        self.ar._defer_tail = True
-        return self
-
-    def __exit__(self, *exc):
-        self.ar._defer_tail = self.prev
-        return False
 
 
 class NoAr(nn.Module):

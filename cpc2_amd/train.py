@@ -345,6 +345,8 @@ class DataParallelContext:
         encoder_output.register_hook(start)
 
     def reduce_and_step(self):
+        if self.opt.flat_grad.is_cuda:
+            join_tail(self.opt.flat_grad.device)                 # (parameter gradients still on the library's side stream)
         if self.active and self.opt.flat_grad.is_cuda:
             self._coop_seen = self._coop_launches()              # (the next step's forward launches count from here)
         if self.active:
@@ -463,14 +465,17 @@ def backward(totLoss):
 
 
 def _ar_scope(cpcModel):
-    """The context network's deferred weight gradients (model.py, CPCAR.deferred_weight_gradients) are cpcStep's to allow for the
-    BARE model only: the gradients are read by the optimiser after the backward pass (and by DataParallelContext's early
+    """The context network's and the encoder's deferred parameter gradients (model.py, deferred_weight_gradients) are cpcStep's to
+    allow for the BARE model only: the gradients are read by the optimiser after the backward pass (and by DataParallelContext's early
     all-reduce, which joins first) -- a DistributedDataParallel / DataParallel wrapper would read them as they are accumulated."""
     import contextlib
-    ar = getattr(cpcModel, "gAR", None) if isinstance(cpcModel, CPCModel) else None
-    if isinstance(ar, CPCAR):
-        return ar.deferred_weight_gradients()
-    return contextlib.nullcontext()
+    stack = contextlib.ExitStack()
+    if isinstance(cpcModel, CPCModel):
+        if isinstance(cpcModel.gAR, CPCAR):
+            stack.enter_context(cpcModel.gAR.deferred_weight_gradients())
+        if isinstance(cpcModel.gEncoder, CPCEncoder):
+            stack.enter_context(cpcModel.gEncoder.deferred_weight_gradients())
+    return stack
 
 
 def _defer_scope(cpcCriterion, encoded_full):

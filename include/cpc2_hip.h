@@ -152,6 +152,13 @@ int cpc_encoder_forward(const float *x, const float *const *params, float *z, vo
 int cpc_encoder_backward(const float *x, const float *const *params, const float *dz, void *saved,
                          void *scratch, float *const *grads, int n_windows, int length, int hidden,
                          float eps, cpc_stream_t stream);
+/* Deferred form of the same backward: the small passes of conv1-4 that only finish parameter gradients (the column sums of
+ * dgamma / dbeta / dbias, the sum of each weight-gradient product's K-split slabs) run on a stream of the library's; the gradients
+ * of conv1-4 and their norms may then not be read (nor x, saved, scratch reused) until cpc_side_tail_join(stream') -- see
+ * cpc_gru_backward_deferred.  conv0's gradients are complete on `stream` as before. */
+int cpc_encoder_backward_deferred(const float *x, const float *const *params, const float *dz, void *saved,
+                         void *scratch, float *const *grads, int n_windows, int length, int hidden,
+                         float eps, cpc_stream_t stream);
 /* Inspection (tests only; the layout of `saved` is otherwise private): what the forward pass keeps of layer 0..4 --
  * the ChannelNorm of model.py:52-60 as (xhat, rstd) (layers 1..4) and, at hidden 256 / 512, the layer's ReLU'd output as the
  * next layer's input planes (layers 0..3).  out[10]:

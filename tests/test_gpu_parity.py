@@ -1830,7 +1830,7 @@ def test_criterion_backward_is_deferred_only_inside_the_callers_scope(monkeypatc
 
 
 def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(monkeypatch):
-    """cpc_gru_backward_deferred (layer 0's weight gradients finish on the library's side stream under the encoder's backward):
+    """cpc_gru_backward_deferred / cpc_encoder_backward_deferred (parameter-gradient work on the library's side stream):
     (1) cpcStep on the bare model defers them, and every gradient of the step is bit-identical to the immediate form's;
     (2) model called directly (the reference's train.py), or a tensor hook on one of those weights: not deferred;
     (3) two GRU layers: layer 1's gradients on the caller's stream, layer 0's deferred -- same bits again."""
@@ -1847,18 +1847,24 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
         x = synth.audio_windows(b, 20480, 44).to(DEV)
         label = torch.zeros(b, dtype=torch.long, device=DEV)
         lib = _lib.load()
-        calls = []
-        real = lib.cpc_gru_backward_deferred
+        calls, enc_calls = [], []
+        real, real_enc = lib.cpc_gru_backward_deferred, lib.cpc_encoder_backward_deferred
 
         def spy(*a):
             calls.append(1)
             return real(*a)
+
+        def spy_enc(*a):
+            enc_calls.append(1)
+            return real_enc(*a)
         monkeypatch.setattr(lib, "cpc_gru_backward_deferred", spy)
+        monkeypatch.setattr(lib, "cpc_encoder_backward_deferred", spy_enc)
 
         def grads(how):
             crit.seed(5)
             opt.zero_grad()
             del calls[:]
+            del enc_calls[:]
             if how == "step":
                 tot, _l, _a = cpcStep(x, x, label, model, crit)
             elif how == "direct":                          # the reference's own sequence of calls: no scope
@@ -1869,18 +1875,24 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
             assert not model_mod._tail                     # joined by the end of the backward pass
             opt._gather_stray_grads()
             torch.cuda.synchronize()
-            return opt.flat_grad.detach().clone(), len(calls)
+            return opt.flat_grad.detach().clone(), (len(calls), len(enc_calls))
         g_step, n_step = grads("step")
         g_direct, n_direct = grads("direct")
-        assert n_step == 1 and n_direct == 0, (n_step, n_direct)
+        assert n_step == (1, 1) and n_direct == (0, 0), (n_step, n_direct)      # (recurrent backward, encoder backward)
         assert torch.equal(g_step, g_direct) and float(g_step.abs().max()) > 0
         touched = []
         handle = model.gAR.baseNet.weight_hh_l0.register_hook(lambda g: touched.append(float(g.abs().sum())))
         g_hooked, n_hooked = grads("step")
         handle.remove()
-        assert n_hooked == 0 and len(touched) == 1 and touched[0] > 0
+        assert n_hooked == (0, 1) and len(touched) == 1 and touched[0] > 0
         assert torch.equal(g_step, g_hooked)
+        handle = model.gEncoder.conv2.weight.register_hook(lambda g: touched.append(float(g.abs().sum())))
+        g_hooked2, n_hooked2 = grads("step")
+        handle.remove()
+        assert n_hooked2 == (1, 0) and len(touched) == 2 and touched[1] > 0
+        assert torch.equal(g_step, g_hooked2)
         monkeypatch.setattr(lib, "cpc_gru_backward_deferred", real)
+        monkeypatch.setattr(lib, "cpc_encoder_backward_deferred", real_enc)
 
 
 def test_seeded_backward_of_the_summed_losses_is_the_plain_one():

@@ -1,13 +1,13 @@
 #!/bin/bash
 # the GRU's layer-0 weight-gradient products and bias sums on the side stream, under the encoder's backward (shipped) against the
-# immediate form (CPC_NO_GRU_TAIL=1); alternating pairs on one box
+# immediate form (CPC_NO_GRAD_TAIL=1); alternating pairs on one box
 OUT=gpurun_out/ab_gru_tail.txt
 : > $OUT
 for cfg in small large; do
 for rep in 1 2 3; do
   for v in immediate deferred; do
-    unset CPC_NO_GRU_TAIL
-    [ $v = immediate ] && export CPC_NO_GRU_TAIL=1
+    unset CPC_NO_GRAD_TAIL
+    [ $v = immediate ] && export CPC_NO_GRAD_TAIL=1
     timeout -k 10 200 python bench.py --config $cfg --cpu-seconds 0 --also "" --steps 40 --warmup 8 > gpurun_out/ab_x_$v.json 2>gpurun_out/ab_x_$v.err || tail -5 gpurun_out/ab_x_$v.err >> $OUT
     python - >> $OUT <<PY
 import json
