@@ -205,10 +205,11 @@ struct PlanesTNOperand {
 bool gemm_tn_planes_ok(int M, int N, long R);
 size_t gemm_tn_planes_scratch_bytes(int M, int N, long R);
 size_t gemm_nt_planes_scratch_bytes(long M, int N, int K, long out_rows);   // what RowMap::splitk_scratch needs (0: no K split)
-// reduce_on_side: the pass that sums the K split's slabs into C runs on the library's side stream (side_tail_*): C and the scratch
-// are then not to be touched until side_tail_join
+// left_slabs (optional): the K split's slabs are left in `scratch` and their number reported instead of being summed into C -- the
+// caller runs planes_tn_reduce when and where it wants (the deferred encoder backward: on the side stream, at the end)
 int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
-                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st, bool reduce_on_side = false);
+                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st, int *left_slabs = nullptr);
+int planes_tn_reduce(const float *slabs, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k, hipStream_t st);
 
 int gemm_mode();        // gemm_f32.hip: 0 exact bf16 split (six products), 1 f32 MFMA, 2 three products (opt-in, cpc_gemm_set_mode)
 

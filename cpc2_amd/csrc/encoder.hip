@@ -1242,6 +1242,7 @@ static int encoder_backward(const float *x, const float *const *prm, const float
     CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
 
     const float *dy = dz;                  // [N][L[i+1]][H] of the current layer
+    int left[5] = {0, 0, 0, 0, 0};         // deferred form: K-split slabs of the layers' weight-gradient products still to be summed
     for (int i = 4; i >= 1; --i) {
         const int k = kConv[i].k, s = kConv[i].s, p = kConv[i].p;
         // norm + relu backward -> dU_i (shifted rows), partial sums for dgamma, dbeta, dbias
@@ -1258,18 +1259,24 @@ static int encoder_backward(const float *x, const float *const *prm, const float
             const PlaneOut o{e.dUp, e.dUplane, 0, e.dUrows};
             CPC_DISPATCH_HP(H, hipLaunchKernelGGL(norm_bwd_pl_kernel<HH>, dim3(NORM_BWD_BLOCKS), dim3(256), 0, st, na, o, durows / 16));
             CPC_CHECK_LAUNCH("norm_bwd_pl_kernel");
-            {
-                hipStream_t cst = st;
-                if (side) CPC_TRY(side_tail_begin(st, &cst));
-                CPC_TRY(colsum_split(na.part, NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1], H,
-                                     side ? e.cs_l[i] : e.cs, cst));
-                if (side) CPC_TRY(side_tail_end());
-            }
+            if (!side) CPC_TRY(colsum_split(na.part, NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1], H, e.cs, st));
             // weight gradient over the virtual rows (dU is zero on a sample's border rows): dW[co][j*H+ci] = sum_m dU(m+1)[co] Y(m s + j)[ci]
             const PlanesTNOperand TA{e.dUp, e.dUplane, 0, e.dUrows, 1, H};
             const PlanesTNOperand TB{e.Yp[i - 1], e.Yplane[i - 1], log2i(s), e.Yrts[i - 1], 0, H};
             CPC_TRY(gemm_tn_planes(TA, TB, grads[4 * i], 0, H, k * H, (long)N * e.Rv[i], side ? e.tn_l[i] : e.tn, side ? e.tn_l_bytes[i] : e.tn_bytes,
-                                   H, k, st, side));
+                                   H, k, st, side ? &left[i] : nullptr));
+            if (side && i == 1) {
+                // everything the layers have left behind -- their partial sums and K-split slabs, each in a buffer of its own -- is
+                // finished on the side stream from here on, under the last backward-data product and conv0's backward.  ONE fork: an
+                // event on the caller's stream costs it ~6 us of idle time (one per pass made the passes' move a wash)
+                hipStream_t wst = st;
+                CPC_TRY(side_tail_begin(st, &wst));
+                for (int j = 4; j >= 1; --j) {
+                    CPC_TRY(colsum_split(e.part_l[j], NORM_BWD_BLOCKS, 3L * H, 3 * H, grads[4 * j + 2], grads[4 * j + 3], grads[4 * j + 1], H, e.cs_l[j], wst));
+                    if (left[j] > 0) CPC_TRY(planes_tn_reduce(e.tn_l[j], left[j], H, kConv[j].k * H, grads[4 * j], 0, H, kConv[j].k, wst));
+                }
+                CPC_TRY(side_tail_end());
+            }
             // backward data.  Lengths that divide by the stride (training windows): rows t_hi = 0 .. L_out - 1 of every sample
             // in whole tiles, and a small kernel for the boundary row t_hi = L_out; otherwise all L_out + 1 rows in the product
             // (the trailing input rows no output frame reads get a zero gradient)

@@ -894,8 +894,9 @@ size_t gemm_tn_planes_scratch_bytes(int M, int N, long R)
 }
 
 int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C, long ldc, int M, int N, long R, void *scratch,
-                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st, bool reduce_on_side)
+                   size_t scratch_bytes, int conv_cin, int conv_k, hipStream_t st, int *left_slabs)
 {
+    if (left_slabs != nullptr) *left_slabs = 0;
     CPC_REQUIRE(gemm_tn_planes_ok(M, N, R), "gemm_tn_planes: shape M=%d N=%d R=%ld not supported", M, N, R);
     auto bad = [](const PlanesTNOperand &o) {
         return o.p == nullptr || reinterpret_cast<uintptr_t>(o.p) % 32 != 0 || o.plane % 16 != 0 || o.plane <= 0 ||
@@ -924,13 +925,19 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
         if (rc != CPC_OK) return rc;
     }
     CPC_CHECK_LAUNCH("gemm_planes_kernel (tn)");
+    if (left_slabs != nullptr) {           // the caller sums the slabs later (planes_tn_reduce)
+        *left_slabs = S;
+        return CPC_OK;
+    }
+    return planes_tn_reduce(a.slabs, S, M, N, C, ldc, conv_cin, conv_k, st);
+}
+
+int planes_tn_reduce(const float *slabs, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k, hipStream_t st)
+{
     const long total = (long)M * N;
-    hipStream_t rst = st;
-    if (reduce_on_side) CPC_TRY(side_tail_begin(st, &rst));      // (the slabs are the caller's to keep until cpc_side_tail_join)
-    hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total / 4, 256), 2048)), dim3(256), 0, rst, a.slabs, S, M, N, C,
+    hipLaunchKernelGGL(planes_tn_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(total / 4, 256), 2048)), dim3(256), 0, st, slabs, S, M, N, C,
                        ldc, conv_cin, conv_k);
     CPC_CHECK_LAUNCH("planes_tn_reduce_kernel");
-    if (reduce_on_side) CPC_TRY(side_tail_end());
     return CPC_OK;
 }
 
