@@ -63,6 +63,7 @@ SIGNATURES = {
     "cpc_transformer_scratch_bytes": (c_size_t, [c_int] * 7),
     "cpc_transformer_forward": (c_int, [c_ptr] * 5 + [c_int] * 7 + [c_float, ctypes.c_ulonglong, c_ptr]),
     "cpc_transformer_backward": (c_int, [c_ptr] * 7 + [c_int] * 7 + [c_float, ctypes.c_ulonglong, c_ptr]),
+    "cpc_transformer_backward_deferred": (c_int, [c_ptr] * 7 + [c_int] * 7 + [c_float, ctypes.c_ulonglong, c_ptr]),
     "cpc_mt_create": (c_ptr, [ctypes.c_uint32]),
     "cpc_mt_destroy": (None, [c_ptr]),
     "cpc_mt_seed": (c_int, [c_ptr, ctypes.c_uint32]),

@@ -15,6 +15,7 @@
 #include "rowcfg.h"
 
 #include <algorithm>
+#include <functional>
 #include <vector>
 #include <cmath>
 
@@ -918,6 +919,7 @@ struct TrLayout {
     size_t saved_bytes;
     // scratch
     float *wqkv, *wt, *o, *u, *da, *db, *dc, *dh, *dqkv, *part, *krel_part, *tn, *cs;
+    float *da2, *db2, *part2, *tn2;      // second homes of buffers the backward writes twice (transformer_backward, defer_tail)
     size_t tn_bytes, scratch_bytes, lds_fwd, lds_bwd;
 };
 
@@ -970,6 +972,10 @@ static int tr_layout(TrLayout &L, int N, int S, int D, int Dout, int SS, int lay
     // the same room serves an ordered K split of the layer's products when they have few tiles
     L.tn_bytes = std::max(L.tn_bytes, std::max(gemm_nt_scratch_bytes(L.rows * nc, dmax, TR_DFF), gemm_nt_scratch_bytes(L.rows, dmax, 3 * dmax)));
     L.tn = sc.take<float>(L.tn_bytes / sizeof(float));
+    L.da2 = sc.take<float>(R * dmax * nc);
+    L.db2 = sc.take<float>(R * dmax * nc);
+    L.part2 = sc.take<float>((size_t)LN_BWD_BLOCKS * 4 * rows_per_wave(std::min(D, Dout)) * 2 * dmax);
+    L.tn2 = sc.take<float>(L.tn_bytes / sizeof(float));
     L.scratch_bytes = sc.used();
     const size_t ldk = L.dk + 1, ldp = SS + 1;
     L.lds_fwd = sizeof(float) * (2 * SS * ldk + L.dk * ldp + TR_QT * ldk + TR_QT * ldp);
@@ -997,6 +1003,15 @@ static int launch_ln_fwd(const float *a, const float *b, const float *w, const f
     return CPC_OK;
 }
 
+// dgamma / dbeta of a LayerNorm from the partial sums its backward kernel left
+static int ln_bwd_sums(const float *part, int D, float *dw, float *db, hipStream_t st)
+{
+    const long slots = (long)LN_BWD_BLOCKS * 4 * rows_per_wave(D);
+    CPC_TRY(colsum(part, slots, 2L * D, D, dw, st));
+    CPC_TRY(colsum(part + D, slots, 2L * D, D, db, st));
+    return CPC_OK;
+}
+
 static int launch_ln_bwd(const float *dy, const float *xhat, const float *rstd, const float *w, float *dx, float *dw, float *db,
                          float *part, long rows, int D, hipStream_t st)
 {
@@ -1005,10 +1020,8 @@ static int launch_ln_bwd(const float *dy, const float *xhat, const float *rstd, 
     la.rows = rows;
     CPC_DISPATCH_H(D, hipLaunchKernelGGL(ln_bwd_kernel<HH>, dim3(LN_BWD_BLOCKS), dim3(256), 0, st, la));
     CPC_CHECK_LAUNCH("ln_bwd_kernel");
-    const long slots = (long)LN_BWD_BLOCKS * 4 * rows_per_wave(D);
-    CPC_TRY(colsum(part, slots, 2L * D, D, dw, st));
-    CPC_TRY(colsum(part + D, slots, 2L * D, D, db, st));
-    return CPC_OK;
+    if (dw == nullptr) return CPC_OK;            // the caller sums the partials later (ln_bwd_sums)
+    return ln_bwd_sums(part, D, dw, db, st);
 }
 
 static uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0); }
@@ -1102,7 +1115,7 @@ static int transformer_forward(const float *x, const float *const *prm, float *o
 
 static int transformer_backward(const float *x, const float *const *prm, const float *dout, void *saved, void *scratch, float *dx,
                                 float *const *grads, int N, int S, int D, int Dout, int SS, int layers, int nc, float p_drop,
-                                uint64_t seed, hipStream_t st)
+                                uint64_t seed, hipStream_t st, bool defer_tail = false)
 {
     TrLayout L;
     CPC_TRY(tr_layout(L, N, S, D, Dout, SS, layers, nc, saved, scratch));
@@ -1112,22 +1125,44 @@ static int transformer_backward(const float *x, const float *const *prm, const f
     RowMap none{};
     none.splitk_scratch = L.tn; none.splitk_bytes = L.tn_bytes;
     const float *dcur = dout;
+    // defer_tail: everything that only FINISHES a parameter gradient of the last layer handled (layer 0) -- seven weight-gradient
+    // products, their bias sums, the LayerNorms' and Krelpos' column sums: ~0.6 ms of a CPC-transformer step that nothing on `st`
+    // needs -- is collected and launched on the library's side stream at the end (ONE fork), where it runs under the encoder's
+    // backward.  The two buffers the pass writes twice (da, db) and the LayerNorm partials get second homes, the input-gradient
+    // products their own K-split room.
+    std::vector<std::function<int(hipStream_t)>> tail;
     for (int l = layers - 1; l >= 0; --l) {
         const float *const *p = prm + (size_t)l * P_COUNT;
         float *const *g = grads + (size_t)l * P_COUNT;
         const float *xin = (l == 0) ? x : L.xout[l - 1];
         const uint64_t lseed = seed + 0x1000ull * (uint64_t)l;
         const int k = (l + 1 == layers) ? nc : 1;          // classifiers of this layer's head
+        const bool dt = defer_tail && l == 0 && nc == 1;
+        float *const da2 = dt ? L.da2 : L.da, *const db2 = dt ? L.db2 : L.db, *const part2 = dt ? L.part2 : L.part;
+        if (dt) { none.splitk_scratch = L.tn2; }            // (L.tn is the side stream's from here on)
+        auto W = [&](std::function<int(hipStream_t)> fn) -> int {
+            if (dt) { tail.push_back(std::move(fn)); return CPC_OK; }
+            return fn(st);
+        };
         // LN2
-        CPC_TRY(launch_ln_bwd(dcur, L.xh2[l], L.rstd2[l], p[P_LN2W], L.da, g[P_LN2W], g[P_LN2B], L.part, R * k, Dout, st));   // da = du
+        if (l == layers - 1) CPC_TRY(infonce_deferred_mark(st));      // (see infonce_deferred_start below)
+        CPC_TRY(launch_ln_bwd(dcur, L.xh2[l], L.rstd2[l], p[P_LN2W], L.da, nullptr, nullptr, L.part, R * k, Dout, st));       // da = du
+        // a deferred criterion backward waiting to run (its dz sum and predictor weight gradients) starts here, beside this layer's
+        // backward, as it does beside the recurrent kernels (no-op when nothing is pending)
+        if (l == layers - 1) CPC_TRY(infonce_deferred_start(st));
+        CPC_TRY(W([=](hipStream_t ws) -> int { return ln_bwd_sums(L.part, Dout, g[P_LN2W], g[P_LN2B], ws); }));
         // last_linear: u = t Wl^T + bl
-        CPC_TRY(gemm_tn(L.da, Dout, L.t[l], D, g[P_WL], D, Dout, D, R * k, L.tn, L.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(L.da, Dout, R * k, Dout, g[P_BL], L.cs, st));
+        CPC_TRY(W([=](hipStream_t ws) -> int {
+            CPC_TRY(gemm_tn(L.da, Dout, L.t[l], D, g[P_WL], D, Dout, D, R * k, L.tn, L.tn_bytes, 0, 0, ws));
+            return colsum_rows(L.da, Dout, R * k, Dout, g[P_BL], L.cs, ws);
+        }));
         CPC_TRY(transpose2d(p[P_WL], L.wt, Dout, D, st));                                            // [D][Dout]
         CPC_TRY(gemm_nt(L.da, Dout, L.wt, Dout, L.db, D, nullptr, R * k, D, Dout, none, st));        // db = dt [R*k][D] = df [R][k*D]
         // lin2: f = h W2^T + b2
-        CPC_TRY(gemm_tn(L.db, (long)k * D, L.hdrop[l], TR_DFF, g[P_W2], TR_DFF, k * D, TR_DFF, R, L.tn, L.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(L.db, (long)k * D, R, k * D, g[P_B2], L.cs, st));
+        CPC_TRY(W([=](hipStream_t ws) -> int {
+            CPC_TRY(gemm_tn(L.db, (long)k * D, L.hdrop[l], TR_DFF, g[P_W2], TR_DFF, k * D, TR_DFF, R, L.tn, L.tn_bytes, 0, 0, ws));
+            return colsum_rows(L.db, (long)k * D, R, k * D, g[P_B2], L.cs, ws);
+        }));
         CPC_TRY(transpose2d(p[P_W2], L.wt, k * D, TR_DFF, st));                                      // [dff][k*D]
         {   // (the adjoint of ReLU + dropout in the epilogue: h holds relu(.) * mask * scale, an element carries gradient iff it is > 0)
             RowMap gate = none;
@@ -1136,8 +1171,10 @@ static int transformer_backward(const float *x, const float *const *prm, const f
             CPC_TRY(gemm_nt(L.db, (long)k * D, L.wt, (long)k * D, L.dh, TR_DFF, nullptr, R, TR_DFF, k * D, gate, st));
         }
         // lin1: h = y W1^T + b1
-        CPC_TRY(gemm_tn(L.dh, TR_DFF, L.y[l], D, g[P_W1], D, TR_DFF, D, R, L.tn, L.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(L.dh, TR_DFF, R, TR_DFF, g[P_B1], L.cs, st));
+        CPC_TRY(W([=](hipStream_t ws) -> int {
+            CPC_TRY(gemm_tn(L.dh, TR_DFF, L.y[l], D, g[P_W1], D, TR_DFF, D, R, L.tn, L.tn_bytes, 0, 0, ws));
+            return colsum_rows(L.dh, TR_DFF, R, TR_DFF, g[P_B1], L.cs, ws);
+        }));
         CPC_TRY(transpose2d(p[P_W1], L.wt, TR_DFF, D, st));                                          // [D][dff]
         CPC_TRY(gemm_nt(L.dh, TR_DFF, L.wt, TR_DFF, L.dc, D, nullptr, R, D, TR_DFF, none, st));      // dc = dy_b
         if (k > 1) {                                                                                  // dy_a = sum over classifiers of dt
@@ -1148,17 +1185,18 @@ static int transformer_backward(const float *x, const float *const *prm, const f
             CPC_TRY(launch_add2(L.dc, L.dc, L.db, R * D, st));                                        // dy = dy_a + dy_b
         }
         // LN1: y = LN(x + o)
-        CPC_TRY(launch_ln_bwd(L.dc, L.xh1[l], L.rstd1[l], p[P_LN1W], L.da, g[P_LN1W], g[P_LN1B], L.part, R, D, st));      // da = d(x+o)
+        CPC_TRY(launch_ln_bwd(L.dc, L.xh1[l], L.rstd1[l], p[P_LN1W], da2, nullptr, nullptr, part2, R, D, st));             // da2 = d(x+o)
+        CPC_TRY(W([=](hipStream_t ws) -> int { return ln_bwd_sums(part2, D, g[P_LN1W], g[P_LN1B], ws); }));
         // Wo: o = ctx Wo^T
-        CPC_TRY(gemm_tn(L.da, D, L.ctx[l], D, g[P_WO], D, D, D, R, L.tn, L.tn_bytes, 0, 0, st));
+        CPC_TRY(W([=](hipStream_t ws) -> int { return gemm_tn(da2, D, L.ctx[l], D, g[P_WO], D, D, D, R, L.tn, L.tn_bytes, 0, 0, ws); }));
         CPC_TRY(transpose2d(p[P_WO], L.wt, D, D, st));
-        CPC_TRY(gemm_nt(L.da, D, L.wt, D, L.db, D, nullptr, R, D, D, none, st));                     // db = dctx
+        CPC_TRY(gemm_nt(da2, D, L.wt, D, db2, D, nullptr, R, D, D, none, st));                       // db2 = dctx
         // attention
         AttnArgs aa{};
         aa.qkv = L.qkv[l]; aa.krel = p[P_KREL]; aa.probs = L.probs[l];
         aa.N = N; aa.S = S; aa.D = D; aa.dk = L.dk; aa.SS = SS; aa.chunks = L.chunks;
         aa.seed = lseed; aa.thresh = thresh; aa.scale = scale; aa.inv_sqrt_dk = 1.f / std::sqrt((float)L.dk);
-        aa.dctx = L.db; aa.dqkv = L.dqkv; aa.dkrel_part = L.krel_part;
+        aa.dctx = db2; aa.dqkv = L.dqkv; aa.dkrel_part = L.krel_part;
         const int nchunk = N * TR_HEADS * L.chunks;
         int status = CPC_OK;
         static const bool attn_valu = getenv("CPC_ATTN_VALU") != nullptr;
@@ -1198,14 +1236,16 @@ static int transformer_backward(const float *x, const float *const *prm, const f
         }
         CPC_TRY(status);
         CPC_CHECK_LAUNCH("attn_bwd_kernel");
-        if (p[P_KREL] != nullptr) CPC_TRY(colsum(L.krel_part, nchunk, (long)L.dk * SS, L.dk * SS, g[P_KREL], st));
+        if (p[P_KREL] != nullptr)
+            CPC_TRY(W([=](hipStream_t ws) -> int { return colsum(L.krel_part, nchunk, (long)L.dk * SS, L.dk * SS, g[P_KREL], ws); }));
         // Q/K/V projections
-        if (g[P_WK] == g[P_WQ] + (size_t)D * D && g[P_WV] == g[P_WK] + (size_t)D * D) {            // (back to back: one product)
-            CPC_TRY(gemm_tn(L.dqkv, 3L * D, xin, D, g[P_WQ], D, 3 * D, D, R, L.tn, L.tn_bytes, 0, 0, st));
-        } else {
+        CPC_TRY(W([=](hipStream_t ws) -> int {
+            if (g[P_WK] == g[P_WQ] + (size_t)D * D && g[P_WV] == g[P_WK] + (size_t)D * D)               // (back to back: one product)
+                return gemm_tn(L.dqkv, 3L * D, xin, D, g[P_WQ], D, 3 * D, D, R, L.tn, L.tn_bytes, 0, 0, ws);
             for (int i = 0; i < 3; ++i)
-                CPC_TRY(gemm_tn(L.dqkv + (size_t)i * D, 3L * D, xin, D, g[P_WQ + i], D, D, D, R, L.tn, L.tn_bytes, 0, 0, st));
-        }
+                CPC_TRY(gemm_tn(L.dqkv + (size_t)i * D, 3L * D, xin, D, g[P_WQ + i], D, D, D, R, L.tn, L.tn_bytes, 0, 0, ws));
+            return (int)CPC_OK;
+        }));
         float *dxl = (l == 0) ? dx : L.dc;
         if (dxl != nullptr) {
             const float *wqkv = p[P_WQ];
@@ -1216,9 +1256,15 @@ static int transformer_backward(const float *x, const float *const *prm, const f
             }
             CPC_TRY(transpose2d(wqkv, L.wt, 3 * D, D, st));                                           // [D][3D]
             CPC_TRY(gemm_nt(L.dqkv, 3L * D, L.wt, 3L * D, L.u, D, nullptr, R, D, 3 * D, none, st));
-            CPC_TRY(launch_add2(dxl, L.u, L.da, R * D, st));                                           // + residual path
+            CPC_TRY(launch_add2(dxl, L.u, da2, R * D, st));                                            // + residual path
         }
         dcur = dxl;
+    }
+    if (!tail.empty()) {
+        hipStream_t ws = st;
+        CPC_TRY(side_tail_begin(st, &ws));
+        for (auto &fn : tail) CPC_TRY(fn(ws));
+        CPC_TRY(side_tail_end());
     }
     return CPC_OK;
 }
@@ -1255,4 +1301,13 @@ extern "C" int cpc_transformer_backward(const float *x, const float *const *para
 {
     return cpc::transformer_backward(x, params, dout, saved, scratch, dx, grads, n, s, d_model, d_out, size_seq, layers, n_classifiers, dropout_p,
                                      seed, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_transformer_backward_deferred(const float *x, const float *const *params, const float *dout, void *saved, void *scratch,
+                                                 float *dx, float *const *grads, int n, int s, int d_model, int d_out, int size_seq,
+                                                 int layers, int n_classifiers, float dropout_p, unsigned long long seed,
+                                                 cpc_stream_t stream)
+{
+    return cpc::transformer_backward(x, params, dout, saved, scratch, dx, grads, n, s, d_model, d_out, size_seq, layers, n_classifiers, dropout_p,
+                                     seed, static_cast<hipStream_t>(stream), true);
 }

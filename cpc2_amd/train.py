@@ -471,10 +471,9 @@ def _ar_scope(cpcModel):
     import contextlib
     stack = contextlib.ExitStack()
     if isinstance(cpcModel, CPCModel):
-        if isinstance(cpcModel.gAR, CPCAR):
-            stack.enter_context(cpcModel.gAR.deferred_weight_gradients())
-        if isinstance(cpcModel.gEncoder, CPCEncoder):
-            stack.enter_context(cpcModel.gEncoder.deferred_weight_gradients())
+        for m in cpcModel.modules():            # CPCEncoder, CPCAR, TransformerLayer
+            if hasattr(m, "deferred_weight_gradients"):
+                stack.enter_context(m.deferred_weight_gradients())
     return stack
 
 

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import check, f32c, grad_buffers, ptr, ptr_array, require_gpu, scratch, stream_ptr
+from ._tail import _TailScope, _all_in_place, _keep_for_tail, _no_hooks
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -68,11 +69,12 @@ class _TransformerFn(torch.autograd.Function):
     n_classifiers > 1: the last layer is a MultiClassifierTransformerHead and the output is [n, s, k, d_out]."""
 
     @staticmethod
-    def forward(ctx, x, size_seq, n_layers, n_classifiers, dropout_p, seed, *params):
+    def forward(ctx, x, size_seq, n_layers, n_classifiers, dropout_p, seed, defer_tail, *params):
         require_gpu(x, *[p for p in params if p is not None])
         lib = _lib.load()
         x = f32c(x)
         ctx.param_refs = params
+        ctx.defer_tail = bool(defer_tail) and n_classifiers == 1
         params = tuple(f32c(p) if p is not None else None for p in params)
         n, s, d_model = x.shape
         per = lib.cpc_transformer_param_count()
@@ -100,12 +102,24 @@ class _TransformerFn(torch.autograd.Function):
         dout = f32c(dout)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         grads = grad_buffers(ctx.param_refs)
-        sc = scratch(lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers, n_classifiers), x.device)
-        check(lib.cpc_transformer_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
-                                           n, s, d_model, d_out, size_seq, n_layers, n_classifiers, dropout_p, seed,
-                                           stream_ptr(x.device)),
-              "transformer_backward")
-        return (dx, None, None, None, None, None) + tuple(grads)
+        nscratch = lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers, n_classifiers)
+        per = lib.cpc_transformer_param_count()
+        l0 = [(p, g) for p, g in zip(ctx.param_refs[:per], grads[:per]) if p is not None]
+        # the deferred form (cpc2_hip.h): inside the caller's scope (TransformerLayer.deferred_weight_gradients) and with every
+        # gradient of layer 0 written in place into the flat gradient buffer (model.py, _GruFn.backward)
+        if ctx.defer_tail and _all_in_place([p for p, _g in l0], [g for _p, g in l0]):
+            sc = scratch(nscratch, x.device, tag="tr_tail")      # a buffer of its own: the side stream outlives this call
+            check(lib.cpc_transformer_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
+                                                        ptr_array(grads), n, s, d_model, d_out, size_seq, n_layers, n_classifiers,
+                                                        dropout_p, seed, stream_ptr(x.device)), "transformer_backward_deferred")
+            _keep_for_tail(x.device, (x, saved, params, dout, sc))
+        else:
+            sc = scratch(nscratch, x.device)
+            check(lib.cpc_transformer_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
+                                               n, s, d_model, d_out, size_seq, n_layers, n_classifiers, dropout_p, seed,
+                                               stream_ptr(x.device)),
+                  "transformer_backward")
+        return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
 class TransformerLayer(nn.Module):
@@ -121,6 +135,12 @@ class TransformerLayer(nn.Module):
         self.sizeSeq = sizeSeq
         self.dropout_p = float(dropout)
         self._calls = 0
+        self._defer_tail = False       # set by deferred_weight_gradients() for the duration of the caller's scope
+
+    def deferred_weight_gradients(self):
+        """Context manager around the FORWARD call (model.py, _TailScope): the backward of a forward pass made inside may leave this
+        layer's parameter-gradient work on the library's side stream until the end of the backward pass."""
+        return _TailScope(self)
 
     def _param_list(self):
         m = self.multihead
@@ -136,7 +156,9 @@ class TransformerLayer(nn.Module):
         # a fresh dropout stream per call, derived from torch's CPU generator (so torch.manual_seed governs it)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
         x, s = _pad_to_blocks(x, self.sizeSeq)
-        return _TransformerFn.apply(x, self.sizeSeq, 1, 1, p, seed, *self._param_list())[:, :s]
+        params = self._param_list()
+        defer = self._defer_tail and _no_hooks([q for q in params if q is not None])
+        return _TransformerFn.apply(x, self.sizeSeq, 1, 1, p, seed, defer, *params)[:, :s]
 
 
 def _pad_to_blocks(x, size_seq):
@@ -190,7 +212,7 @@ class MultiClassifierTransformerHead(nn.Module):
         p = self.dropout_p if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
         x, s = _pad_to_blocks(x, self.sizeSeq)
-        return _TransformerFn.apply(x, self.sizeSeq, 1, self.nclassifiers, p, seed, *self._param_list())[:, :s]
+        return _TransformerFn.apply(x, self.sizeSeq, 1, self.nclassifiers, p, seed, False, *self._param_list())[:, :s]
 
 
 def buildTransformerAR(dimEncoded, dimAR, nLayers, sizeSeq, abspos):

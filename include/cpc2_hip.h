@@ -254,6 +254,13 @@ int cpc_transformer_backward(const float *x, const float *const *params, const f
                              void *scratch, float *dx, float *const *grads, int n, int s, int d_model,
                              int d_out, int size_seq, int layers, int n_classifiers, float dropout_p,
                              unsigned long long seed, cpc_stream_t stream);
+/* Deferred form (see cpc_gru_backward_deferred): with one classifier, every parameter gradient of layer 0 -- seven weight-gradient
+ * products with their bias sums, the LayerNorms' and Krelpos' column sums -- is produced on the library's stream after this call
+ * has returned; `dx` and the gradients of layers 1.. are ordered on `stream`.  cpc_side_tail_join before anything reads them. */
+int cpc_transformer_backward_deferred(const float *x, const float *const *params, const float *dout, void *saved,
+                             void *scratch, float *dx, float *const *grads, int n, int s, int d_model,
+                             int d_out, int size_seq, int layers, int n_classifiers, float dropout_p,
+                             unsigned long long seed, cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Negative-index sampler of CPCUnsupersivedCriterion.sampleClean (criterion.py:247-266), HOST

@@ -1895,6 +1895,57 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
         monkeypatch.setattr(lib, "cpc_encoder_backward_deferred", real_enc)
 
 
+def test_transformer_parameter_gradients_are_deferred_inside_the_callers_scope(monkeypatch):
+    """cpc_transformer_backward_deferred (arMode='transformer': the layer's seven weight-gradient products, bias sums and column sums
+    on the library's side stream): cpcStep on the bare model defers, the model called directly does not, every gradient of the step
+    is the same bit for bit -- in training mode (dropout on, same seed) and with the criterion's own deferred backward beside it."""
+    from cpc2_amd import model as model_mod
+    from cpc2_amd.transformers import buildTransformerAR
+    hidden, b = 256, 2
+    mp = synth.encoder_params(hidden, 51)
+    mp.update(synth.transformer_params(hidden, hidden, 128, 52))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), buildTransformerAR(hidden, hidden, 1, 128, False))
+    sd = dict(mp)
+    sd.update({kk: v for kk, v in model.state_dict().items() if kk.endswith(".z") or kk.endswith(".mask")})
+    model.load_state_dict(sd)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128)
+    crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 53))
+    model, crit = model.to(DEV).train(), crit.to(DEV).train()
+    opt = buildOptimizer(model, crit, lr=2e-4)
+    x = synth.audio_windows(b, 20480, 54).to(DEV)
+    label = torch.zeros(b, dtype=torch.long, device=DEV)
+    lib = _lib.load()
+    calls = []
+    real = lib.cpc_transformer_backward_deferred
+
+    def spy(*a):
+        calls.append(1)
+        return real(*a)
+    monkeypatch.setattr(lib, "cpc_transformer_backward_deferred", spy)
+
+    def grads(how):
+        crit.seed(5)
+        torch.manual_seed(11)                              # (the layer draws its dropout seed from torch's generator)
+        opt.zero_grad()
+        del calls[:]
+        if how == "step":
+            tot, _l, _a = cpcStep(x, x, label, model, crit)
+        else:
+            c, z, _ = model(torch.cat([x, x]), label)
+            losses, _a = crit(c[:b], z[b:], label)
+            tot = losses.sum()
+        tot.backward()
+        assert not model_mod._tail
+        opt._gather_stray_grads()
+        torch.cuda.synchronize()
+        return opt.flat_grad.detach().clone(), len(calls)
+    g_step, n_step = grads("step")
+    g_direct, n_direct = grads("direct")
+    monkeypatch.setattr(lib, "cpc_transformer_backward_deferred", real)
+    assert (n_step, n_direct) == (1, 0)
+    assert torch.equal(g_step, g_direct) and float(g_step.abs().max()) > 0
+
+
 def test_seeded_backward_of_the_summed_losses_is_the_plain_one():
     """cpc2_amd.train.backward(totLoss) (train.py:106,109 without the one-element kernels autograd puts between the criterion's
     forward and backward: a cached 1.0 as the root gradient, a cached vector of ones out of the sum's backward) gives every
