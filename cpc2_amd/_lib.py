@@ -54,6 +54,7 @@ SIGNATURES = {
     "cpc_lstm_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cpc_lstm_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_lstm_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_lstm_backward_deferred": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_rnn_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cpc_rnn_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cpc_rnn_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),

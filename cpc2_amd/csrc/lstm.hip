@@ -553,7 +553,8 @@ struct LstmLayout {
     float *gates[8], *hall[8], *call[8], *outl[8];
     size_t saved_bytes;
     // scratch
-    float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn;
+    float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn, *tn2;
+    size_t tn2_bytes;
     float4 *wpack;
     gu64_t *comm;
     size_t comm_bytes;
@@ -592,6 +593,8 @@ int lstm_layout(LstmLayout &g, int G, int N, int T, int Din, int H, int layers, 
     // the same room serves an ordered K split of the projections when they have few tiles
     g.tn_bytes = std::max(g.tn_bytes, std::max(gemm_nt_scratch_bytes((long)N * T, G * H, dmax), gemm_nt_scratch_bytes((long)N * T, dmax, G * H)));
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
+    g.tn2_bytes = gemm_nt_scratch_bytes((long)N * T, dmax, G * H);      // (the input-gradient product's K split beside a deferred tail)
+    g.tn2 = sc.take<float>(g.tn2_bytes / sizeof(float));
     g.scratch_bytes = sc.used();
     return CPC_OK;
 }
@@ -669,7 +672,7 @@ static int lstm_forward(const float *x, const float *const *prm, const float *h0
 
 template <int G>
 static int lstm_backward(const float *x, const float *const *prm, const float *dout, void *saved, void *scratch, float *dx,
-                         float *const *grads, int N, int T, int Din, int H, int layers, hipStream_t st)
+                         float *const *grads, int N, int T, int Din, int H, int layers, hipStream_t st, bool defer_tail = false)
 {
     LstmLayout g;
     CPC_TRY(lstm_layout(g, G, N, T, Din, H, layers, saved, scratch));
@@ -710,18 +713,24 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         CPC_CHECK_LAUNCH("lstm_bwd_kernel");
         CPC_TRY(infonce_deferred_start(st));      // (no-op unless a deferred criterion backward is waiting to run beside this)
         const int GH = G * H;
+        // (defer_tail: layer 0's weight gradients on the library's side stream, as in gru_backward)
+        hipStream_t wst = st;
+        const bool tail = defer_tail && l == 0;
+        if (tail) CPC_TRY(side_tail_begin(st, &wst));
         // dW_hh[g][k] = sum_{n,t} dG[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)
-        CPC_TRY(gemm_tn(g.dgh, GH, g.hall[l], H, grads[4 * l + 1], H, GH, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(g.dgh, GH, (long)N * (T + 1), GH, grads[4 * l + 3], g.cs, st));
+        CPC_TRY(gemm_tn(g.dgh, GH, g.hall[l], H, grads[4 * l + 1], H, GH, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(g.dgh, GH, (long)N * (T + 1), GH, grads[4 * l + 3], g.cs, wst));
         // dW_ih[g][k] = sum dG[n,t][g] * x[n,t][k]
-        CPC_TRY(gemm_tn(g.dgi, GH, xin, din, grads[4 * l], din, GH, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, st));
-        CPC_TRY(colsum_rows(g.dgi, GH, (long)N * T, GH, grads[4 * l + 2], g.cs, st));
+        CPC_TRY(gemm_tn(g.dgi, GH, xin, din, grads[4 * l], din, GH, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(g.dgi, GH, (long)N * T, GH, grads[4 * l + 2], g.cs, wst));
+        if (tail) CPC_TRY(side_tail_end());
         // dX = dG . W_ih
         float *dxl = (l == 0) ? dx : ((l % 2) ? g.dxa : g.dxb);
         if (dxl != nullptr) {
             CPC_TRY(transpose2d(w_ih, g.wt, GH, din, st));                         // [din][G*H]
             RowMap none{};
-        none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes;
+            if (tail) { none.splitk_scratch = g.tn2; none.splitk_bytes = g.tn2_bytes; }        // (g.tn is the side stream's now)
+            else { none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes; }
             CPC_TRY(gemm_nt(g.dgi, GH, g.wt, GH, dxl, din, nullptr, (long)N * T, din, GH, none, st));
         }
         dcur = dxl;
@@ -761,6 +770,15 @@ extern "C" int cpc_lstm_backward(const float *x, const float *const *params, con
     CPC_TRY(cpc::coop_error_take("cpc_lstm_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_backward<4>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_lstm_backward_deferred(const float *x, const float *const *params, const float *dout, void *saved, void *scratch,
+                                          float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
+                                          cpc_stream_t stream)
+{
+    CPC_TRY(cpc::coop_error_take("cpc_lstm_backward_deferred"));
+    return cpc::lstm_backward<4>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
+                                 static_cast<hipStream_t>(stream), true);
 }
 
 extern "C" size_t cpc_rnn_saved_bytes(int n, int t, int dim_in, int hidden, int layers)

@@ -246,11 +246,12 @@ class _GruFn(torch.autograd.Function):
 
 class _LstmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, n_layers, want_hidden, *params):
+    def forward(ctx, x, h0, c0, n_layers, want_hidden, defer_tail, *params):
         require_gpu(x, *params)
         lib = _lib.load()
         x = f32c(x)
         ctx.param_refs = params
+        ctx.defer_tail = bool(defer_tail)
         params = tuple(f32c(p) for p in params)
         n, t, dim_in = x.shape
         hidden = params[1].shape[1]
@@ -284,11 +285,18 @@ class _LstmFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
-        sc = scratch(lib.cpc_lstm_scratch_bytes(n, t, dim_in, hidden, n_layers), x.device)
-        check(lib.cpc_lstm_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
-                                    ptr_array(grads), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
-              "lstm_backward")
-        return (dx, None, None, None, None) + tuple(grads)
+        nscratch = lib.cpc_lstm_scratch_bytes(n, t, dim_in, hidden, n_layers)
+        if ctx.defer_tail and _all_in_place(ctx.param_refs[:4], grads[:4]):        # (the deferred form: see _GruFn.backward)
+            sc = scratch(nscratch, x.device, tag="lstm_tail")
+            check(lib.cpc_lstm_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
+                                                 n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "lstm_backward_deferred")
+            _keep_for_tail(x.device, (x, saved, params, dout, sc))
+        else:
+            sc = scratch(nscratch, x.device)
+            check(lib.cpc_lstm_backward(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
+                                        ptr_array(grads), n, t, dim_in, hidden, n_layers, stream_ptr(x.device)),
+                  "lstm_backward")
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
 class CPCAR(nn.Module):
@@ -329,7 +337,7 @@ class CPCAR(nn.Module):
         layers, keep = self.baseNet.num_layers, bool(self.keepHidden)
         if isinstance(self.baseNet, nn.LSTM):
             h0, c0 = self.hidden if self.hidden is not None else (None, None)
-            x, h, c = _LstmFn.apply(x, h0, c0, layers, keep, *self._param_list())
+            x, h, c = _LstmFn.apply(x, h0, c0, layers, keep, self._defer_tail and self._may_defer(), *self._param_list())
             if self.keepHidden:
                 self.hidden = (h.detach(), c.detach())
         else:
@@ -409,7 +417,7 @@ class LSTMPredictor(nn.LSTM):
             raise NotImplementedError("LSTMPredictor: batch_first, unidirectional, zero initial state only")
         params = [getattr(self, f"{n}_l{layer}") for layer in range(self.num_layers)
                   for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
-        return _LstmFn.apply(x, None, None, self.num_layers, False, *params)[0], None
+        return _LstmFn.apply(x, None, None, self.num_layers, False, False, *params)[0], None
 
 
 class RNNPredictor(nn.RNN):

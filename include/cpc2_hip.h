@@ -213,6 +213,10 @@ int cpc_lstm_forward(const float *x, const float *const *params, const float *h0
 int cpc_lstm_backward(const float *x, const float *const *params, const float *dout, void *saved,
                       void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
                       int hidden, int layers, cpc_stream_t stream);
+/* Deferred form: as cpc_gru_backward_deferred (layer 0's weight gradients on the library's stream until cpc_side_tail_join). */
+int cpc_lstm_backward_deferred(const float *x, const float *const *params, const float *dout, void *saved,
+                      void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
+                      int hidden, int layers, cpc_stream_t stream);
 
 /* CPCAR with mode="RNN" (model.py:174-176 -> torch.nn.RNN, tanh): weight_ih [H, in], weight_hh [H, H],
  * bias_ih [H], bias_hh [H]; arguments as for the GRU. */

@@ -1835,10 +1835,10 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
     (2) model called directly (the reference's train.py), or a tensor hook on one of those weights: not deferred;
     (3) two GRU layers: layer 1's gradients on the caller's stream, layer 0's deferred -- same bits again."""
     from cpc2_amd import model as model_mod
-    for layers, hidden, b in ((1, 256, 2), (2, 256, 2)):
+    for layers, hidden, b, mode in ((1, 256, 2, "GRU"), (2, 256, 2, "GRU"), (1, 256, 2, "LSTM")):
         mp = synth.encoder_params(hidden, 41)
-        mp.update(synth.gru_params(hidden, hidden, layers, 42))
-        model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, layers))
+        mp.update((synth.gru_params if mode == "GRU" else synth.lstm_params)(hidden, hidden, layers, 42))
+        model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, layers, mode=mode))
         model.load_state_dict(mp)
         crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 32, rnnMode="linear", sizeInputSeq=128)
         crit.load_state_dict(synth.predictor_params(12, hidden, hidden, 43))
@@ -1848,7 +1848,8 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
         label = torch.zeros(b, dtype=torch.long, device=DEV)
         lib = _lib.load()
         calls, enc_calls = [], []
-        real, real_enc = lib.cpc_gru_backward_deferred, lib.cpc_encoder_backward_deferred
+        rec_name = "cpc_gru_backward_deferred" if mode == "GRU" else "cpc_lstm_backward_deferred"
+        real, real_enc = getattr(lib, rec_name), lib.cpc_encoder_backward_deferred
 
         def spy(*a):
             calls.append(1)
@@ -1857,7 +1858,7 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
         def spy_enc(*a):
             enc_calls.append(1)
             return real_enc(*a)
-        monkeypatch.setattr(lib, "cpc_gru_backward_deferred", spy)
+        monkeypatch.setattr(lib, rec_name, spy)
         monkeypatch.setattr(lib, "cpc_encoder_backward_deferred", spy_enc)
 
         def grads(how):
@@ -1891,7 +1892,7 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
         handle.remove()
         assert n_hooked2 == (1, 0) and len(touched) == 2 and touched[1] > 0
         assert torch.equal(g_step, g_hooked2)
-        monkeypatch.setattr(lib, "cpc_gru_backward_deferred", real)
+        monkeypatch.setattr(lib, rec_name, real)
         monkeypatch.setattr(lib, "cpc_encoder_backward_deferred", real_enc)
 
 
