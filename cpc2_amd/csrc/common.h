@@ -65,9 +65,14 @@ enum ProfSlot { PROF_GEMM_NT = 0, PROF_GEMM_TN, PROF_NCE_FWD, PROF_NCE_BWD, PROF
                 PROF_CONV0_BWD, PROF_PLANES_NT, PROF_PLANES_TN, PROF_SLOTS };
 class ProfScope {
 public:
-    ProfScope(int slot, hipStream_t st);
+    // attached = true: the scope records nothing itself -- the ONE kernel launched inside takes start() / stop() as the events
+    // of its own dispatch (hipExtLaunchKernelGGL): no barrier packets on the stream, which cost ~6 us of idle time each
+    ProfScope(int slot, hipStream_t st, bool attached = false);
     ~ProfScope();
+    hipEvent_t start() const { return active_ ? a_ : nullptr; }
+    hipEvent_t stop() const { return active_ ? b_ : nullptr; }
 private:
+    bool attached_;
     int slot_;
     hipStream_t st_;
     hipEvent_t a_, b_;

@@ -25,6 +25,7 @@
 //   row block 3 is multiplied while those reads and the new requests are under way.
 // All LDS traffic is issued from inline asm: hipcc drains vmcnt to 0 before any LDS read it can see behind an LDS-DMA.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "ldsdma.h"
 #include "rowcfg.h"
 
@@ -727,7 +728,8 @@ bool gemm_nt_planes_norm_ok(long M, int N, int K)
 }
 
 // one instantiation: dynamic LDS attribute (once), launch
-template <int DBG, bool TN, int TERMS, bool NORM, bool PAIR> static int launch_planes(dim3 grid, const PlanesNTArgs &a, hipStream_t st)
+template <int DBG, bool TN, int TERMS, bool NORM, bool PAIR> static int launch_planes(dim3 grid, const PlanesNTArgs &a, hipStream_t st,
+                                                                                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
     constexpr int bytes = PAIR ? PP_LDS : PT_LDS;
     static bool attr_set = false;
@@ -736,7 +738,10 @@ template <int DBG, bool TN, int TERMS, bool NORM, bool PAIR> static int launch_p
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_planes_kernel<DBG, TN, TERMS, NORM, PAIR>), grid, dim3(512), bytes, st, a);
+    if (ev_start != nullptr)       // (in-situ timing: the events of the dispatch itself, no barrier packets on the stream)
+        hipExtLaunchKernelGGL((gemm_planes_kernel<DBG, TN, TERMS, NORM, PAIR>), grid, dim3(512), bytes, st, ev_start, ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL((gemm_planes_kernel<DBG, TN, TERMS, NORM, PAIR>), grid, dim3(512), bytes, st, a);
     return CPC_OK;
 }
 
@@ -785,25 +790,26 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
     static const bool no_pair = getenv("CPC_PLANES_NO_PAIR") != nullptr;
     const bool pair = !no_pair && A.kshift >= 1 && a.A.segv % PT_BM == 0 && M % PT_BM == 0 && (a.kchunk / PT_BK) % 2 == 0;
     const dim3 grid((unsigned)blocks, (unsigned)splits);
-    ProfScope prof(PROF_PLANES_NT, st);
+    ProfScope prof(PROF_PLANES_NT, st, true);
+    const hipEvent_t e0 = prof.start(), e1 = prof.stop();
     int rc = CPC_OK;
     const int mode3 = gemm_mode() == 2;
     const int sel = (a.dbg & 48) ? ((a.dbg & 48) >> 2) : (a.dbg & 3);                 // DBG template value of the probes
     if (pair) {
-        if (sel == 1) rc = launch_planes<1, false, 6, false, true>(grid, a, st);
-        else if (sel == 2) rc = launch_planes<2, false, 6, false, true>(grid, a, st);
-        else if (norm != nullptr) rc = launch_planes<0, false, 6, true, true>(grid, a, st);
-        else if (mode3) rc = launch_planes<0, false, 3, false, true>(grid, a, st);
-        else rc = launch_planes<0, false, 6, false, true>(grid, a, st);
+        if (sel == 1) rc = launch_planes<1, false, 6, false, true>(grid, a, st, e0, e1);
+        else if (sel == 2) rc = launch_planes<2, false, 6, false, true>(grid, a, st, e0, e1);
+        else if (norm != nullptr) rc = launch_planes<0, false, 6, true, true>(grid, a, st, e0, e1);
+        else if (mode3) rc = launch_planes<0, false, 3, false, true>(grid, a, st, e0, e1);
+        else rc = launch_planes<0, false, 6, false, true>(grid, a, st, e0, e1);
     } else {
-        if (sel == 4) rc = launch_planes<4, false, 6, false, false>(grid, a, st);
-        else if (sel == 8) rc = launch_planes<8, false, 6, false, false>(grid, a, st);
-        else if (sel == 12) rc = launch_planes<12, false, 6, false, false>(grid, a, st);
-        else if (sel == 1) rc = launch_planes<1, false, 6, false, false>(grid, a, st);
-        else if (sel == 2) rc = launch_planes<2, false, 6, false, false>(grid, a, st);
-        else if (norm != nullptr) rc = launch_planes<0, false, 6, true, false>(grid, a, st);
-        else if (mode3) rc = launch_planes<0, false, 3, false, false>(grid, a, st);
-        else rc = launch_planes<0, false, 6, false, false>(grid, a, st);
+        if (sel == 4) rc = launch_planes<4, false, 6, false, false>(grid, a, st, e0, e1);
+        else if (sel == 8) rc = launch_planes<8, false, 6, false, false>(grid, a, st, e0, e1);
+        else if (sel == 12) rc = launch_planes<12, false, 6, false, false>(grid, a, st, e0, e1);
+        else if (sel == 1) rc = launch_planes<1, false, 6, false, false>(grid, a, st, e0, e1);
+        else if (sel == 2) rc = launch_planes<2, false, 6, false, false>(grid, a, st, e0, e1);
+        else if (norm != nullptr) rc = launch_planes<0, false, 6, true, false>(grid, a, st, e0, e1);
+        else if (mode3) rc = launch_planes<0, false, 3, false, false>(grid, a, st, e0, e1);
+        else rc = launch_planes<0, false, 6, false, false>(grid, a, st, e0, e1);
     }
     if (rc != CPC_OK) return rc;
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");

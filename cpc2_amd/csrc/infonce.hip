@@ -12,6 +12,7 @@
 // column k of that tile -- computed by the same MFMA chain as the negatives, so a negative that happens
 // to be the positive frame ties EXACTLY, as in the reference) followed by the Nneg gathered negatives.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "coop.h"
 #include "ldsdma.h"
 #include "rowcfg.h"
@@ -1178,9 +1179,11 @@ static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *
     }
     int status = CPC_OK;
     {
-        ProfScope prof(PROF_NCE_FWD, st);
         static const bool no_dma = getenv("CPC_NCE_NO_DMA") != nullptr;           // A/B switch: the register-gather kernel
-        if (!no_dma && (l.Henc == 256 || l.Henc == 512) && a.stamps == nullptr && l.Nneg % 8 == 0 && l.Nneg <= 256 && a.perm != nullptr) {
+        const bool dma = !no_dma && (l.Henc == 256 || l.Henc == 512) && a.stamps == nullptr && l.Nneg % 8 == 0 && l.Nneg <= 256 && a.perm != nullptr;
+        ProfScope prof(PROF_NCE_FWD, st, dma);      // (the stream kernel takes the timing events with its own dispatch: common.h)
+        const hipEvent_t e0 = prof.start(), e1 = prof.stop();
+        if (dma) {
             // persistent waves, two per SIMD: 8 workgroups of one wave per CU (LDS: two 8.25 KiB slots + two index lists each)
             const size_t lds = 2 * NCE_SLOT + 2 * NCE_LIST;
             static int n_cus = 0;
@@ -1193,10 +1196,12 @@ static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *
             const unsigned grid = (unsigned)std::min(n_bt, 8 * n_cus);
             if (l.Henc == 256) {
                 status = allow_lds(infonce_fwd_dma_kernel<256>, lds);
-                if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_dma_kernel<256>, dim3(grid), dim3(64), lds, st, a, n_bt);
+                if (status == CPC_OK && e0 != nullptr) hipExtLaunchKernelGGL(infonce_fwd_dma_kernel<256>, dim3(grid), dim3(64), lds, st, e0, e1, 0, a, n_bt);
+                else if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_dma_kernel<256>, dim3(grid), dim3(64), lds, st, a, n_bt);
             } else {
                 status = allow_lds(infonce_fwd_dma_kernel<512>, lds);
-                if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_dma_kernel<512>, dim3(grid), dim3(64), lds, st, a, n_bt);
+                if (status == CPC_OK && e0 != nullptr) hipExtLaunchKernelGGL(infonce_fwd_dma_kernel<512>, dim3(grid), dim3(64), lds, st, e0, e1, 0, a, n_bt);
+                else if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_dma_kernel<512>, dim3(grid), dim3(64), lds, st, a, n_bt);
             }
         } else {
             NCE_DISPATCH(l.Henc, {

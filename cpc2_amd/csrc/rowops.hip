@@ -32,18 +32,18 @@ static std::vector<ProfRec> g_prof;
 static const char *kProfNames[PROF_SLOTS] = {"gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd",
                                              "conv0_fwd", "conv0_bwd", "gemm_planes_nt", "gemm_planes_tn"};
 
-ProfScope::ProfScope(int slot, hipStream_t st) : slot_(slot), st_(st), active_(false)
+ProfScope::ProfScope(int slot, hipStream_t st, bool attached) : attached_(attached), slot_(slot), st_(st), active_(false)
 {
     const int on = g_prof_on.load(std::memory_order_relaxed);
     if (on == 0 || (on == 2 && slot != PROF_PLANES_NT) || (on == 3 && slot != PROF_GEMM_NT)) return;
     if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) return;
-    active_ = hipEventRecord(a_, st_) == hipSuccess;
+    active_ = attached_ ? true : hipEventRecord(a_, st_) == hipSuccess;
 }
 
 ProfScope::~ProfScope()
 {
     if (!active_) return;
-    (void)hipEventRecord(b_, st_);
+    if (!attached_) (void)hipEventRecord(b_, st_);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back({slot_, a_, b_});
 }
