@@ -607,25 +607,36 @@ template <int H> __device__ __forceinline__ void tile_flush(const char *tile, co
 }
 
 // conv0 + norm + relu -> Y0 as planes.  One block per 64 consecutive rows of Y0 (halo and slack rows included: zeros).
-template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv0Args a, PlaneOut o)
+// (n_groups groups of 64 rows, walked by gridDim.x persistent blocks: the 52 parameter registers of a lane are loaded once per block
+//  instead of once per 64 rows, and the samples of the next group are requested before the current one is computed)
+template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv0Args a, PlaneOut o, long n_groups)
 {
     using Cfg = RowCfg<H>;
     constexpr int G = Cfg::G, VPL = Cfg::VPL;
     static_assert(Cfg::RPW == 1, "plane producers: one row per wave pass");
     __shared__ float xs[64 * C0_K];
     __shared__ __attribute__((aligned(16))) char tile[PlaneTile<H>::BYTES];
-    const long G0 = (long)blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane;
 
-    for (int i = threadIdx.x; i < 64 * C0_K; i += 256) {
-        const int slot = i / C0_K, j = i - slot * C0_K;
-        const long row = G0 + slot;
-        const long n = row / a.R0;
-        const int t = (int)(row - n * a.R0) - a.halo;
-        const int pos = C0_S * t - C0_P + j;
-        xs[i] = (n < a.N && t >= 0 && t < a.L1 && pos >= 0 && pos < a.L0) ? a.x[n * a.L0 + pos] : 0.f;
-    }
+    // three samples per thread and group (64 rows x 10 taps = 640 = 2.5 x 256), requested together
+    auto fetch = [&](long grp, float (&v)[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int i = threadIdx.x + 256 * q;
+            v[q] = 0.f;
+            if (i < 64 * C0_K && grp < n_groups) {
+                const int slot = i / C0_K, j = i - slot * C0_K;
+                const long row = grp * 64 + slot;
+                const long n = row / a.R0;
+                const int t = (int)(row - n * a.R0) - a.halo;
+                const int pos = C0_S * t - C0_P + j;
+                if (n < a.N && t >= 0 && t < a.L1 && pos >= 0 && pos < a.L0) v[q] = a.x[n * a.L0 + pos];
+            }
+        }
+    };
+    float xnext[3];
+    fetch(blockIdx.x, xnext);
     float wreg[VPL][4][C0_K], breg[VPL][4], gam[VPL][4], bet[VPL][4];
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
@@ -638,7 +649,13 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
             gam[v][e] = a.gamma[c];
             bet[v][e] = a.beta[c];
         }
+    for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const long G0 = grp * 64;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (threadIdx.x + 256 * q < 64 * C0_K) xs[threadIdx.x + 256 * q] = xnext[q];
     __syncthreads();
+    fetch(grp + gridDim.x, xnext);               // (in flight under this group's arithmetic)
     for (int sub = 0; sub < 4; ++sub) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
@@ -687,6 +704,7 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
         __syncthreads();
         tile_flush<H>(tile, o, G0 + sub * 16);
         __syncthreads();
+    }
     }
 }
 
@@ -1150,7 +1168,10 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
         ProfScope prof(PROF_CONV0_FWD, st);
         const PlaneOut o{e.Yp[0], e.Yplane[0], log2i(kConv[1].s), e.Yrts[0]};
         const long rows = (long)kConv[1].s * e.Yrts[0];               // every row of the planes is written (halo, slack: zeros)
-        CPC_DISPATCH_HP(H, hipLaunchKernelGGL(conv0_fwd_pl_kernel<HH>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, c0, o));
+        // (4096 persistent blocks: 187 -> 176 us at CPC-small against one block per group; 1024 / 2048: 179-180)
+        const long groups = rows / 64;
+        const unsigned blocks = (unsigned)std::min<long>(groups, 4096);
+        CPC_DISPATCH_HP(H, hipLaunchKernelGGL(conv0_fwd_pl_kernel<HH>, dim3(blocks), dim3(256), 0, st, c0, o, groups));
     } else {
         ProfScope prof(PROF_CONV0_FWD, st);
         CPC_DISPATCH_H(H, hipLaunchKernelGGL(conv0_fwd_kernel<HH>, dim3(c0.n_tiles), dim3(256), 0, st, c0));
