@@ -1027,6 +1027,7 @@ struct GruLayout {
     size_t saved_bytes;
     // scratch
     float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn, *tn2;
+    float *dgi_l[8], *dgh_l[8];            // layers 1..: gate gradients of their own (deferred tail: the side stream still reads them)
     size_t tn2_bytes;
     float4 *wpack;
     unsigned long long *comm;
@@ -1069,6 +1070,11 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     // (the input-gradient product's K split when the weight-gradient products run beside it on the side stream: gru_backward, defer_tail)
     g.tn2_bytes = gemm_nt_scratch_bytes((long)N * T, dmax, 3 * H);
     g.tn2 = sc.take<float>(g.tn2_bytes / sizeof(float));
+    g.dgi_l[0] = g.dgi; g.dgh_l[0] = g.dgh;
+    for (int l = 1; l < layers; ++l) {
+        g.dgi_l[l] = sc.take<float>((size_t)N * T * 3 * H);
+        g.dgh_l[l] = sc.take<float>((size_t)N * (T + 1) * 3 * H);
+    }
     g.scratch_bytes = sc.used();
     return CPC_OK;
 }
@@ -1135,9 +1141,10 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
     return CPC_OK;
 }
 
-// defer_tail: the weight gradients of the last layer handled (layer 0: nothing on `st` needs them before the optimiser) are produced
-// on the library's side stream, beside what the caller enqueues next (the encoder's backward: its normalisation / reduction kernels
-// leave the matrix pipe idle for ~0.3 ms per step); cpc_side_tail_join makes a stream wait for them
+// defer_tail: the weight gradients of every layer (nothing on `st` needs them before the optimiser) are produced on the library's
+// side stream: layer l's beside the recurrent kernel of layer l - 1 (latency-bound: the matrix pipe is idle), layer 0's beside what
+// the caller enqueues next (the encoder's backward: its normalisation / reduction kernels leave the matrix pipe idle for ~0.3 ms per
+// step).  Each layer keeps its gate gradients in a buffer of its own for that.  cpc_side_tail_join makes a stream wait for them
 static int gru_backward(const float *x, const float *const *prm, const float *dout, void *saved, void *scratch, float *dx,
                         float *const *grads, int N, int T, int Din, int H, int layers, hipStream_t st, bool defer_tail = false)
 {
@@ -1153,7 +1160,9 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         GruArgs a{};
         a.wpack = g.wpack; a.hall = g.hall[l]; a.gates = g.gates[l]; a.hn = g.hn[l];
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq; a.whh = w_hh;
-        a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
+        // (deferred tail: every layer's gate gradients stay where they are until the side stream has used them)
+        float *const dgi = defer_tail ? g.dgi_l[l] : g.dgi, *const dgh = defer_tail ? g.dgh_l[l] : g.dgh;
+        a.dout = dcur; a.dgi = dgi; a.dgh = dgh;
         CPC_TRY(infonce_deferred_mark(st));       // (see infonce_deferred_start below)
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
         static const int n_cus = coop_cu_count();
@@ -1192,14 +1201,14 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         CPC_TRY(infonce_deferred_start(st));      // (no-op unless a deferred criterion backward is waiting to run beside this)
 
         hipStream_t wst = st;
-        const bool tail = defer_tail && l == 0;
+        const bool tail = defer_tail;
         if (tail) CPC_TRY(side_tail_begin(st, &wst));
         // dW_hh[g][k] = sum_{n,t} dGH[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)
-        CPC_TRY(gemm_tn(g.dgh, 3L * H, g.hall[l], H, grads[4 * l + 1], H, 3 * H, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, wst));
-        CPC_TRY(colsum_rows(g.dgh, 3L * H, (long)N * (T + 1), 3 * H, grads[4 * l + 3], g.cs, wst));
+        CPC_TRY(gemm_tn(dgh, 3L * H, g.hall[l], H, grads[4 * l + 1], H, 3 * H, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(dgh, 3L * H, (long)N * (T + 1), 3 * H, grads[4 * l + 3], g.cs, wst));
         // dW_ih[g][k] = sum dGI[n,t][g] * x[n,t][k]
-        CPC_TRY(gemm_tn(g.dgi, 3L * H, xin, din, grads[4 * l], din, 3 * H, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, wst));
-        CPC_TRY(colsum_rows(g.dgi, 3L * H, (long)N * T, 3 * H, grads[4 * l + 2], g.cs, wst));
+        CPC_TRY(gemm_tn(dgi, 3L * H, xin, din, grads[4 * l], din, 3 * H, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(dgi, 3L * H, (long)N * T, 3 * H, grads[4 * l + 2], g.cs, wst));
         if (tail) CPC_TRY(side_tail_end());
         // dX = dGI . W_ih
         float *dxl = (l == 0) ? dx : ((l % 2) ? g.dxa : g.dxb);
@@ -1208,7 +1217,7 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
             RowMap none{};
             if (tail) { none.splitk_scratch = g.tn2; none.splitk_bytes = g.tn2_bytes; }        // (g.tn is the side stream's now)
             else { none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes; }
-            CPC_TRY(gemm_nt(g.dgi, 3L * H, g.wt, 3L * H, dxl, din, nullptr, (long)N * T, din, 3 * H, none, st));
+            CPC_TRY(gemm_nt(dgi, 3L * H, g.wt, 3L * H, dxl, din, nullptr, (long)N * T, din, 3 * H, none, st));
         }
         dcur = dxl;
     }

@@ -554,6 +554,7 @@ struct LstmLayout {
     size_t saved_bytes;
     // scratch
     float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn, *tn2;
+    float *dgi_l[8], *dgh_l[8];            // layers 1..: gate gradients of their own (deferred tail: the side stream still reads them)
     size_t tn2_bytes;
     float4 *wpack;
     gu64_t *comm;
@@ -595,6 +596,11 @@ int lstm_layout(LstmLayout &g, int G, int N, int T, int Din, int H, int layers, 
     g.tn = sc.take<float>(g.tn_bytes / sizeof(float));
     g.tn2_bytes = gemm_nt_scratch_bytes((long)N * T, dmax, G * H);      // (the input-gradient product's K split beside a deferred tail)
     g.tn2 = sc.take<float>(g.tn2_bytes / sizeof(float));
+    g.dgi_l[0] = g.dgi; g.dgh_l[0] = g.dgh;
+    for (int l = 1; l < layers; ++l) {
+        g.dgi_l[l] = sc.take<float>((size_t)N * T * G * H);
+        g.dgh_l[l] = sc.take<float>((size_t)N * (T + 1) * G * H);
+    }
     g.scratch_bytes = sc.used();
     return CPC_OK;
 }
@@ -686,7 +692,9 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         LstmArgs a{};
         a.wpack = g.wpack; a.whh = w_hh; a.hall = g.hall[l]; a.call = g.call[l]; a.gates = g.gates[l];
         a.N = N; a.T = T; a.H = H; a.hp = hp; a.kq = kq;
-        a.dout = dcur; a.dgi = g.dgi; a.dgh = g.dgh;
+        // (deferred tail: every layer's gate gradients stay where they are until the side stream has used them)
+        float *const dgi = defer_tail ? g.dgi_l[l] : g.dgi, *const dgh = defer_tail ? g.dgh_l[l] : g.dgh;
+        a.dout = dcur; a.dgi = dgi; a.dgh = dgh;
         CPC_TRY(infonce_deferred_mark(st));       // (see infonce_deferred_start below)
         int members = 0;
         int nb = lstm_coop_windows(G, H, N, &members);
@@ -715,14 +723,14 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         const int GH = G * H;
         // (defer_tail: layer 0's weight gradients on the library's side stream, as in gru_backward)
         hipStream_t wst = st;
-        const bool tail = defer_tail && l == 0;
+        const bool tail = defer_tail;
         if (tail) CPC_TRY(side_tail_begin(st, &wst));
         // dW_hh[g][k] = sum_{n,t} dG[n,t][g] * h_{t-1}[n][k]   (hall row t is h_{t-1}; row T of dGH is zero)
-        CPC_TRY(gemm_tn(g.dgh, GH, g.hall[l], H, grads[4 * l + 1], H, GH, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, wst));
-        CPC_TRY(colsum_rows(g.dgh, GH, (long)N * (T + 1), GH, grads[4 * l + 3], g.cs, wst));
+        CPC_TRY(gemm_tn(dgh, GH, g.hall[l], H, grads[4 * l + 1], H, GH, H, (long)N * (T + 1), g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(dgh, GH, (long)N * (T + 1), GH, grads[4 * l + 3], g.cs, wst));
         // dW_ih[g][k] = sum dG[n,t][g] * x[n,t][k]
-        CPC_TRY(gemm_tn(g.dgi, GH, xin, din, grads[4 * l], din, GH, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, wst));
-        CPC_TRY(colsum_rows(g.dgi, GH, (long)N * T, GH, grads[4 * l + 2], g.cs, wst));
+        CPC_TRY(gemm_tn(dgi, GH, xin, din, grads[4 * l], din, GH, din, (long)N * T, g.tn, g.tn_bytes, 0, 0, wst));
+        CPC_TRY(colsum_rows(dgi, GH, (long)N * T, GH, grads[4 * l + 2], g.cs, wst));
         if (tail) CPC_TRY(side_tail_end());
         // dX = dG . W_ih
         float *dxl = (l == 0) ? dx : ((l % 2) ? g.dxa : g.dxb);
@@ -731,7 +739,7 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
             RowMap none{};
             if (tail) { none.splitk_scratch = g.tn2; none.splitk_bytes = g.tn2_bytes; }        // (g.tn is the side stream's now)
             else { none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes; }
-            CPC_TRY(gemm_nt(g.dgi, GH, g.wt, GH, dxl, din, nullptr, (long)N * T, din, GH, none, st));
+            CPC_TRY(gemm_nt(dgi, GH, g.wt, GH, dxl, din, nullptr, (long)N * T, din, GH, none, st));
         }
         dcur = dxl;
     }

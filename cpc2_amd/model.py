@@ -223,11 +223,11 @@ class _GruFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
         kind = ctx.kind
-        # The deferred form (cpc2_hip.h, cpc_gru_backward_deferred): layer 0's weight gradients finish on a stream of the library's
+        # The deferred form (cpc2_hip.h, cpc_gru_backward_deferred): every layer's weight gradients finish on a stream of the library's
         # while the encoder's backward runs.  Only inside the caller's scope (CPCAR.deferred_weight_gradients: nothing reads these
         # gradients before the backward pass has ended) and only when every one of them is written IN PLACE into the flat gradient
         # buffer -- a private buffer would be added to .grad by autograd the moment this function returns.
-        defer = ctx.defer_tail and _all_in_place(ctx.param_refs[:4], grads[:4])
+        defer = ctx.defer_tail and _all_in_place(ctx.param_refs, grads)
         nscratch = getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers)
         if defer:
             sc = scratch(nscratch, x.device, tag="gru_tail")      # a buffer of its own: the side stream outlives this call
@@ -286,7 +286,7 @@ class _LstmFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
         nscratch = lib.cpc_lstm_scratch_bytes(n, t, dim_in, hidden, n_layers)
-        if ctx.defer_tail and _all_in_place(ctx.param_refs[:4], grads[:4]):        # (the deferred form: see _GruFn.backward)
+        if ctx.defer_tail and _all_in_place(ctx.param_refs, grads):                # (the deferred form: see _GruFn.backward)
             sc = scratch(nscratch, x.device, tag="lstm_tail")
             check(lib.cpc_lstm_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
                                                  n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "lstm_backward_deferred")
@@ -323,7 +323,7 @@ class CPCAR(nn.Module):
         return _TailScope(self)
 
     def _may_defer(self):
-        return _no_hooks(self._param_list()[:4])
+        return _no_hooks(self._param_list())
 
     def _param_list(self):
         out = []

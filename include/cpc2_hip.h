@@ -186,10 +186,10 @@ int cpc_gru_forward(const float *x, const float *const *params, const float *h0,
 int cpc_gru_backward(const float *x, const float *const *params, const float *dout, void *saved,
                      void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
                      int hidden, int layers, cpc_stream_t stream);
-/* Deferred form of the same backward: on return `dx` and the gradients of layers 1.. are ordered on `stream`; the gradients of
- * layer 0 (weight_ih_l0, weight_hh_l0 and the two biases: two weight-gradient products and two column sums that nothing in a
- * backward pass needs before the optimiser) are produced on a stream of the library's, beside what the caller enqueues on `stream`
- * next, and NOTHING may read them (nor reuse x, saved, scratch, dout) until cpc_side_tail_join(stream') has been called for the
+/* Deferred form of the same backward: on return `dx` is ordered on `stream`; the parameter gradients of every layer (weight_ih,
+ * weight_hh and the two biases: two weight-gradient products and two column sums per layer that nothing in a backward pass needs
+ * before the optimiser) are produced on a stream of the library's, beside the next layer's recurrent kernel and what the caller
+ * enqueues on `stream` next, and NOTHING may read them (nor reuse x, saved, scratch, dout) until cpc_side_tail_join(stream') has been called for the
  * stream' that will -- it makes stream' wait for them (a no-op when nothing is pending; one such tail per device).  For callers
  * that write gradients in place and read them only at the end of the backward pass (cpc2_amd: FlatAdam's flat buffer). */
 int cpc_gru_backward_deferred(const float *x, const float *const *params, const float *dout, void *saved,
