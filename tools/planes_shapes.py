@@ -64,7 +64,10 @@ def row(name, r, layer, st=None):
     g = [int(r[f"Grid_Size_{a}"]) // int(r[f"Workgroup_Size_{a}"]) for a in "XYZ"]
     tnk, norm, pair = kind(r)
     form = ("TN" if tnk else "NT") + (" pair" if pair else "") + (" + norm epilogue" if norm else "")
-    extra = f" {st[3]} | {int(st[1]) / 1e3:.0f} k | {st[4]} / {st[5]} |" if st else " | | |"
+    if st and float(st[3]) > 3.0:            # a K-split launch: the stamps are per workgroup, not per tile
+        extra = f" (K split: stamps not per tile) | | {st[4]} / {st[5]} |"
+    else:
+        extra = f" {st[3]} | {int(st[1]) / 1e3:.0f} k | {st[4]} / {st[5]} |" if st else " | | |"
     return f"| {name} | {form} | {g[0]}x{g[1]}x{g[2]} | {flops[layer] / 1e9:.1f} | {us:.1f} | {tf:.0f} | {tf / PEAK:.3f} |" + extra
 
 
