@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one optimisation step of the reference's trainStep (train.py:95-113) on one batch of
-synthetic windows already resident in HBM: model on cat([past, future]) (reference semantics: 2b
-windows through encoder + GRU), InfoNCE criterion, backward, gradient all-reduce (N > 1), fused Adam.
+synthetic windows already resident in HBM: encoder on cat([past, future]) (2b windows), the context
+network on the b windows whose context train.py:102 keeps (the other half's context is sliced away
+there and its gradient is identically zero: same outputs, gradients and update -- the reference's own
+2b-window dataflow is measured beside it as `small_strict`), InfoNCE criterion, backward, gradient
+all-reduce (N > 1), fused Adam.
 Workload at every N: BASELINE.json configs[1] per GPU -- CPC-small (hiddenEncoder = hiddenGar = 256,
 GRU x1, nPredicts = 12, 128 negatives, linear predictors), 64 windows of 20480 samples per GPU
 (weak scaling; N = 8 is configs[2]).  Prints ONE JSON line on rank 0.
@@ -51,6 +54,9 @@ CONFIGS = {
     # the same window twice, so the two halves of train.py:99's 2b-window batch are identical; SURVEY 8d allows the one-pass
     # step as a labelled extra).  Bit-identical losses and parameter updates at about half the encoder work.
     "small_dedup": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", dedup=True),
+    # the reference's own dataflow: CPCModel.forward on all 2b windows (the context network also on the b windows whose context
+    # train.py:102 drops) -- what the headline was measured on up to round 4; identical results (tests/test_gpu_parity.py)
+    "small_strict": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", strict=True),
 }
 GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
@@ -77,6 +83,11 @@ def planes_nt_algorithmic_flops(b, cfg, dedup=False):
     return flops, launches
 
 
+def ar_windows(b, cfg, dedup=False):
+    """Windows the context network runs on: b (cpcStep's default and dedup), 2b in the reference's own dataflow (strict)."""
+    return 2 * b if (cfg.get("strict") and not dedup) else b
+
+
 def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
     """Algorithmic FLOPs of what still runs on the split-in-kernel gemm_nt_x6_kernel (operands split while staged): the
     context network's input projection + its dX, the predictor GEMM + its dC (hidden sizes other than 256 / 512: also the
@@ -89,6 +100,7 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
         flops, launches = flops + f, launches + l
     t_len = lens[5]
     din = h
+    n = ar_windows(b, cfg, dedup)                       # (the context network's share: encoder 2 passes, context network 1)
     for _layer in range(cfg["layers"]):
         if cfg["ar"] == "transformer":                # QKV(3) + Wo + lin1 + lin2 + last_linear, and their 5 dX GEMMs
             flops += 2 * (2.0 * n * t_len * (5 * h * h + 2 * h * 2048))
@@ -247,6 +259,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     from cpc2_amd.train import DataParallelContext, backward, cpcStep
     model, crit, opt = build(cfg, device)
     dedup = bool(args.dedup or cfg.get("dedup"))
+    strict = bool(cfg.get("strict"))
     # N > 1: the criterion / context-network gradient slices are all-reduced under the encoder's backward (train.py)
     dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()),
                              overlap=not os.environ.get("CPC_BENCH_NO_OVERLAP"), timing=True)
@@ -257,7 +270,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     label = torch.zeros(args.batch, dtype=torch.long, device=device)
 
     def step():
-        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup, dp=dp)
+        tot, losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup, dp=dp, strict=strict)
         backward(tot)                                       # (train.py:109; cpc2_amd.train.backward seeds it with a cached 1.0)
         dp.reduce_and_step()
         opt.zero_grad()
@@ -339,7 +352,10 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                                f"{cfg['npred']}, {cfg['nneg']} negatives, {('multi-head ' if cfg.get('multihead') else '') + cfg.get('rnn', 'linear')} predictors), {args.batch} x 1.28 s "
                                f"windows per GPU, " + ("past==future deduplicated (encoder+AR on b windows), "
                                                          if dedup else
-                                                         "reference trainStep semantics (encoder+AR on 2b windows), ")
+                                                         "reference trainStep dataflow (encoder+AR on 2b windows), " if strict else
+                                                         "reference trainStep semantics: encoder on the 2b windows of cat([past, future]), "
+                                                         "context network on the b context windows (train.py:102 drops the other "
+                                                         "half's context; identical outputs, gradients and update), ")
                                + "fwd+bwd+allreduce+Adam",
                    "windows_per_gpu": args.batch, "global_batch": world * args.batch,
                    "parallelism": f"dp{world}", "final_losses": final_loss,
@@ -507,7 +523,9 @@ def main():
         out["comm"] = comm
     also = args.also
     if also is None:
-        also = "large,transformer,small_3term,small_dedup" if (world == 1 and args.config == "small" and not args.no_prof) else ""
+        # (N > 1: the line still carries BASELINE configs[4] -- CPC-large is DEFINED as the 8-GPU data-parallel config)
+        also = ("large,transformer,small_strict,small_3term,small_dedup" if world == 1 else "large") \
+            if (args.config == "small" and not args.no_prof) else ""
     others = []
     for name in [n for n in also.split(",") if n]:
         rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)

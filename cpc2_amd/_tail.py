@@ -27,10 +27,17 @@ def join_tail(device):
 
 def _keep_for_tail(device, tensors):
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    first = idx not in _tail
     _tail.setdefault(idx, []).append(tensors)
-    if first:
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_tail(device))
+    # one callback per deferred call (join_tail is idempotent): an entry left behind by a backward pass that raised must not keep
+    # the next pass from queueing its own
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: join_tail(device))
+
+
+def _tail_tag(name, device):
+    """Scratch tag of a deferred backward call: distinct for every call that is pending on the device at the same time (the side
+    stream still reads the earlier calls' buffers until the join empties the list)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (name, len(_tail.get(idx, ())))
 
 
 def _all_in_place(params, grads):
@@ -64,3 +71,42 @@ class _TailScope:
         return False
 
 
+
+
+# --------------------------------------------------------------------------- gradients with a fixed home
+# Buffers for gradients whose layout is fixed by the caller (criterion.py: the zero halves of train.py:102-103's slices; cpcStep's
+# split of the encoder output into context windows and target windows): allocated and zeroed once per (shape, device, slot), the
+# producers write their part in place and the consumer hands the whole buffer on.  A buffer is reused only after the backward pass
+# that read it has been enqueued on the same stream; the slot carries every number the "stays zero" / "who writes what" invariant
+# depends on (window counts), so two users with the same full shape but different splits never share one.
+_grad_cache = {}
+
+
+def _cached_grad_buffer(shape, device, slot):
+    key = (tuple(shape), str(device), slot)
+    buf = _grad_cache.get(key)
+    if buf is None:
+        if len(_grad_cache) > 8:
+            _grad_cache.clear()
+        buf = _grad_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return buf
+
+
+def grad_home(t):
+    """(full_shape, slot, start) a tensor was marked with by split_windows (criterion.py), if it can be honoured: the gradient with
+    respect to `t` should be written into windows start.. of that cached buffer -- the consumer then takes it without a copy."""
+    home = getattr(t, "_cpc_grad_home", None)
+    if home is None or not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        return None
+    full_shape, _slot, start = home
+    if tuple(t.shape[1:]) != tuple(full_shape[1:]) or start + t.shape[0] > full_shape[0]:
+        return None
+    return home
+
+
+def grad_home_view(home, like):
+    """The piece of its home buffer a gradient shaped like `like` is written into (None: no home, allocate)."""
+    if home is None:
+        return torch.empty_like(like)
+    full_shape, slot, start = home
+    return _cached_grad_buffer(full_shape, like.device, slot)[start:start + like.shape[0]]

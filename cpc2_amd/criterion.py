@@ -222,17 +222,7 @@ def carry_join(view, parent, start):
 # (device, shape, slot): the criterion's backward writes dc / dz straight into the other half and hands the whole buffer on.
 # Nothing ever writes the zero half (autograd only reads gradients it does not own: this cache holds a reference), and a buffer is
 # reused only after the backward pass that read it has been enqueued on the same stream.
-_grad_cache = {}
-
-
-def _cached_grad_buffer(shape, device, slot):
-    key = (tuple(shape), str(device), slot)
-    buf = _grad_cache.get(key)
-    if buf is None:
-        if len(_grad_cache) > 8:
-            _grad_cache.clear()
-        buf = _grad_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
-    return buf
+from ._tail import _cached_grad_buffer, grad_home, grad_home_view  # noqa: E402
 
 
 class _FirstWindows(torch.autograd.Function):
@@ -247,7 +237,7 @@ class _FirstWindows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        buf = _cached_grad_buffer(ctx.full_shape, g.device, "context")
+        buf = _cached_grad_buffer(ctx.full_shape, g.device, ("context", ctx.n))
         if not (g.data_ptr() == buf.data_ptr() and g.is_contiguous() and g.dtype == torch.float32):
             buf[:ctx.n].copy_(g)
         return buf, None
@@ -259,8 +249,49 @@ def first_windows(x, n):
     if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.is_contiguous() and x.dtype == torch.float32):
         return x[:n]
     out = _FirstWindows.apply(x, n)
-    out._cpc_first_of = tuple(x.shape)
+    out._cpc_first_of = (tuple(x.shape), n)
     return out
+
+
+class _SplitWindows(torch.autograd.Function):
+    """(x[:n], x[n:]) along the window axis whose backward neither fills nor adds: both gradients are written by their producers
+    straight into the two parts of ONE cached buffer (grad_home), which is handed on whole.  The deferred criterion backward is
+    joined here -- autograd runs this node when BOTH gradients are due, i.e. after the context network's backward."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.full_shape, ctx.n = tuple(x.shape), n
+        ctx.set_materialize_grads(False)
+        first, rest = x[:n], x[n:]
+        return first.view_as(first), rest.view_as(rest)
+
+    @staticmethod
+    def backward(ctx, g_first, g_rest):
+        n = ctx.n
+        device = (g_first if g_first is not None else g_rest).device
+        join_deferred(device)
+        buf = _cached_grad_buffer(ctx.full_shape, device, ("split", n))
+        row = buf.stride(0) * buf.element_size()
+        for g, part, at in ((g_first, buf[:n], 0), (g_rest, buf[n:], n)):
+            if g is None:
+                part.zero_()
+            elif not (g.data_ptr() == buf.data_ptr() + at * row and g.is_contiguous() and g.dtype == torch.float32):
+                part.copy_(g)
+        return buf, None
+
+
+def split_windows(x, n):
+    """cpcStep's split of the encoder output [2b, T, H] into the context network's windows x[:n] and the criterion's target windows
+    x[n:] (train.py:99-103 keeps exactly these: the context of the first half, the encoded data of the second).  Each part is marked
+    with its home in the gradient buffer (`_cpc_grad_home`, honoured by the recurrent / transformer / criterion backward) and the
+    second with `_cpc_join`: whoever consumes the gradient of `x` sits behind the join of a deferred criterion backward."""
+    if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.is_contiguous() and x.dtype == torch.float32):
+        return x[:n], x[n:]
+    first, rest = _SplitWindows.apply(x, n)
+    first._cpc_grad_home = (tuple(x.shape), ("split", n), 0)
+    rest._cpc_grad_home = (tuple(x.shape), ("split", n), n)
+    rest._cpc_join = True
+    return first, rest
 
 
 class _DeferScope:
@@ -288,6 +319,7 @@ class _InfoNCEFn(torch.autograd.Function):
         ctx.c_first_of = getattr(c, "_cpc_first_of", None) if (c.is_contiguous() and c.dtype == torch.float32) else None
         c = f32c(c)
         ctx.z_full_shape = None
+        ctx.z_home = grad_home(z)              # (split_windows: dz is written where the split's backward looks for it)
         if defer is not None:
             ctx.z_full_shape, ctx.z_start = tuple(z.shape), defer[0]
             z = z[defer[0]:defer[0] + defer[1]]
@@ -326,16 +358,16 @@ class _InfoNCEFn(torch.autograd.Function):
         b, t, k, dim_ar, dim_enc, n_neg = ctx.dims
         dlosses = f32c(dlosses)
         if ctx.c_first_of is not None:       # (first_windows: dc goes where the slice's backward looks for it, the rest stays zero)
-            dc = _cached_grad_buffer(ctx.c_first_of, c.device, "context")[:c.shape[0]]
+            dc = _cached_grad_buffer(ctx.c_first_of[0], c.device, ("context", ctx.c_first_of[1]))[:c.shape[0]]
         else:
             dc = torch.empty_like(c)
         defer = ctx.z_full_shape is not None
         if defer and ctx.z_full_shape != tuple(z.shape):
             # (windows outside start .. start + n get no gradient from the criterion: zero once, see _cached_grad_buffer)
-            dz_out = _cached_grad_buffer(ctx.z_full_shape, z.device, ("targets", ctx.z_start))
+            dz_out = _cached_grad_buffer(ctx.z_full_shape, z.device, ("targets", ctx.z_start, z.shape[0]))
             dz = dz_out[ctx.z_start:ctx.z_start + z.shape[0]]
         else:
-            dz_out = dz = torch.empty_like(z)
+            dz_out = dz = grad_home_view(ctx.z_home, z)
         gw = grad_buffers(ctx.param_refs)
         dw = _packed_view(gw)                 # contiguous in the flat gradient buffer -> written in place
         direct = dw is not None

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import check, f32c, grad_buffers, ptr, ptr_array, require_gpu, scratch, stream_ptr
-from ._tail import _TailScope, _all_in_place, _keep_for_tail, _no_hooks, _tail, join_tail  # noqa: F401
+from ._tail import _TailScope, _all_in_place, _keep_for_tail, _no_hooks, _tail, _tail_tag, grad_home, grad_home_view, join_tail  # noqa: F401
 
 
 # --------------------------------------------------------------------------- ChannelNorm
@@ -122,7 +122,7 @@ class _EncoderFn(torch.autograd.Function):
         # the deferred form (cpc2_hip.h): inside the caller's scope (CPCEncoder.deferred_weight_gradients) and with every gradient
         # of conv1-4 written in place into the flat gradient buffer
         if ctx.defer_tail and _all_in_place(ctx.param_refs[4:], grads[4:]):
-            sc = scratch(nscratch, x.device, tag="enc_tail")      # a buffer of its own: the side stream outlives this call
+            sc = scratch(nscratch, x.device, tag=_tail_tag("enc_tail", x.device))      # a buffer of its own: the side stream outlives this call
             check(lib.cpc_encoder_backward_deferred(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
                                                     n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward_deferred")
             _keep_for_tail(x.device, (x, saved, params, dz, sc))  # (not `grads`: see _GruFn.backward)
@@ -187,6 +187,7 @@ class _GruFn(torch.autograd.Function):
     def forward(ctx, x, h0, n_layers, want_hidden, kind, defer_tail, *params):
         require_gpu(x, *params)
         lib = _lib.load()
+        ctx.dx_home = grad_home(x)             # (cpcStep's split_windows: dx has a fixed place in the encoder output's gradient)
         x = f32c(x)
         ctx.param_refs = params
         ctx.kind = kind
@@ -220,7 +221,7 @@ class _GruFn(torch.autograd.Function):
         n, t, dim_in, hidden, n_layers = ctx.dims
         dout = f32c(dout)
         need_dx = ctx.needs_input_grad[0]
-        dx = torch.empty_like(x) if need_dx else None
+        dx = grad_home_view(ctx.dx_home, x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
         kind = ctx.kind
         # The deferred form (cpc2_hip.h, cpc_gru_backward_deferred): every layer's weight gradients finish on a stream of the library's
@@ -230,7 +231,7 @@ class _GruFn(torch.autograd.Function):
         defer = ctx.defer_tail and _all_in_place(ctx.param_refs, grads)
         nscratch = getattr(lib, f"cpc_{kind}_scratch_bytes")(n, t, dim_in, hidden, n_layers)
         if defer:
-            sc = scratch(nscratch, x.device, tag="gru_tail")      # a buffer of its own: the side stream outlives this call
+            sc = scratch(nscratch, x.device, tag=_tail_tag("gru_tail", x.device))      # a buffer of its own: the side stream outlives this call
             check(lib.cpc_gru_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
                                                 n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "gru_backward_deferred")
             # alive until the join.  NOT `grads`: autograd adopts a returned gradient as .grad only while nobody else holds it -- with a
@@ -249,6 +250,7 @@ class _LstmFn(torch.autograd.Function):
     def forward(ctx, x, h0, c0, n_layers, want_hidden, defer_tail, *params):
         require_gpu(x, *params)
         lib = _lib.load()
+        ctx.dx_home = grad_home(x)
         x = f32c(x)
         ctx.param_refs = params
         ctx.defer_tail = bool(defer_tail)
@@ -283,11 +285,11 @@ class _LstmFn(torch.autograd.Function):
         n, t, dim_in, hidden, n_layers = ctx.dims
         dout = f32c(dout)
         need_dx = ctx.needs_input_grad[0]
-        dx = torch.empty_like(x) if need_dx else None
+        dx = grad_home_view(ctx.dx_home, x) if need_dx else None
         grads = grad_buffers(ctx.param_refs)
         nscratch = lib.cpc_lstm_scratch_bytes(n, t, dim_in, hidden, n_layers)
         if ctx.defer_tail and _all_in_place(ctx.param_refs, grads):                # (the deferred form: see _GruFn.backward)
-            sc = scratch(nscratch, x.device, tag="lstm_tail")
+            sc = scratch(nscratch, x.device, tag=_tail_tag("lstm_tail", x.device))
             check(lib.cpc_lstm_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx), ptr_array(grads),
                                                  n, t, dim_in, hidden, n_layers, stream_ptr(x.device)), "lstm_backward_deferred")
             _keep_for_tail(x.device, (x, saved, params, dout, sc))

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join, first_windows
+from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join, first_windows, split_windows
 from .model import CPCAR, CPCEncoder, CPCModel, join_tail
 
 
@@ -386,9 +386,36 @@ class DataParallelContext:
 
 
 # --------------------------------------------------------------------------- the step
-def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False, dp=None):
+def _context_windows_only(cpcModel):
+    """May cpcStep run the context network on the b context windows alone?  train.py:99-103 keeps `c_feature[:b]` and
+    `encoded_data[b:]` of the model's 2b-window outputs: the context of the future half is sliced away, its gradient is identically
+    zero and so are its terms in every parameter gradient.  Every context network of this package is per window (no statistics
+    across windows), so running it on the first b windows gives the same c_feature[:b], the same gradients and the same update.
+    Only for the bare CPCModel (a wrapper's forward() is the plug-in boundary and stays the 2b-window call), without span masking
+    (its numpy draws cover all 2b rows) and without a state carried across calls (keepHidden stores the hidden state of all
+    2b windows)."""
+    import os
+    from .model import BiDIRAR, BiDIRARTangled, NoAr
+    from .transformers import StaticPositionEmbedding, TransformerLayer
+    if os.environ.get("CPC_STRICT_2B") or type(cpcModel) is not CPCModel or cpcModel.mask_prob > 0.0:
+        return False
+    if not hasattr(cpcModel.gEncoder, "forward_channel_last"):
+        return False
+    ar = cpcModel.gAR
+    if isinstance(ar, CPCAR):
+        return not ar.keepHidden and ar.hidden is None
+    if isinstance(ar, (NoAr, BiDIRAR, BiDIRARTangled)):
+        return True
+    return isinstance(ar, torch.nn.Sequential) and all(isinstance(m, (StaticPositionEmbedding, TransformerLayer)) for m in ar)
+
+
+def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False, dp=None, strict=False):
     """train.py:95-108: model on cat([past, future]); context from the past half, targets from the
     future half; returns (totLoss, allLosses [1,K], allAcc [1,K]).
+
+    Default: the encoder runs on the 2b windows, the context network on the b windows whose context the reference keeps
+    (_context_windows_only: identical outputs, gradients and updates).  strict=True: the reference's own dataflow, the
+    context network on all 2b windows through CPCModel.forward.
 
     dedup=True: when `future` IS `past` (no augmentation: dataset.py:308-321 yields the same window twice) the
     two halves of the reference's 2b-window batch are identical and every op up to the criterion is per
@@ -403,6 +430,16 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
             allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
         return sum_losses(allLosses), allLosses, allAcc
     combined = torch.cat([past, future], dim=0)
+    if not strict and _context_windows_only(cpcModel):
+        with _ar_scope(cpcModel):
+            encoded_full = cpcModel.gEncoder.forward_channel_last(combined)          # [2b, T, H]
+            context_in, encoded_data = split_windows(encoded_full, b)
+            c_feature = cpcModel.gAR(context_in)                                      # [b, T, H]: train.py:102's c_feature[:b]
+        if dp is not None:
+            dp.attach(encoded_full)
+        with _defer_scope(cpcCriterion, encoded_data):
+            allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
+        return sum_losses(allLosses), allLosses, allAcc
     # (train.py:100,105 concatenate the labels too and take the first half back: CPCModel hands `label` through untouched, so the
     #  round trip -- two small kernels per step -- is skipped for it; any other model gets the reference's tensors)
     passthrough = isinstance(getattr(cpcModel, "module", cpcModel), CPCModel)

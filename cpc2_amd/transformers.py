@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import check, f32c, grad_buffers, ptr, ptr_array, require_gpu, scratch, stream_ptr
-from ._tail import _TailScope, _all_in_place, _keep_for_tail, _no_hooks
+from ._tail import _TailScope, _all_in_place, _keep_for_tail, _no_hooks, _tail_tag, grad_home, grad_home_view
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -72,6 +72,7 @@ class _TransformerFn(torch.autograd.Function):
     def forward(ctx, x, size_seq, n_layers, n_classifiers, dropout_p, seed, defer_tail, *params):
         require_gpu(x, *[p for p in params if p is not None])
         lib = _lib.load()
+        ctx.dx_home = grad_home(x)             # (cpcStep's split_windows)
         x = f32c(x)
         ctx.param_refs = params
         ctx.defer_tail = bool(defer_tail) and n_classifiers == 1
@@ -100,7 +101,7 @@ class _TransformerFn(torch.autograd.Function):
         x, saved, *params = ctx.saved_tensors
         n, s, d_model, d_out, size_seq, n_layers, n_classifiers, dropout_p, seed = ctx.cfg
         dout = f32c(dout)
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = grad_home_view(ctx.dx_home, x) if ctx.needs_input_grad[0] else None
         grads = grad_buffers(ctx.param_refs)
         nscratch = lib.cpc_transformer_scratch_bytes(n, s, d_model, d_out, size_seq, n_layers, n_classifiers)
         per = lib.cpc_transformer_param_count()
@@ -108,7 +109,9 @@ class _TransformerFn(torch.autograd.Function):
         # the deferred form (cpc2_hip.h): inside the caller's scope (TransformerLayer.deferred_weight_gradients) and with every
         # gradient of layer 0 written in place into the flat gradient buffer (model.py, _GruFn.backward)
         if ctx.defer_tail and _all_in_place([p for p, _g in l0], [g for _p, g in l0]):
-            sc = scratch(nscratch, x.device, tag="tr_tail")      # a buffer of its own: the side stream outlives this call
+            # a buffer of its own, and one PER PENDING CALL: the side stream reads it after this call has returned, and a second
+            # TransformerLayer of the same context network (nLevelsGRU >= 2) runs its backward before the join
+            sc = scratch(nscratch, x.device, tag=_tail_tag("tr_tail", x.device))
             check(lib.cpc_transformer_backward_deferred(ptr(x), ptr_array(params), ptr(dout), ptr(saved), ptr(sc), ptr(dx),
                                                         ptr_array(grads), n, s, d_model, d_out, size_seq, n_layers, n_classifiers,
                                                         dropout_p, seed, stream_ptr(x.device)), "transformer_backward_deferred")

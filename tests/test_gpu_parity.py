@@ -1651,14 +1651,16 @@ def test_training_steps_are_reproducible_bit_for_bit():
         assert torch.equal(finals[0], finals[1]), f"hidden {hidden}: parameters differ between two identical runs"
 
 
-@pytest.mark.parametrize("dedup", [False, True])
-def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch, dedup):
+@pytest.mark.parametrize("form", ["context", "strict", "dedup"])
+def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch, form):
     """cpc_infonce_backward_deferred + cpc_infonce_join (dz and the predictor weight gradients on the library's side stream,
     beside the recurrent backward; joined where autograd sums the encoder output's gradient) runs the SAME kernels as the
-    immediate form: every gradient and the parameters after two steps are equal bit for bit, with the reference's 2b-window
-    batch (the criterion then differentiates with respect to the full encoder output, rows b.. only) and with dedup."""
+    immediate form: every gradient and the parameters after two steps are equal bit for bit -- with cpcStep's default (context
+    network on the b context windows: the criterion differentiates with respect to the target half of split_windows), with the
+    reference's own 2b-window dataflow (strict: with respect to the full encoder output, rows b.. only) and with dedup."""
     from cpc2_amd import criterion as crit_mod
     hidden, b = 256, 6
+    dedup, strict = form == "dedup", form == "strict"
     results = []
     for defer in (True, False):
         if defer:
@@ -1685,7 +1687,7 @@ def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch
         monkeypatch.setattr(crit_mod._InfoNCEFn, "apply", staticmethod(spy))
         grads = []
         for _ in range(2):
-            tot, _losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup)
+            tot, _losses, _acc = cpcStep(x, x, label, model, crit, dedup=dedup, strict=strict)
             tot.backward()
             assert not crit_mod._deferred, "a deferred backward is still pending after the backward pass"
             grads.append(opt.flat_grad.detach().clone())
@@ -1694,11 +1696,95 @@ def test_deferred_criterion_backward_gives_the_same_step_bit_for_bit(monkeypatch
         monkeypatch.setattr(crit_mod._InfoNCEFn, "apply", real)
         assert all((d is not None) == defer for d in seen), seen
         if defer:
-            assert seen[0] == ((0, b) if dedup else (b, b))
+            assert seen[0] == ((b, b) if strict else (0, b))
         results.append((grads, opt.flat.detach().clone()))
     for step in range(2):
         assert torch.equal(results[0][0][step], results[1][0][step]), f"step {step}: gradients differ between the two forms"
     assert torch.equal(results[0][1], results[1][1])
+
+
+def _step_model(hidden, layers, mode, nneg, seed=3):
+    torch.manual_seed(seed)
+    if mode == "transformer":
+        from cpc2_amd.transformers import buildTransformerAR
+        ar = buildTransformerAR(hidden, hidden, layers, 128, False)
+    else:
+        ar = cpc2_amd.CPCAR(hidden, hidden, False, layers, mode=mode)
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), ar).to(DEV)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, nneg, rnnMode="linear", sizeInputSeq=128).to(DEV)
+    return model, crit
+
+
+@pytest.mark.parametrize("name,hidden,layers,mode,b,nneg", [("gru", 256, 1, "GRU", 6, 32), ("gru_x2_512", 512, 2, "GRU", 5, 64),
+                                                          ("lstm", 256, 1, "LSTM", 6, 32), ("transformer", 256, 1, "transformer", 4, 32),
+                                                          ("transformer_x2", 256, 2, "transformer", 3, 32), ("gru_64", 64, 1, "GRU", 3, 16),
+                                                          ("rnn", 256, 1, "RNN", 4, 32), ("gru_many", 256, 1, "GRU", 40, 32)])
+def test_context_network_on_the_context_windows_only_is_the_reference_step(name, hidden, layers, mode, b, nneg):
+    """train.py:99-103 keeps c_feature[:b] and encoded_data[b:] of the model's 2b-window outputs.  cpcStep's default form runs the
+    context network on the b context windows only; `strict=True` is the reference's own dataflow (CPCModel.forward on all 2b
+    windows).  With past != future, three Adam steps (transformer: dropout 0.1 on, the masks are keyed by element position):
+    losses, every gradient and the parameters agree -- bit for bit where the row count does not change a K split or a
+    summation order, else to rounding (2e-6 of scale; parameters within 2 % of the distance Adam moved them)."""
+    lr, steps = 2e-4, 3
+    res = {}
+    for form in ("context", "strict"):
+        model, crit = _step_model(hidden, layers, mode, nneg)
+        opt = buildOptimizer(model, crit, lr=lr)
+        crit.seed(5)
+        torch.manual_seed(11)                                   # (the transformer's dropout stream)
+        past = synth.audio_windows(b, 20480, 24).to(DEV)
+        future = synth.audio_windows(b, 20480, 25).to(DEV)
+        label = torch.zeros(b, dtype=torch.long, device=DEV)
+        init = opt.flat.detach().clone()
+        losses, grads = [], []
+        for _ in range(steps):
+            tot, ls, _acc = cpcStep(past, future, label, model, crit, strict=form == "strict")
+            tot.backward()
+            losses.append(ls.detach().clone())
+            grads.append(opt.flat_grad.detach().clone())
+            opt.step()
+            opt.zero_grad()
+        _lib.check(_lib.load().cpc_async_error_check(_lib.stream_ptr(torch.device(DEV))), "async error check")
+        res[form] = (torch.cat(losses), grads, opt.flat.detach().clone(), init, opt)
+    got, ref = res["context"], res["strict"]
+    assert torch.isfinite(got[0]).all() and torch.isfinite(got[2]).all()
+    exact = torch.equal(got[0], ref[0]) and all(torch.equal(a, c) for a, c in zip(got[1], ref[1])) and torch.equal(got[2], ref[2])
+    print(f"{name}: context-windows-only vs strict 2b form: {'bit-identical' if exact else 'equal to rounding'}")
+    assert_close(got[0][:12], ref[0][:12], 2e-6, "losses, step 0")
+    assert_close(got[0], ref[0], 2e-5, "losses")
+    opt = got[4]
+    for step in range(steps):
+        for prm, off in zip(opt.params, opt.offsets):            # per parameter tensor: each against its own scale
+            n = prm.numel()
+            # (after an Adam step the two runs' parameters differ by rounding-sized gradients' worth, and a ReLU decision that flips
+            #  with them moves a gradient by ~1e-3 of its scale: section 2 of DESIGN.md; step 0 is the sharp comparison)
+            assert_close(got[1][step][off:off + n], ref[1][step][off:off + n], 4e-6 if step == 0 else 5e-3,
+                         f"step {step}: gradient at flat offset {off} ({tuple(prm.shape)})")
+    moved = (ref[2] - ref[3]).abs()
+    assert float(moved.max()) > 0.5 * lr * steps
+    diff = (got[2] - ref[2]).abs()
+    assert float(diff.max()) <= 0.25 * lr * steps, f"a parameter ended {float(diff.max()):.2e} away"
+    assert float(diff.mean()) <= 0.02 * float(moved.mean()), f"mean parameter distance {float(diff.mean()):.2e} vs moved {float(moved.mean()):.2e}"
+
+
+def test_context_windows_only_form_is_refused_where_it_would_change_the_observable():
+    """The reduced dataflow is cpcStep's own and only for the bare CPCModel without state across calls: span masking (numpy draws
+    over all 2b rows), keepHidden (the stored state covers 2b windows) and any wrapper keep the reference's 2b-window call."""
+    from cpc2_amd.train import _context_windows_only
+    hidden = 64
+    enc = cpc2_amd.CPCEncoder(hidden)
+    assert _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1)))
+    assert _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 2, mode="LSTM")))
+    assert not _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, True, 1)))
+    assert not _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1), mask_prob=0.05))
+    assert not _context_windows_only(torch.nn.DataParallel(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1))))
+    # and with keepHidden the two forms are used as the reference would: the state of all 2b windows is carried
+    model = cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, True, 1)).to(DEV)
+    crit = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 16, rnnMode="linear", sizeInputSeq=128).to(DEV)
+    x = synth.audio_windows(2, 20480, 24).to(DEV)
+    with torch.no_grad():
+        cpcStep(x, x, torch.zeros(2, dtype=torch.long, device=DEV), model, crit)
+    assert model.gAR.hidden.shape == (1, 4, hidden)
 
 
 _DEFER_LAYERS_SCRIPT = """
@@ -1820,7 +1906,7 @@ def test_criterion_backward_is_deferred_only_inside_the_callers_scope(monkeypatc
         opt._gather_stray_grads()
         return opt.flat_grad.detach().clone()
     seen, g_deferred = _spied_criterion_calls(monkeypatch, step)
-    assert seen == [(2, 2)], seen
+    assert seen == [(0, 2)], seen            # (the target half of split_windows: windows 0.. of the tensor the criterion is given)
     touched = []
     handle = crit.wPrediction.predictors[3].weight.register_hook(lambda g: touched.append(float(g.abs().sum())))
     seen, g_hooked = _spied_criterion_calls(monkeypatch, step)
@@ -1866,8 +1952,8 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
             opt.zero_grad()
             del calls[:]
             del enc_calls[:]
-            if how == "step":
-                tot, _l, _a = cpcStep(x, x, label, model, crit)
+            if how == "step":                              # (strict: the same 2b-window dataflow as the direct calls below)
+                tot, _l, _a = cpcStep(x, x, label, model, crit, strict=True)
             elif how == "direct":                          # the reference's own sequence of calls: no scope
                 c, z, _ = model(torch.cat([x, x]), label)
                 losses, _a = crit(c[:b], z[b:], label)
@@ -1896,16 +1982,20 @@ def test_recurrent_weight_gradients_are_deferred_only_inside_the_callers_scope(m
         monkeypatch.setattr(lib, "cpc_encoder_backward_deferred", real_enc)
 
 
-def test_transformer_parameter_gradients_are_deferred_inside_the_callers_scope(monkeypatch):
+@pytest.mark.parametrize("n_layers", [1, 2, 3])
+def test_transformer_parameter_gradients_are_deferred_inside_the_callers_scope(monkeypatch, n_layers):
     """cpc_transformer_backward_deferred (arMode='transformer': the layer's seven weight-gradient products, bias sums and column sums
     on the library's side stream): cpcStep on the bare model defers, the model called directly does not, every gradient of the step
-    is the same bit for bit -- in training mode (dropout on, same seed) and with the criterion's own deferred backward beside it."""
+    is the same bit for bit -- in training mode (dropout on, same seed) and with the criterion's own deferred backward beside it.
+    nLevelsGRU >= 2 (round-4 advisor finding): every TransformerLayer of the nn.Sequential defers on its own, the side stream
+    still reads layer l's buffers while layer l - 1 runs its backward: each pending call has a scratch buffer of its own."""
     from cpc2_amd import model as model_mod
     from cpc2_amd.transformers import buildTransformerAR
     hidden, b = 256, 2
     mp = synth.encoder_params(hidden, 51)
-    mp.update(synth.transformer_params(hidden, hidden, 128, 52))
-    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), buildTransformerAR(hidden, hidden, 1, 128, False))
+    for layer in range(n_layers):
+        mp.update(synth.transformer_params(hidden, hidden, 128, 52 + 10 * layer, prefix=f"gAR.{layer}."))
+    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), buildTransformerAR(hidden, hidden, n_layers, 128, False))
     sd = dict(mp)
     sd.update({kk: v for kk, v in model.state_dict().items() if kk.endswith(".z") or kk.endswith(".mask")})
     model.load_state_dict(sd)
@@ -1930,7 +2020,7 @@ def test_transformer_parameter_gradients_are_deferred_inside_the_callers_scope(m
         opt.zero_grad()
         del calls[:]
         if how == "step":
-            tot, _l, _a = cpcStep(x, x, label, model, crit)
+            tot, _l, _a = cpcStep(x, x, label, model, crit, strict=True)      # (the same 2b-window dataflow as the direct call)
         else:
             c, z, _ = model(torch.cat([x, x]), label)
             losses, _a = crit(c[:b], z[b:], label)
@@ -1940,11 +2030,12 @@ def test_transformer_parameter_gradients_are_deferred_inside_the_callers_scope(m
         opt._gather_stray_grads()
         torch.cuda.synchronize()
         return opt.flat_grad.detach().clone(), len(calls)
-    g_step, n_step = grads("step")
-    g_direct, n_direct = grads("direct")
+    for _rep in range(2):                                  # (twice: the second pass finds every buffer in place)
+        g_step, n_step = grads("step")
+        g_direct, n_direct = grads("direct")
+        assert (n_step, n_direct) == (n_layers, 0)
+        assert torch.equal(g_step, g_direct) and float(g_step.abs().max()) > 0
     monkeypatch.setattr(lib, "cpc_transformer_backward_deferred", real)
-    assert (n_step, n_direct) == (1, 0)
-    assert torch.equal(g_step, g_direct) and float(g_step.abs().max()) > 0
 
 
 def test_seeded_backward_of_the_summed_losses_is_the_plain_one():
