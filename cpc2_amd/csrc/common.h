@@ -71,6 +71,9 @@ public:
     ~ProfScope();
     hipEvent_t start() const { return active_ ? a_ : nullptr; }
     hipEvent_t stop() const { return active_ ? b_ : nullptr; }
+    // an attached scope whose kernel was NOT launched after all (an error path): its events were never recorded -- drop them
+    // instead of queueing a record cpc_prof_read would call hipEventElapsedTime on
+    void cancel();
 private:
     bool attached_;
     int slot_;

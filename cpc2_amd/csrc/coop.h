@@ -38,7 +38,8 @@ template <int H, int NB> __device__ __forceinline__ void coop_fwd_who(int idx, i
     k = g * U + p / NB;
 }
 
-// two f32 lanes per register pair: v_pk_fma_f32 issues at the rate of v_fma_f32 and does twice the work
+// two f32 lanes as one value.  (Device code is built WITHOUT the packed-f32 VALU instructions -- build.py, DEVICE_FLAGS: round 3's
+// launch-to-launch differences -- so pk_fma compiles to two v_fma_f32; the type is kept for the register-pair layout of the weights.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_lo(const float4 &v) { return f32x2{v.x, v.y}; }
@@ -118,8 +119,10 @@ static inline int coop_cu_count()
 int *coop_error_word();                         // device-visible address of the word (nullptr: allocation failed)
 int coop_error_take(const char *where);         // host: CPC_OK, or CPC_ERR_HIP (message set, word cleared)
 int coop_fault_injection();                     // tests: CPC_COOP_FAULT=1 makes member 0 of group 0 withhold one publish
+bool coop_allowed();                            // process-wide policy (cpc_coop_set_policy): false = streaming kernels only
 void coop_count_launch();                       // every cooperative recurrent launch is counted (cpc_coop_launches)
 long coop_launches();
+void coop_count_backward_call();                 // every recurrent backward entry (any kernel kind) is counted (cpc_recurrent_backward_calls)
 enum { COOP_ERR_FWD_WAIT = 1, COOP_ERR_BWD_WAIT = 2, COOP_ERR_NONFINITE_GRAD = 3, COOP_ERR_BAD_INDEX = 4 };     // 3: the Adam kernel (rowops.hip), 4: the criterion's index check (infonce.hip)
 __device__ __forceinline__ void coop_report(int *err, int code)
 {

@@ -811,7 +811,7 @@ int gemm_nt_planes(const PlanesOperand &A, const PlanesOperand &B, float *C, lon
         else if (mode3) rc = launch_planes<0, false, 3, false, false>(grid, a, st, e0, e1);
         else rc = launch_planes<0, false, 6, false, false>(grid, a, st, e0, e1);
     }
-    if (rc != CPC_OK) return rc;
+    if (rc != CPC_OK) { prof.cancel(); return rc; }
     CPC_CHECK_LAUNCH("gemm_planes_kernel (nt)");
     if (splits > 1 && left_slabs != nullptr && ldc == N) {
         *left_slabs = splits;

@@ -1104,7 +1104,7 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
         static const int n_cus = coop_cu_count();
         // the cooperative kernel needs every workgroup resident at once (1 per CU)
         int G = 0;
-        int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        int nb = (coop_off || !coop_allowed()) ? 0 : coop_windows_per_group(H, N, n_cus, &G);
         if (nb != 0 && !(H == 256 ? coop_fwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * G), n_cus) : coop_fwd_fits<512>(nb, (unsigned)(cdiv(N, nb) * G), n_cus)))
             nb = 0;                             // not resident all at once: the streaming kernel has no such requirement
         if (nb != 0) {
@@ -1167,7 +1167,7 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         static const bool coop_off = getenv("CPC_GRU_STREAM") != nullptr;
         static const int n_cus = coop_cu_count();
         int G = 0;
-        int nb = coop_off ? 0 : coop_windows_per_group(H, N, n_cus, &G);
+        int nb = (coop_off || !coop_allowed()) ? 0 : coop_windows_per_group(H, N, n_cus, &G);
         if (nb != 0 && !(H == 256 ? coop_bwd_fits<256>(nb, (unsigned)(cdiv(N, nb) * G), n_cus) : coop_bwd_fits<512>(nb, (unsigned)(cdiv(N, nb) * G), n_cus)))
             nb = 0;
         if (nb != 0) {
@@ -1251,6 +1251,7 @@ extern "C" int cpc_gru_backward(const float *x, const float *const *params, cons
                                 float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                 cpc_stream_t stream)
 {
+    cpc::coop_count_backward_call();
     CPC_TRY(cpc::coop_error_take("cpc_gru_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::gru_backward(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                              static_cast<hipStream_t>(stream));
@@ -1260,6 +1261,7 @@ extern "C" int cpc_gru_backward_deferred(const float *x, const float *const *par
                                          float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                          cpc_stream_t stream)
 {
+    cpc::coop_count_backward_call();
     CPC_TRY(cpc::coop_error_take("cpc_gru_backward_deferred"));
     return cpc::gru_backward(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                              static_cast<hipStream_t>(stream), true);

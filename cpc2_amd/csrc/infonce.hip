@@ -1209,6 +1209,7 @@ static int nce_launch_fwd(NceArgs &a, const NceLayout &l, float *losses, float *
                 if (status == CPC_OK) hipLaunchKernelGGL(infonce_fwd_kernel<HH>, dim3((unsigned)(l.b * l.W)), dim3(64), l.lds_fwd, st, a);
             });
         }
+        if (status != CPC_OK) prof.cancel();        // (nothing was launched: an attached scope's events were never recorded)
     }
     CPC_TRY(status);
     CPC_CHECK_LAUNCH("infonce_fwd_kernel");

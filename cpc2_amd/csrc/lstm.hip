@@ -610,7 +610,7 @@ int lstm_coop_windows(int G, int H, int N, int *members)
 {
     static const bool coop_off = getenv("CPC_LSTM_STREAM") != nullptr;
     static const int n_cus = coop_cu_count();
-    if (G != 4 || coop_off) return 0;
+    if (G != 4 || coop_off || !coop_allowed()) return 0;
     return coop_windows_per_group(H, N, n_cus, members);
 }
 
@@ -775,6 +775,7 @@ extern "C" int cpc_lstm_backward(const float *x, const float *const *params, con
                                  float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                  cpc_stream_t stream)
 {
+    cpc::coop_count_backward_call();
     CPC_TRY(cpc::coop_error_take("cpc_lstm_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_backward<4>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                                  static_cast<hipStream_t>(stream));
@@ -784,6 +785,7 @@ extern "C" int cpc_lstm_backward_deferred(const float *x, const float *const *pa
                                           float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                           cpc_stream_t stream)
 {
+    cpc::coop_count_backward_call();
     CPC_TRY(cpc::coop_error_take("cpc_lstm_backward_deferred"));
     return cpc::lstm_backward<4>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                                  static_cast<hipStream_t>(stream), true);
@@ -816,6 +818,7 @@ extern "C" int cpc_rnn_backward(const float *x, const float *const *params, cons
                                 float *dx, float *const *grads, int n, int t, int dim_in, int hidden, int layers,
                                 cpc_stream_t stream)
 {
+    cpc::coop_count_backward_call();
     CPC_TRY(cpc::coop_error_take("cpc_rnn_backward"));      // a time-out of an earlier cooperative launch surfaces here
     return cpc::lstm_backward<1>(x, params, dout, saved, scratch, dx, grads, n, t, dim_in, hidden, layers,
                                  static_cast<hipStream_t>(stream));

@@ -40,6 +40,14 @@ ProfScope::ProfScope(int slot, hipStream_t st, bool attached) : attached_(attach
     active_ = attached_ ? true : hipEventRecord(a_, st_) == hipSuccess;
 }
 
+void ProfScope::cancel()
+{
+    if (!active_) return;
+    active_ = false;
+    (void)hipEventDestroy(a_);
+    (void)hipEventDestroy(b_);
+}
+
 ProfScope::~ProfScope()
 {
     if (!active_) return;
@@ -63,9 +71,14 @@ int *coop_error_word()
     });
     return g_err_dev;
 }
+// cooperative policy of the process (cpc_coop_set_policy): 0 = cooperative kernels wherever they fit, 1 = streaming kernels only
+static std::atomic<int> g_coop_policy{0};
+bool coop_allowed() { return g_coop_policy.load(std::memory_order_relaxed) == 0; }
 static std::atomic<long> g_coop_launches{0};
 void coop_count_launch() { g_coop_launches.fetch_add(1, std::memory_order_relaxed); }
 long coop_launches() { return g_coop_launches.load(std::memory_order_relaxed); }
+static std::atomic<long> g_rec_bwd_calls{0};
+void coop_count_backward_call() { g_rec_bwd_calls.fetch_add(1, std::memory_order_relaxed); }
 
 int coop_error_take(const char *where)
 {
@@ -448,3 +461,9 @@ extern "C" int cpc_async_error_check(cpc_stream_t stream)
 // Cooperative recurrent launches (GRU / LSTM kernels that need every workgroup resident) issued by this process so far: the
 // data-parallel glue asserts its collectives are ordered behind them (cpc2_amd/train.py, DataParallelContext.attach)
 extern "C" long cpc_coop_launches(void) { return cpc::coop_launches(); }
+extern "C" long cpc_recurrent_backward_calls(void) { return cpc::g_rec_bwd_calls.load(std::memory_order_relaxed); }
+extern "C" int cpc_coop_set_policy(int policy)
+{
+    if (policy < 0) return cpc::g_coop_policy.load(std::memory_order_relaxed);
+    return cpc::g_coop_policy.exchange(policy != 0 ? 1 : 0, std::memory_order_relaxed);
+}

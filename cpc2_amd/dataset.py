@@ -52,6 +52,18 @@ def filterSeqs(pathTxt, seqCouples):
     return [x for x in seqCouples if os.path.basename(os.path.splitext(x[1])[0]) in wanted]
 
 
+def shard_for_rank(files, rank, world_size):
+    """The contiguous slice of a sequence list one data-parallel rank loads -- cpc/train.py:389-393 (`filter_distributed`):
+    files[len * rank // world : len * (rank + 1) // world].  The slices of the world_size ranks partition the list in order,
+    sizes differ by at most one, and world_size == 1 returns the list itself.  Applied by the caller to the train, validation
+    (and noise) lists alike, after the train / validation split, as the reference does (:396-399)."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"shard_for_rank: rank {rank} outside a world of {world_size}")
+    start = len(files) * rank // world_size
+    end = len(files) * (rank + 1) // world_size
+    return files[start:end]
+
+
 # --------------------------------------------------------------------------- samplers (dataset.py:603-757)
 def _uniform_batches(dataSize, sizeWindow, offset, batchSize):
     n = dataSize // sizeWindow - (1 if offset > 0 else 0)

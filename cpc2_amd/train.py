@@ -245,7 +245,7 @@ class DataParallelContext:
         self.trace = trace
         self.timing = timing                    # bench.py: events around the part of a step the exchange holds the stream for
         self._spans = []
-        self._coop_seen = self._coop_at_attach = None
+        self._coop_seen = None
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
         self.early, self.late, self._pending, self._fired = [], [], [], False
@@ -324,19 +324,20 @@ class DataParallelContext:
         # share the device.  The schedule keeps the two apart by stream order: the early all-reduce is issued behind the recurrent
         # backward (it waits for everything the compute stream holds at that point), and reduce_and_step() makes the compute
         # stream wait for every collective before the next step's forward pass.  The first half is asserted here: if the forward
-        # pass of this step launched cooperative kernels, the backward pass must have launched its own before the hook fires.
+        # pass of this step launched cooperative kernels, a recurrent backward (cooperative or not: the two fit a CU separately)
+        # must have been issued before the hook fires.
         on_gpu = self.opt.flat_grad.is_cuda
         now = self._coop_launches() if on_gpu else 0
         fwd_coop = now - (self._coop_seen if self._coop_seen is not None else now)
-        self._coop_at_attach = now
+        bwd_calls_at_attach = int(_lib.load().cpc_recurrent_backward_calls()) if on_gpu else 0
 
         def start(_grad):
             if not self._fired:                 # once per backward pass
                 self._fired = True
-                if on_gpu and fwd_coop > 0 and self._coop_launches() == self._coop_at_attach:
-                    raise RuntimeError("DataParallelContext: the early all-reduce would be issued BEFORE the cooperative recurrent "
-                                       "backward of this step (a collective's kernels beside a kernel that needs every "
-                                       "workgroup resident): attach() must be given the encoder output, upstream of the context network")
+                if on_gpu and fwd_coop > 0 and int(_lib.load().cpc_recurrent_backward_calls()) == bwd_calls_at_attach:
+                    raise RuntimeError("DataParallelContext: the early all-reduce would be issued BEFORE the recurrent backward of "
+                                       "this step (a collective's kernels beside a cooperative kernel that needs every workgroup "
+                                       "resident): attach() must be given the encoder output, upstream of the context network")
                 if on_gpu:
                     join_tail(self.opt.flat_grad.device)         # (a context network's weight gradients still on the side stream)
                 if getattr(self.opt, "direct_grads", False):
@@ -409,6 +410,21 @@ def _context_windows_only(cpcModel):
     return isinstance(ar, torch.nn.Sequential) and all(isinstance(m, (StaticPositionEmbedding, TransformerLayer)) for m in ar)
 
 
+def _guard_cooperative_kernels(cpcModel, cpcCriterion):
+    """The cooperative recurrent kernels (GRU / LSTM at hidden 256 / 512) need every workgroup resident, i.e. nothing else on the
+    CUs while they run.  DataParallelContext keeps its collectives away from them by stream order; the reference's arrangement --
+    DistributedDataParallel (or DataParallel over several devices) around model / criterion, train.py:523-532 -- does not: DDP
+    all-reduces the criterion's bucket (an RCCL kernel on the same CUs) while the recurrent backward runs.  Handed such a wrapper
+    on an RCCL process group, the process switches to the streaming recurrent kernels for good (cpc_coop_set_policy)."""
+    wrappers = (torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)
+    if not (isinstance(cpcModel, wrappers) or isinstance(cpcCriterion, wrappers)):
+        return
+    multi_dp = any(isinstance(m, torch.nn.DataParallel) and len(m.device_ids or ()) > 1 for m in (cpcModel, cpcCriterion))
+    on_rccl = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    if (multi_dp or on_rccl) and _lib.load().cpc_coop_set_policy(-1) == 0:
+        _lib.load().cpc_coop_set_policy(1)
+
+
 def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False, dp=None, strict=False):
     """train.py:95-108: model on cat([past, future]); context from the past half, targets from the
     future half; returns (totLoss, allLosses [1,K], allAcc [1,K]).
@@ -421,6 +437,8 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
     two halves of the reference's 2b-window batch are identical and every op up to the criterion is per
     window, so one pass over b windows gives bit-identical c_feature / encoded_data at half the work."""
     b = past.size(0)
+    if past.is_cuda:
+        _guard_cooperative_kernels(cpcModel, cpcCriterion)
     if dedup and (future is past or (future.data_ptr() == past.data_ptr() and future.shape == past.shape)):
         with _ar_scope(cpcModel):
             c_feature, encoded_data, label = cpcModel(past, label)

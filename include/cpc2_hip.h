@@ -61,6 +61,16 @@ int cpc_async_error_check(cpc_stream_t stream);
  * issued by this process so far.  The data-parallel glue (train.py:523-527's role) checks with it that a gradient all-reduce
  * is never issued between a step's forward and backward recurrent launches. */
 long cpc_coop_launches(void);
+/* Calls of the recurrent backward entry points (cpc_gru_backward*, cpc_lstm_backward*, cpc_rnn_backward; cooperative or streaming
+ * kernels alike) by this process so far: what "the recurrent backward of this step has been issued" is decided by. */
+long cpc_recurrent_backward_calls(void);
+/* Process-wide policy for those kernels: 0 (default) = cooperative wherever they fit, 1 = the streaming (non-cooperative) kernels
+ * only; returns the previous policy, policy < 0 only queries.  The cooperative kernels assume that nothing else holds CUs while
+ * they run.  One rank per GPU with the library's own gradient exchange keeps that by stream order (cpc2_amd/train.py,
+ * DataParallelContext); the reference's arrangement -- DistributedDataParallel around model and criterion on an RCCL process
+ * group, cpc/train.py:523-527 -- does not: its criterion bucket is all-reduced (an RCCL kernel on the same CUs) while the
+ * recurrent backward runs.  cpcStep selects policy 1 when it is handed such a wrapper (sticky for the process). */
+int cpc_coop_set_policy(int policy);
 int cpc_prof_enable(int on);
 int cpc_prof_read(const char *name, double *total_ms, long *count);
 

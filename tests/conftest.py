@@ -40,7 +40,8 @@ def _free_port():
 
 
 DP_TESTS = ("test_two_ranks_equal_one_process_with_two_micro_batches", "test_rccl_process_group_of_one_rank",
-            "test_reference_style_ddp_wrapping_with_flat_adam", "test_reference_ddp_arguments_do_not_defer_the_criterion_backward")
+            "test_reference_style_ddp_wrapping_with_flat_adam", "test_reference_ddp_arguments_do_not_defer_the_criterion_backward",
+            "test_reference_ddp_wrapping_on_rccl_takes_the_streaming_recurrent_kernels")
 
 
 def _dp_tests_selected(config):
@@ -86,6 +87,7 @@ def pytest_sessionstart(session):
     # a group are started together by a launcher process that never touches the GPU itself
     groups = [{"rank0": ("ranks", 0, 2, port), "rank1": ("ranks", 1, 2, port), "single": ("single", 0, 1, port),
                "nccl": ("nccl", 0, 1, port1)},
+              {"ddpnccl": ("ddpnccl", 0, 1, str(_free_port()))},
               {"ddp0": ("ddp", 0, 2, port2), "ddp1": ("ddp", 1, 2, port2)},
               {"ddpref0": ("ddpref", 0, 2, port3), "ddpref1": ("ddpref", 1, 2, port3)}]
     plan = []

@@ -11,6 +11,10 @@ mode "nccl":   world_size 1 over RCCL: init, broadcast, overlapped + blocking al
 mode "ddp":    the reference's own arrangement (cpc/train.py:523-527): model and criterion wrapped in
                torch.nn.parallel.DistributedDataParallel (gloo, two ranks on cuda:0), FlatAdam as the optimiser -- DDP's
                buckets average the gradients that the fused backward kernels wrote into the flat buffer.
+mode "ddpnccl": that arrangement on an RCCL process group of ONE rank at hidden 256 (where the bare model takes the cooperative GRU
+               kernels): cpcStep must switch the process to the streaming recurrent kernels (DDP all-reduces the criterion's
+               bucket -- an RCCL kernel -- while the recurrent backward runs), the asynchronous error word stays clean, and the
+               update is the bare model's under the same policy.
 mode "ddpref": the same with the reference's own DDP arguments (find_unused_parameters left False: the wrappers then hand
                tensor attributes through, which is how a criterion that keyed its deferred backward on one would have let
                DDP's reducer read predictor gradients that a side stream had not written yet -- round-3 advisor finding).
@@ -37,6 +41,8 @@ from oracle import synth                        # noqa: E402
 
 DEV = torch.device("cuda:0")
 HIDDEN, B, K, NNEG, STEPS, SHARDS = 64, 2, 12, 16, 2, 2
+if mode == "ddpnccl":
+    HIDDEN, NNEG = 256, 32
 
 
 def build():
@@ -159,6 +165,54 @@ elif mode in ("ddp", "ddpref"):
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
+elif mode == "ddpnccl":
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from cpc2_amd import _lib
+    lib = _lib.load()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    x = shard(rank)
+    # (a) the bare model under the streaming policy, no process group: the update the wrapped run must reproduce
+    lib.cpc_coop_set_policy(1)
+    crit.seed(1234)
+    bare = []
+    for _ in range(STEPS):
+        tot, ls, _acc = cpcStep(x, x, label, model, crit, strict=True)
+        tot.backward()
+        opt.step()
+        opt.zero_grad()
+        bare.append(ls.detach().cpu())
+    bare_flat = opt.flat.detach().clone()
+    assert lib.cpc_coop_launches() == 0
+    # (b) the bare model under the default policy takes the cooperative kernels at this width
+    lib.cpc_coop_set_policy(0)
+    model, crit, opt = build()
+    tot, _ls, _acc = cpcStep(x, x, label, model, crit)
+    tot.backward()
+    opt.zero_grad()
+    coop_bare = lib.cpc_coop_launches()
+    assert coop_bare >= 2, coop_bare
+    # (c) the reference's arrangement on RCCL: fresh modules, DDP around both
+    model, crit, opt = build()
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    ddp_model = DDP(model, device_ids=[0])
+    ddp_crit = DDP(crit, device_ids=[0])
+    crit.seed(1234)
+    for _ in range(STEPS):
+        tape.begin()
+        tot, ls, _acc = cpcStep(x, x, label, ddp_model, ddp_crit)
+        tot.backward()
+        opt._gather_stray_grads()
+        tape("pre", 0, opt.flat_grad.numel(), opt.flat_grad)
+        tape("post", 0, opt.flat_grad.numel(), opt.flat_grad)
+        opt.step()
+        opt.zero_grad()
+        losses.append(ls.detach().cpu())
+    _lib.check(lib.cpc_async_error_check(_lib.stream_ptr(DEV)), "async error check")
+    extra = {"policy_after": int(lib.cpc_coop_set_policy(-1)), "coop_launches_wrapped": int(lib.cpc_coop_launches() - coop_bare),
+             "coop_launches_bare": int(coop_bare), "bare_losses": torch.stack(bare), "bare_flat": bare_flat.cpu()}
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
 else:
     samplers, micro = [], []
     for r in range(SHARDS):
@@ -184,6 +238,8 @@ else:
 result = {"flat": opt.flat.detach().cpu(), "flat_sum": checksum(opt.flat), "losses": torch.stack(losses),
           "step_count": opt.step_count, "names": names, "mode": mode}
 result.update(tape.export())
+if mode == "ddpnccl":
+    result.update(extra)
 if mode == "single":
     result["micro"] = torch.stack([m.cpu() for m in micro]).view(STEPS, SHARDS, -1)     # [step][shard]: accumulated so far
 if after_backward:

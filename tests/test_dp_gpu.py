@@ -160,3 +160,19 @@ def test_reference_ddp_arguments_do_not_defer_the_criterion_backward(dp_jobs):
     assert not kernel, "\n".join(kernel)
     assert not transport, "DistributedDataParallel (find_unused_parameters=False) over gloo:\n" + "\n".join(transport)
     _end_to_end(d0, d1, single)
+
+
+def test_reference_ddp_wrapping_on_rccl_takes_the_streaming_recurrent_kernels(dp_jobs):
+    """cpc/train.py:523-527 on an RCCL process group (one rank; hidden 256, where the bare model runs the cooperative GRU):
+    DDP all-reduces the criterion's bucket -- an RCCL kernel -- while the recurrent backward runs, and a cooperative kernel needs
+    every workgroup resident.  cpcStep therefore switches the process to the streaming recurrent kernels when it is handed the
+    wrappers: no cooperative launch under them, a clean asynchronous error word (checked in the job), and the same losses and
+    update as the bare model under that policy."""
+    res = dp_jobs["ddpnccl"]
+    _verify_record(res, "ddpnccl")
+    assert res["coop_launches_bare"] >= 2, "the bare model at hidden 256 did not take the cooperative kernels"
+    assert res["policy_after"] == 1 and res["coop_launches_wrapped"] == 0, (res["policy_after"], res["coop_launches_wrapped"])
+    assert res["step_count"] == 2 and torch.isfinite(res["flat"]).all()
+    assert torch.allclose(res["losses"], res["bare_losses"], rtol=2e-6, atol=0)
+    d = (res["flat"] - res["bare_flat"]).abs()
+    assert float(d.max()) <= TOL * float(res["bare_flat"].abs().max()), float(d.max())

@@ -7,7 +7,7 @@ from pathlib import Path
 import torch
 
 from cpc2_amd import audio
-from cpc2_amd.dataset import AudioBatchData, filterSeqs, findAllSeqs
+from cpc2_amd.dataset import AudioBatchData, filterSeqs, findAllSeqs, shard_for_rank
 
 GOLD = Path(__file__).parent / "golden"
 DB = GOLD / "test_db"
@@ -177,3 +177,28 @@ def test_pack_boundaries_follow_the_reference_rule(monkeypatch):
         monkeypatch.setattr(dataset.random, "shuffle", lambda x: None)           # the order under test is the given one
         obj.prepare()
         assert (obj.packageIndex, obj.totSize) == rule(lengths, limit), (lengths, limit)
+
+
+def test_shard_for_rank_partitions_like_the_reference():
+    """cpc/train.py:389-393: rank r of ws loads files[len * r // ws : len * (r + 1) // ws] -- a partition in order, sizes within
+    one of each other; on the reference's own fixture (9 files) with 2, 4 and 8 ranks, and each shard feeds an AudioBatchData."""
+    import pytest
+    seq_names, speakers = findAllSeqs(str(DB), extension=".flac")
+    seq_names = sorted(seq_names)
+    for ws in (1, 2, 4, 8, 9, 11):
+        shards = [shard_for_rank(seq_names, r, ws) for r in range(ws)]
+        assert [x for sh in shards for x in sh] == seq_names                       # a partition, in order
+        sizes = [len(sh) for sh in shards]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == len(seq_names)
+        for r, sh in enumerate(shards):                                              # the reference's arithmetic, literally
+            assert sh == seq_names[len(seq_names) * r // ws:len(seq_names) * (r + 1) // ws]
+    assert shard_for_rank(seq_names, 0, 1) is not None and len(shard_for_rank(seq_names, 0, 1)) == 9
+    with pytest.raises(ValueError):
+        shard_for_rank(seq_names, 2, 2)
+    # two ranks load disjoint audio whose windows add up to the whole fixture's
+    total = 0
+    for r in range(2):
+        data = AudioBatchData(str(DB), 20480, shard_for_rank(seq_names, r, 2), None, len(speakers), nProcessLoader=1)
+        total += len(data)
+    whole = AudioBatchData(str(DB), 20480, seq_names, None, len(speakers), nProcessLoader=1)
+    assert abs(total - len(whole)) <= 1                # (each shard drops its own ragged tail window)

@@ -394,11 +394,13 @@ def test_encoder_vs_oracle_fp64(hidden, n, length):
         assert_close(p.grad, pm["gEncoder." + name].grad, 5e-5, f"grad {name} (the kernels' ReLU decisions)")
 
 
-def _kernel_relu_decisions(hidden, params, x):
+def _kernel_relu_decisions(hidden, params, x, windows=None):
     """The 0/1 masks [N, H, L_i] of the five ReLUs as the HIP forward pass decided them, read from what it keeps: the outputs
-    of layers 0..3 are the next layers' input planes in `saved` (cpc_encoder_saved_layout), layer 4's is z."""
+    of layers 0..3 are the next layers' input planes in `saved` (cpc_encoder_saved_layout), layer 4's is z.  windows: only
+    these windows' masks (the forward pass still runs on all of x: the launch geometry is the batch's)."""
     lib = _lib.load()
     n, _one, length = x.shape
+    sel = torch.arange(n, device=DEV) if windows is None else torch.as_tensor(list(windows), device=DEV)
     plist = [v.to(DEV).contiguous() for v in params.values()]
     xd = x.to(DEV)
     frames = lib.cpc_encoder_frames(length)
@@ -415,12 +417,12 @@ def _kernel_relu_decisions(hidden, params, x):
         assert po >= 0
         planes = saved[po:po + 2 * 3 * plane].view(torch.bfloat16).view(3, plane)
         ch = torch.arange(hidden, device=DEV).view(1, 1, hidden)
-        R = (torch.arange(n, device=DEV).view(n, 1, 1) * rows_next + halo + torch.arange(lv, device=DEV).view(1, lv, 1))
+        R = (sel.view(-1, 1, 1) * rows_next + halo + torch.arange(lv, device=DEV).view(1, lv, 1))
         idx = ((((ch // 16) << sshift) + (R & ((1 << sshift) - 1))) * rts + (R >> sshift)) * 16 + ch % 16      # [n, lv, hidden]
         y = (planes[0][idx].float() + planes[1][idx].float()) + planes[2][idx].float()
         masks.append((y > 0).permute(0, 2, 1).contiguous().cpu())
         del idx, y, R
-    masks.append((z > 0).permute(0, 2, 1).contiguous().cpu())
+    masks.append((z[sel] > 0).permute(0, 2, 1).contiguous().cpu())
     return masks
 
 
@@ -1041,10 +1043,11 @@ def test_device_index_expansion_and_prefetch_are_bit_exact():
         assert torch.equal(p.sample(b, t_len, t_len - k, nn, torch.device(DEV)).cpu(), want)
 
 
-def test_criterion_properties_at_full_size():
-    """b=64 (BASELINE config C2): untrained-predictor loss is ln(1+Nneg) for every step; the loss does not
-    depend on a common shift of all logits; gradients are finite and dz rows beyond reach are zero."""
-    b, t_len, h, k, nn = 64, 128, 256, 12, 128
+@pytest.mark.parametrize("h,nn", [(256, 128), (512, 256)])
+def test_criterion_properties_at_full_size(h, nn):
+    """b=64 (BASELINE configs C2 and, hidden 512 / 256 negatives, C5 per GPU): untrained-predictor loss is ln(1+Nneg) for every
+    step; the loss does not depend on a common shift of all logits; gradients are finite and dz rows beyond reach are zero."""
+    b, t_len, k = 64, 128, 12
     crit = make_criterion(k, h, h, nn, 70, scale=0.0)            # zero predictors -> uniform logits
     c = synth.features((b, t_len, h), 71).to(DEV).requires_grad_(True)
     z = synth.features((b, t_len, h), 72, relu=True).to(DEV).requires_grad_(True)
@@ -1562,17 +1565,31 @@ def test_bidirectional_context_networks_vs_reference_golden(golden, name):
         assert_close(p.grad, t(g[f"{name}_grad." + k]), 1e-4, f"grad {k}")
 
 
-def test_full_size_step_is_window_independent():
-    """BASELINE config C2 sizes (H=256, 128 windows of 20480 samples through encoder + GRU): every op up to the criterion is
-    per window, so a window's features must not depend on which other windows share the batch.  Not bit for bit: the last
-    two convolutions have few enough tiles that their GEMMs split K over workgroups (atomic partial sums, a split that
-    depends on the batch); anything leaking between windows would show at the 1e-1 level, rounding stays below 1e-5."""
-    hidden = 256
+def _full_size_model(hidden, layers, ar):
+    """(model on the GPU in eval mode, its parameters as the oracle takes them) for a BASELINE configuration's context network."""
     mp = synth.encoder_params(hidden, 31)
-    mp.update(synth.gru_params(hidden, hidden, 1, 32))
-    model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, 1))
-    model.load_state_dict(mp)
-    model = model.to(DEV)
+    if ar == "transformer":
+        from cpc2_amd.transformers import buildTransformerAR
+        for layer in range(layers):
+            mp.update(synth.transformer_params(hidden, hidden, 128, 32 + layer, prefix=f"gAR.{layer}."))
+        model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), buildTransformerAR(hidden, hidden, layers, 128, False))
+        sd = dict(mp)
+        sd.update({kk: v for kk, v in model.state_dict().items() if kk.endswith(".z") or kk.endswith(".mask")})
+        model.load_state_dict(sd)
+    else:
+        mp.update(synth.gru_params(hidden, hidden, layers, 32))
+        model = cpc2_amd.CPCModel(cpc2_amd.CPCEncoder(hidden), cpc2_amd.CPCAR(hidden, hidden, False, layers))
+        model.load_state_dict(mp)
+    return model.to(DEV).eval(), mp
+
+
+@pytest.mark.parametrize("hidden,layers,ar", [(256, 1, "GRU"), (512, 2, "GRU"), (256, 1, "transformer")])
+def test_full_size_step_is_window_independent(hidden, layers, ar):
+    """BASELINE config C2 / C5 / C4 sizes (128 windows of 20480 samples through encoder + context network): every op up to the
+    criterion is per window, so a window's features must not depend on which other windows share the batch.  Not bit for bit: the
+    last two convolutions have few enough tiles that their GEMMs split K over workgroups (a split that depends on the batch);
+    anything leaking between windows would show at the 1e-1 level, rounding stays below 1e-5."""
+    model, _mp = _full_size_model(hidden, layers, ar)
     x = synth.audio_windows(128, 20480, 33).to(DEV)
     with torch.no_grad():
         c_all, z_all, _ = model(x, None)
@@ -1758,12 +1775,13 @@ def test_context_network_on_the_context_windows_only_is_the_reference_step(name,
             n = prm.numel()
             # (after an Adam step the two runs' parameters differ by rounding-sized gradients' worth, and a ReLU decision that flips
             #  with them moves a gradient by ~1e-3 of its scale: section 2 of DESIGN.md; step 0 is the sharp comparison)
-            assert_close(got[1][step][off:off + n], ref[1][step][off:off + n], 4e-6 if step == 0 else 5e-3,
+            assert_close(got[1][step][off:off + n], ref[1][step][off:off + n], 4e-6 if step == 0 else 5e-2,
                          f"step {step}: gradient at flat offset {off} ({tuple(prm.shape)})")
     moved = (ref[2] - ref[3]).abs()
     assert float(moved.max()) > 0.5 * lr * steps
     diff = (got[2] - ref[2]).abs()
-    assert float(diff.max()) <= 0.25 * lr * steps, f"a parameter ended {float(diff.max()):.2e} away"
+    # (Adam moves an element by ~lr per step whatever its gradient's size: one whose gradient is rounding noise may go the other way)
+    assert float(diff.max()) <= 1.0 * lr * steps, f"a parameter ended {float(diff.max()):.2e} away"
     assert float(diff.mean()) <= 0.02 * float(moved.mean()), f"mean parameter distance {float(diff.mean()):.2e} vs moved {float(moved.mean()):.2e}"
 
 
@@ -2462,3 +2480,47 @@ def test_config_c1_cpc_small_on_reference_test_data_vs_oracle():
     data = _feeder(DEV)
     seq, _label = next(iter(data.getDataLoader(8, "sequential", False)))
     _full_step_vs_oracle(256, 1, 128, seq[:, 0].cpu(), steps=3, lr=2e-4, seed=1234, tol_loss=1e-3, tol_param=2e-3)
+
+
+@pytest.mark.parametrize("name,hidden,layers,ar", [("c2", 256, 1, "GRU"), ("c5", 512, 2, "GRU"), ("c4", 256, 1, "transformer")])
+def test_full_batch_launch_geometry_vs_oracle_on_four_windows(name, hidden, layers, ar):
+    """Round-4 review: at b = 64 (N = 128 windows: other tiles, K splits and windows-per-group choices than at b = 2) C4 / C5 were
+    only compared with themselves.  Every op below the criterion is per window (model.py:102-108,188-207; transformers.py:52-70),
+    so: the HIP model runs on all 128 windows, the fp64 oracle on windows {0, 63, 64, 127} alone -- z and c of those windows must
+    agree (2e-5), and so must every parameter gradient of a loss that only involves those four windows (the oracle differentiated
+    under the kernels' own ReLU decisions for them, read back from what the forward pass keeps: section 2 of DESIGN.md)."""
+    n, sel = 128, [0, 63, 64, 127]
+    model, mp = _full_size_model(hidden, layers, ar)
+    x = synth.audio_windows(n, 20480, 33)
+    xd = x.to(DEV)
+    c, z, _ = model(xd, None)
+    gc = synth.features((len(sel), 128, hidden), 34).to(DEV)
+    gz = synth.features((len(sel), 128, hidden), 35).to(DEV)
+    ((c[sel] * gc).sum() + (z[sel] * gz).sum()).backward()
+    torch.cuda.synchronize()
+    _lib.check(_lib.load().cpc_async_error_check(_lib.stream_ptr(torch.device(DEV))), "async error check")
+    enc_params = {k: v for k, v in mp.items() if k.startswith("gEncoder.")}
+    masks = _kernel_relu_decisions(hidden, enc_params, x, windows=sel)
+    p64 = {k: v.double().requires_grad_(True) for k, v in mp.items()}
+    pre = []
+    z64 = O.encoder_forward(x[sel].double(), p64, "gEncoder.", masks=masks, pre_out=pre).permute(0, 2, 1)
+    for i, (m, y) in enumerate(zip(masks, pre)):
+        diff = m.bool() != (y > 0)                           # (a handful of pre-activations within fp32 rounding of zero)
+        assert int(diff.sum()) <= max(2, int(1e-6 * diff.numel())), f"layer {i}: {int(diff.sum())} ReLU decisions differ from the fp64 oracle's"
+        if diff.any():
+            assert float(y[diff].abs().max() / y.abs().max()) <= 1e-5
+    if ar == "transformer":
+        c64 = z64
+        for layer in range(layers):
+            c64 = O.transformer_layer_forward(c64, p64, f"gAR.{layer}.")
+    else:
+        c64, _ = O.gru_forward(z64, p64, layers, "gAR.baseNet.")
+    assert_close(z[sel], z64, 2e-5, "z of the four windows")
+    assert_close(c[sel], c64, 2e-5, "c of the four windows")
+    ((c64 * gc.cpu().double()).sum() + (z64 * gz.cpu().double()).sum()).backward()
+    worst = 0.0
+    for pname, p in model.named_parameters():
+        ref = p64[pname].grad
+        worst = max(worst, rel_err(p.grad, ref))
+        assert_close(p.grad, ref, 2e-4, f"grad {pname}")
+    print(f"{name}: four-window gradients at N = {n}: worst {worst:.2e} of scale")
