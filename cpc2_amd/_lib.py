@@ -42,6 +42,8 @@ SIGNATURES = {
     "cpc_encoder_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_encoder_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_encoder_backward_deferred": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_encoder_forward2": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
+    "cpc_encoder_backward2": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_int, c_ptr]),
     "cpc_coop_launches": (c_long, []),
     "cpc_coop_set_policy": (c_int, [c_int]),
     "cpc_recurrent_backward_calls": (c_long, []),

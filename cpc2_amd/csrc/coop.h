@@ -96,8 +96,9 @@ static inline int coop_windows_per_group(int H, int N, int n_cus, int *groups_pe
     const int G = H == 256 ? CoopCfg<256>::G : (H == 512 ? CoopCfg<512>::G : 0);
     if (G == 0 || n_cus < G) return 0;
     const int max_groups = n_cus / G;
+    static const int nb_min = getenv("CPC_COOP_NB_MIN") != nullptr ? atoi(getenv("CPC_COOP_NB_MIN")) : 1;      // A/B switch
     for (int nb = 1; nb <= 8; nb *= 2)
-        if ((int)cdiv(N, nb) <= max_groups) { *groups_per = G; return nb; }
+        if (nb >= nb_min && (int)cdiv(N, nb) <= max_groups) { *groups_per = G; return nb; }
     return 0;
 }
 

@@ -31,7 +31,9 @@ constexpr int C0_K = 10, C0_S = 5, C0_P = 3;
 constexpr int C0_AHEAD = C0_AHEAD_N;   // conv0_bwd: dy rows requested ahead per lane group (measured 1..4, see the kernel)
 
 struct Conv0Args {
-    const float *x;        // [N][L0]
+    const float *x;        // windows 0 .. n_split - 1: [n_split][L0]
+    const float *x2;       // windows n_split .. N - 1: [N - n_split][L0]  (the caller's past and future batches: train.py:99's cat without the copy)
+    int n_split;
     const float *w;        // [H][10]
     const float *b;        // [H]
     const float *gamma;    // [H]
@@ -51,10 +53,15 @@ struct Conv0Args {
 #endif
 };
 
+__device__ __forceinline__ const float *conv0_window(const Conv0Args &a, long n)
+{
+    return n < a.n_split ? a.x + n * a.L0 : a.x2 + (n - a.n_split) * a.L0;
+}
+
 template <int H> __device__ __forceinline__ void conv0_load_segment(float *xs, const Conv0Args &a, int n, int t0)
 {
     // xs[i] = x[n][5*t0 - 3 + i], i < 5*TB + 5, zero outside [0, L0)
-    const float *xn = a.x + (long)n * a.L0;
+    const float *xn = conv0_window(a, n);
     for (int i = threadIdx.x; i < C0_S * C0_TB + C0_K - C0_S; i += blockDim.x) {
         const int pos = C0_S * t0 - C0_P + i;
         xs[i] = (pos >= 0 && pos < a.L0) ? xn[pos] : 0.f;
@@ -336,7 +343,7 @@ template <int H> __global__ __launch_bounds__(256) void conv0_bwd_kernel(Conv0Ar
         const int last = blockIdx.x < a.n_tiles ? blockIdx.x + ((a.n_tiles - 1 - blockIdx.x) / gridDim.x) * gridDim.x : -1;
         if (last >= 0) {
             const int n = last / a.tiles_per_sample, t0 = (last - n * a.tiles_per_sample) * C0_TB;
-            const float *xn = a.x + (long)n * a.L0;
+            const float *xn = conv0_window(a, n);
             for (int i = threadIdx.x; i < C0_S * C0_TB + C0_K - C0_S; i += blockDim.x) {
                 const int pos = C0_S * t0 - C0_P + i;
                 const float want = (pos >= 0 && pos < a.L0) ? xn[pos] : 0.f;
@@ -631,7 +638,7 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
                 const long n = row / a.R0;
                 const int t = (int)(row - n * a.R0) - a.halo;
                 const int pos = C0_S * t - C0_P + j;
-                if (n < a.N && t >= 0 && t < a.L1 && pos >= 0 && pos < a.L0) v[q] = a.x[n * a.L0 + pos];
+                if (n < a.N && t >= 0 && t < a.L1 && pos >= 0 && pos < a.L0) v[q] = conv0_window(a, n)[pos];
             }
         }
     };
@@ -1150,15 +1157,18 @@ static int enc_layout(EncLayout &e, int N, int length, int H, void *saved, void 
     return CPC_OK;
 }
 
+// x2 / n_first: windows n_first .. N - 1 come from x2 (nullptr: all N from x)
 static int encoder_forward(const float *x, const float *const *prm, float *z, void *saved, void *scratch, int N,
-                           int length, int H, float eps, hipStream_t st)
+                           int length, int H, float eps, hipStream_t st, const float *x2 = nullptr, int n_first = 0)
 {
+    CPC_REQUIRE(x2 == nullptr || (n_first > 0 && n_first < N), "encoder: the first batch must hold 1 .. n_windows - 1 windows (got %d of %d)", n_first, N);
     EncLayout e;
     CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
 
     // layer 0: fused conv + norm + relu straight from the waveform
     Conv0Args c0{};
-    c0.x = x; c0.w = prm[0]; c0.b = prm[1]; c0.gamma = prm[2]; c0.beta = prm[3];
+    c0.x = x; c0.x2 = x2; c0.n_split = x2 != nullptr ? n_first : N;
+    c0.w = prm[0]; c0.b = prm[1]; c0.gamma = prm[2]; c0.beta = prm[3];
     c0.y = e.Y[0]; c0.stats = e.stats0;
     c0.N = N; c0.L0 = e.L[0]; c0.L1 = e.L[1]; c0.R0 = e.R[0]; c0.halo = kConv[1].p; c0.eps = eps;
     c0.tiles_per_sample = (int)cdiv(e.L[1], C0_TB);
@@ -1257,8 +1267,10 @@ static int encoder_forward(const float *x, const float *const *prm, float *z, vo
 // column sums of dgamma / dbeta / dbias and the sum of the weight-gradient product's K-split slabs, eight to ten launches of 5-10 us
 // that nothing on `st` needs -- run on the library's side stream (side_tail_*), each layer with buffers of its own
 static int encoder_backward(const float *x, const float *const *prm, const float *dz, void *saved, void *scratch,
-                            float *const *grads, int N, int length, int H, float eps, hipStream_t st, bool defer_small = false)
+                            float *const *grads, int N, int length, int H, float eps, hipStream_t st, bool defer_small = false,
+                            const float *x2 = nullptr, int n_first = 0)
 {
+    CPC_REQUIRE(x2 == nullptr || (n_first > 0 && n_first < N), "encoder: the first batch must hold 1 .. n_windows - 1 windows (got %d of %d)", n_first, N);
     EncLayout e;
     CPC_TRY(enc_layout(e, N, length, H, saved, scratch));
 
@@ -1360,7 +1372,8 @@ static int encoder_backward(const float *x, const float *const *prm, const float
 
     // layer 0
     Conv0Args c0{};
-    c0.x = x; c0.w = prm[0]; c0.b = prm[1]; c0.gamma = prm[2]; c0.beta = prm[3];
+    c0.x = x; c0.x2 = x2; c0.n_split = x2 != nullptr ? n_first : N;
+    c0.w = prm[0]; c0.b = prm[1]; c0.gamma = prm[2]; c0.beta = prm[3];
     c0.stats = e.stats0; c0.dy = dy; c0.part = e.part;
     c0.N = N; c0.L0 = e.L[0]; c0.L1 = e.L[1]; c0.R0 = e.R[0]; c0.halo = kConv[1].p; c0.eps = eps;
     c0.tiles_per_sample = (int)cdiv(e.L[1], C0_TB);
@@ -1441,6 +1454,20 @@ extern "C" int cpc_encoder_backward(const float *x, const float *const *params, 
 {
     return cpc::encoder_backward(x, params, dz, saved, scratch, grads, n_windows, length, hidden, eps,
                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cpc_encoder_forward2(const float *x_first, const float *x_rest, int n_first, const float *const *params, float *z, void *saved,
+                                    void *scratch, int n_windows, int length, int hidden, float eps, cpc_stream_t stream)
+{
+    return cpc::encoder_forward(x_first, params, z, saved, scratch, n_windows, length, hidden, eps, static_cast<hipStream_t>(stream), x_rest, n_first);
+}
+
+extern "C" int cpc_encoder_backward2(const float *x_first, const float *x_rest, int n_first, const float *const *params, const float *dz,
+                                     void *saved, void *scratch, float *const *grads, int n_windows, int length, int hidden, float eps,
+                                     int deferred, cpc_stream_t stream)
+{
+    return cpc::encoder_backward(x_first, params, dz, saved, scratch, grads, n_windows, length, hidden, eps,
+                                 static_cast<hipStream_t>(stream), deferred != 0, x_rest, n_first);
 }
 
 extern "C" int cpc_encoder_backward_deferred(const float *x, const float *const *params, const float *dz, void *saved, void *scratch,

@@ -285,7 +285,13 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
     };
     auto rows_to_offsets = [&](const u32x2_t (&pr)[NCE_PP / 2], unsigned (&vr)[NCE_PP]) {   // after the reads' wait
 #pragma unroll
+#if defined(NCE_DBG) && (NCE_DBG & 8)
+        for (int i = 0; i < NCE_PP; ++i) vr[i] = (min(pr[i >> 1][i & 1], zmax) & 2047u) * (unsigned)(H * 4) + vcol;   // probe: a 2 MiB table (L2-resident)
+#elif defined(NCE_DBG) && (NCE_DBG & 16)
+        for (int i = 0; i < NCE_PP; ++i) vr[i] = (min(pr[i >> 1][i & 1], zmax) & 15u) * (unsigned)(H * 4) + vcol;     // probe: 16 hot rows
+#else
         for (int i = 0; i < NCE_PP; ++i) vr[i] = min(pr[i >> 1][i & 1], zmax) * (unsigned)(H * 4) + vcol;   // (slots past Nneg: any valid row)
+#endif
     };
     auto req_rows = [&](const unsigned (&vr)[NCE_PP], int half) {
         const unsigned dst = lds0 + wslot;
@@ -304,7 +310,11 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
         const unsigned dst = lds0 + wslot;
         if (a.p_packed) {
             // one tensor [b * p_rows][K * H]: row k of (b, t) is K-row number (bb p_rows + t) K + k of it
+#if defined(NCE_DBG) && (NCE_DBG & 32)
+            const unsigned r0 = (unsigned)(((bb * a.p_rows + t) & 63) * a.K);            // probe: the predictions of 64 (b,t) only (no P traffic)
+#else
             const unsigned r0 = (unsigned)((bb * a.p_rows + t) * a.K);
+#endif
             unsigned vp[NCE_PP];
 #pragma unroll
             for (int i = 0; i < NCE_PP; ++i) vp[i] = (r0 + (2 * i + up < a.K ? 2 * i + up : 0)) * (unsigned)(H * 4) + vcol;

@@ -82,19 +82,22 @@ _ENC_GEOMETRY = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
 
 
 class _EncoderFn(torch.autograd.Function):
-    """relu(norm_i(conv_i(.))) x5 in one call; returns the channel-LAST output [N, T, H]."""
+    """relu(norm_i(conv_i(.))) x5 in one call; returns the channel-LAST output [N, T, H].  x2: None, or a second batch of
+    windows that follows x (cpc_encoder_forward2: train.py:99's cat([past, future]) without the copy)."""
 
     @staticmethod
-    def forward(ctx, x, eps, defer_tail, *params):
-        require_gpu(x, *params)
+    def forward(ctx, x, x2, eps, defer_tail, *params):
+        require_gpu(x, x2, *params)
         lib = _lib.load()
         x = f32c(x)
+        x2 = f32c(x2) if x2 is not None else None
         ctx.param_refs = params
         ctx.defer_tail = bool(defer_tail)
         params = tuple(f32c(p) for p in params)
-        n, cin, length = x.shape
-        if cin != 1:
-            raise ValueError(f"CPCEncoder expects [N, 1, L] waveforms (got {tuple(x.shape)})")
+        n_first, cin, length = x.shape
+        if cin != 1 or (x2 is not None and tuple(x2.shape[1:]) != (1, length)):
+            raise ValueError(f"CPCEncoder expects [N, 1, L] waveforms (got {tuple(x.shape)}" + (f" and {tuple(x2.shape)})" if x2 is not None else ")"))
+        n = n_first + (x2.shape[0] if x2 is not None else 0)
         hidden = params[0].shape[0]
         frames = lib.cpc_encoder_frames(length)
         nsaved = lib.cpc_encoder_saved_bytes(n, length, hidden)
@@ -104,33 +107,42 @@ class _EncoderFn(torch.autograd.Function):
         z = torch.empty(n, frames, hidden, dtype=torch.float32, device=x.device)
         saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
         sc = scratch(nscratch, x.device)
-        check(lib.cpc_encoder_forward(ptr(x), ptr_array(params), ptr(z), ptr(saved), ptr(sc), n, length, hidden,
-                                      eps, stream_ptr(x.device)), "encoder_forward")
-        ctx.save_for_backward(x, saved, *params)
+        if x2 is None:
+            check(lib.cpc_encoder_forward(ptr(x), ptr_array(params), ptr(z), ptr(saved), ptr(sc), n, length, hidden,
+                                          eps, stream_ptr(x.device)), "encoder_forward")
+        else:
+            check(lib.cpc_encoder_forward2(ptr(x), ptr(x2), n_first, ptr_array(params), ptr(z), ptr(saved), ptr(sc), n, length, hidden,
+                                           eps, stream_ptr(x.device)), "encoder_forward2")
+        ctx.save_for_backward(x, x2, saved, *params)
         ctx.eps = eps
-        ctx.dims = (n, length, hidden)
+        ctx.dims = (n, length, hidden, n_first)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.load()
-        x, saved, *params = ctx.saved_tensors
-        n, length, hidden = ctx.dims
+        x, x2, saved, *params = ctx.saved_tensors
+        n, length, hidden, n_first = ctx.dims
         dz = f32c(dz)
         grads = grad_buffers(ctx.param_refs)
         nscratch = lib.cpc_encoder_scratch_bytes(n, length, hidden)
         # the deferred form (cpc2_hip.h): inside the caller's scope (CPCEncoder.deferred_weight_gradients) and with every gradient
         # of conv1-4 written in place into the flat gradient buffer
-        if ctx.defer_tail and _all_in_place(ctx.param_refs[4:], grads[4:]):
-            sc = scratch(nscratch, x.device, tag=_tail_tag("enc_tail", x.device))      # a buffer of its own: the side stream outlives this call
+        defer = ctx.defer_tail and _all_in_place(ctx.param_refs[4:], grads[4:])
+        # (deferred: a scratch buffer of its own -- the side stream outlives this call)
+        sc = scratch(nscratch, x.device, tag=_tail_tag("enc_tail", x.device)) if defer else scratch(nscratch, x.device)
+        if x2 is not None:
+            check(lib.cpc_encoder_backward2(ptr(x), ptr(x2), n_first, ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
+                                            n, length, hidden, ctx.eps, int(defer), stream_ptr(x.device)), "encoder_backward2")
+        elif defer:
             check(lib.cpc_encoder_backward_deferred(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
                                                     n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward_deferred")
-            _keep_for_tail(x.device, (x, saved, params, dz, sc))  # (not `grads`: see _GruFn.backward)
         else:
-            sc = scratch(nscratch, x.device)
             check(lib.cpc_encoder_backward(ptr(x), ptr_array(params), ptr(dz), ptr(saved), ptr(sc), ptr_array(grads),
                                            n, length, hidden, ctx.eps, stream_ptr(x.device)), "encoder_backward")
-        return (None, None, None) + tuple(grads)
+        if defer:
+            _keep_for_tail(x.device, (x, x2, saved, params, dz, sc))  # (not `grads`: see _GruFn.backward)
+        return (None, None, None, None) + tuple(grads)
 
 
 class CPCEncoder(nn.Module):
@@ -169,10 +181,11 @@ class CPCEncoder(nn.Module):
             out += [conv.weight, conv.bias, norm.weight, norm.bias]
         return out
 
-    def forward_channel_last(self, x):
-        """[N, 1, L] -> [N, T, H] (what CPCModel consumes); eps taken from batchNorm0."""
+    def forward_channel_last(self, x, x_rest=None):
+        """[N, 1, L] -> [N, T, H] (what CPCModel consumes); eps taken from batchNorm0.  x_rest: a second batch whose windows
+        follow x's (the output is that of forward_channel_last(cat([x, x_rest])) without the concatenation)."""
         params = self._param_list()
-        return _EncoderFn.apply(x, float(self.batchNorm0.epsilon), self._defer_tail and _no_hooks(params[4:]), *params)
+        return _EncoderFn.apply(x, x_rest, float(self.batchNorm0.epsilon), self._defer_tail and _no_hooks(params[4:]), *params)
 
     def forward(self, x):
         # reference layout [N, H, T]; a permuted view of the channel-last buffer

@@ -447,10 +447,10 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
         with _defer_scope(cpcCriterion, encoded_data):
             allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
         return sum_losses(allLosses), allLosses, allAcc
-    combined = torch.cat([past, future], dim=0)
     if not strict and _context_windows_only(cpcModel):
         with _ar_scope(cpcModel):
-            encoded_full = cpcModel.gEncoder.forward_channel_last(combined)          # [2b, T, H]
+            # (train.py:99's cat([past, future]) as two pointers: only the first layer reads the waveform)
+            encoded_full = cpcModel.gEncoder.forward_channel_last(past, future)      # [2b, T, H]
             context_in, encoded_data = split_windows(encoded_full, b)
             c_feature = cpcModel.gAR(context_in)                                      # [b, T, H]: train.py:102's c_feature[:b]
         if dp is not None:
@@ -458,6 +458,7 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
         with _defer_scope(cpcCriterion, encoded_data):
             allLosses, allAcc = cpcCriterion(c_feature, encoded_data, label, signal_quality)
         return sum_losses(allLosses), allLosses, allAcc
+    combined = torch.cat([past, future], dim=0)
     # (train.py:100,105 concatenate the labels too and take the first half back: CPCModel hands `label` through untouched, so the
     #  round trip -- two small kernels per step -- is skipped for it; any other model gets the reference's tensors)
     passthrough = isinstance(getattr(cpcModel, "module", cpcModel), CPCModel)

@@ -169,6 +169,15 @@ int cpc_encoder_backward(const float *x, const float *const *params, const float
 int cpc_encoder_backward_deferred(const float *x, const float *const *params, const float *dz, void *saved,
                          void *scratch, float *const *grads, int n_windows, int length, int hidden,
                          float eps, cpc_stream_t stream);
+/* The same encoder over TWO input batches without concatenating them: windows 0 .. n_first - 1 are x_first [n_first, 1, length],
+ * windows n_first .. n_windows - 1 are x_rest [n_windows - n_first, 1, length] -- train.py:99's cat([past, future]) as two pointers
+ * (only the first layer reads the waveform).  Everything else as cpc_encoder_forward / cpc_encoder_backward; deferred != 0 selects
+ * the deferred form of the backward (cpc_encoder_backward_deferred). */
+int cpc_encoder_forward2(const float *x_first, const float *x_rest, int n_first, const float *const *params, float *z, void *saved,
+                         void *scratch, int n_windows, int length, int hidden, float eps, cpc_stream_t stream);
+int cpc_encoder_backward2(const float *x_first, const float *x_rest, int n_first, const float *const *params, const float *dz,
+                          void *saved, void *scratch, float *const *grads, int n_windows, int length, int hidden, float eps,
+                          int deferred, cpc_stream_t stream);
 /* Inspection (tests only; the layout of `saved` is otherwise private): what the forward pass keeps of layer 0..4 --
  * the ChannelNorm of model.py:52-60 as (xhat, rstd) (layers 1..4) and, at hidden 256 / 512, the layer's ReLU'd output as the
  * next layer's input planes (layers 0..3).  out[10]:

@@ -394,6 +394,27 @@ def test_encoder_vs_oracle_fp64(hidden, n, length):
         assert_close(p.grad, pm["gEncoder." + name].grad, 5e-5, f"grad {name} (the kernels' ReLU decisions)")
 
 
+@pytest.mark.parametrize("hidden,n,n_first", [(256, 5, 2), (64, 3, 1), (512, 4, 3)])
+def test_encoder_over_two_input_batches_equals_the_concatenated_call(hidden, n, n_first):
+    """cpc_encoder_forward2 / cpc_encoder_backward2: windows 0 .. n_first - 1 from one buffer, the rest from another (train.py:99's
+    cat([past, future]) as two pointers; only conv0's kernels read the waveform): output and every gradient are those of the
+    concatenated call, bit for bit."""
+    params = synth.encoder_params(hidden, seed=5)
+    x = synth.audio_windows(n, 20480, seed=6).to(DEV)
+    gout = synth.features((n, 128, hidden), seed=7).to(DEV)
+    res = []
+    for pair in (False, True):
+        enc = load_encoder(hidden, params)
+        out = enc.forward_channel_last(x[:n_first].clone(), x[n_first:].clone()) if pair else enc.forward_channel_last(x)
+        (out * gout).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    with pytest.raises(ValueError):
+        enc.forward_channel_last(x[:1], x[1:, :, :100].contiguous())
+
+
 def _kernel_relu_decisions(hidden, params, x, windows=None):
     """The 0/1 masks [N, H, L_i] of the five ReLUs as the HIP forward pass decided them, read from what it keeps: the outputs
     of layers 0..3 are the next layers' input planes in `saved` (cpc_encoder_saved_layout), layer 4's is z.  windows: only
