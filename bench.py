@@ -528,10 +528,18 @@ def main():
             if (args.config == "small" and not args.no_prof) else ""
     others = []
     for name in [n for n in also.split(",") if n]:
-        rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
+        # (an extra configuration must never cost the headline its line: a failure is recorded in its place.  Every rank runs the
+        #  same code on the same shapes, so an exception is raised on every rank alike and no collective is left half-entered)
+        try:
+            rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
+        except Exception as exc:                                   # noqa: BLE001
+            log(f"{name}: FAILED: {exc!r}")
+            rec = {"config": {"workload": f"CPC-{name}"}, "error": repr(exc)[:400]} if rank == 0 else None
         if rec is not None:
             rec.pop("_gradient_bytes", None)
-            rec.pop("_comm", None)
+            comm_rec = rec.pop("_comm", None)
+            if world > 1 and comm_rec is not None:                 # (N > 1: what the exchange cost this configuration)
+                rec["comm"] = comm_rec
             others.append(rec)
     if rank == 0:
         if others:

@@ -381,6 +381,14 @@ template <int H> __global__ __launch_bounds__(64, 2) void infonce_fwd_dma_kernel
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     int bt = blockIdx.x, par = 0;
     if (bt >= n_bt) return;
+#if defined(NCE_STAGGER)
+    {
+        // probe: the second wave of a SIMD (odd wave slot: HW_ID bits 3:0) starts NCE_STAGGER x 64 cycles late, so that one wave of
+        // the pair requests while the other multiplies from the first element on
+        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        if (hwid & 1u) __builtin_amdgcn_s_sleep(NCE_STAGGER);
+    }
+#endif
     req_p(bt, 0);
     req_list(bt, 0);
     for (; bt < n_bt; bt += gridDim.x, par ^= 1) {
