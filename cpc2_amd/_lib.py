@@ -54,6 +54,7 @@ SIGNATURES = {
     "cpc_gru_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_gru_backward_deferred": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_side_tail_join": (c_int, [c_ptr]),
+    "cpc_side_tail_wait": (c_int, [c_ptr]),
     "cpc_lstm_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cpc_lstm_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cpc_lstm_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),

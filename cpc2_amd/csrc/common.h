@@ -230,5 +230,6 @@ int infonce_deferred_start(hipStream_t st);
 int side_tail_begin(hipStream_t st, hipStream_t *side_stream);
 int side_tail_end();
 int side_tail_join(hipStream_t st);
+int side_tail_wait(hipStream_t st);       // `st` waits for the tail, which stays pending (a later side_tail_join still joins)
 
 }  // namespace cpc

@@ -1268,3 +1268,4 @@ extern "C" int cpc_gru_backward_deferred(const float *x, const float *const *par
 }
 
 extern "C" int cpc_side_tail_join(cpc_stream_t stream) { return cpc::side_tail_join(static_cast<hipStream_t>(stream)); }
+extern "C" int cpc_side_tail_wait(cpc_stream_t stream) { return cpc::side_tail_wait(static_cast<hipStream_t>(stream)); }

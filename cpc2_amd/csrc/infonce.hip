@@ -1511,6 +1511,16 @@ int side_tail_join(hipStream_t st)
     return CPC_OK;
 }
 
+// the same wait WITHOUT taking the tail off the books: a helper stream (the data-parallel exchange's) orders itself behind the tail
+// while the caller's stream goes on; whoever reuses the tail's buffers still joins with side_tail_join
+int side_tail_wait(hipStream_t st)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side));
+    if (side->tail_pending) CPC_CHECK_HIP(hipStreamWaitEvent(st, side->tail, 0));
+    return CPC_OK;
+}
+
 // every stream that is going to touch dz / dwpred of a deferred backward waits here (no-op when nothing is pending)
 static int infonce_join(hipStream_t st)
 {

@@ -246,6 +246,7 @@ class DataParallelContext:
         self.timing = timing                    # bench.py: events around the part of a step the exchange holds the stream for
         self._spans = []
         self._coop_seen = None
+        self._helper = None                     # the stream the early all-reduces are issued from (attach)
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
         self.early, self.late, self._pending, self._fired = [], [], [], False
@@ -338,11 +339,24 @@ class DataParallelContext:
                     raise RuntimeError("DataParallelContext: the early all-reduce would be issued BEFORE the recurrent backward of "
                                        "this step (a collective's kernels beside a cooperative kernel that needs every workgroup "
                                        "resident): attach() must be given the encoder output, upstream of the context network")
-                if on_gpu:
-                    join_tail(self.opt.flat_grad.device)         # (a context network's weight gradients still on the side stream)
                 if getattr(self.opt, "direct_grads", False):
                     self.opt._gather_stray_grads(self.early)     # a gradient autograd did not write in place (accumulation)
-                self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
+                if not on_gpu:
+                    self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
+                    return
+                # The early slices are complete once the compute stream has reached this point AND the library's side stream has
+                # finished the context network's deferred weight gradients.  Only the EXCHANGE has to wait for the latter: it is issued
+                # from a helper stream that is ordered behind both, and the compute stream goes straight on into the encoder's
+                # backward (round 4 joined the side stream into the compute stream here: ~0.1 ms of the encoder's backward waiting
+                # for products nothing in it reads).  The deferred calls' buffers stay on the books until the join at the end of the
+                # backward pass / in reduce_and_step().
+                device = self.opt.flat_grad.device
+                if self._helper is None:
+                    self._helper = torch.cuda.Stream(device)
+                self._helper.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(self._helper):
+                    check(_lib.load().cpc_side_tail_wait(stream_ptr(device)), "side_tail_wait")
+                    self._pending = [self._all_reduce(lo, hi, async_op=True) for lo, hi in self.early]
         encoder_output.register_hook(start)
 
     def reduce_and_step(self):

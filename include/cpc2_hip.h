@@ -215,6 +215,9 @@ int cpc_gru_backward_deferred(const float *x, const float *const *params, const 
                               void *scratch, float *dx, float *const *grads, int n, int t, int dim_in,
                               int hidden, int layers, cpc_stream_t stream);
 int cpc_side_tail_join(cpc_stream_t stream);
+/* `stream` waits for the same work, which STAYS pending: for a stream that only consumes the finished gradients (the data-parallel
+ * exchange's helper stream) while the caller's stream goes on; the buffers of the deferred calls are released by cpc_side_tail_join. */
+int cpc_side_tail_wait(cpc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * CPCAR with mode="LSTM" (model.py:171-173 -> torch.nn.LSTM, batch_first, gate order i,f,g,o;
