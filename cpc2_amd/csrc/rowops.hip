@@ -96,9 +96,14 @@ int coop_error_take(const char *where)
                   "(no out-of-bounds gather took place) -- the loss of that step is meaningless", where);
         return CPC_ERR_HIP;
     }
+    // whatever kept the workgroups from being resident together (another tenant on the device) is likely to still be there: from
+    // here on this process takes the streaming kernels, which have no such requirement (cpc_coop_set_policy(0) restores the default)
+    g_coop_policy.store(1, std::memory_order_relaxed);
     set_error("%s: a cooperative recurrent kernel (%s pass) gave up waiting for the other workgroups of its group -- its "
-              "workgroups were not all resident at once (another kernel on the device?); its outputs are NaN.  "
-              "CPC_GRU_STREAM=1 selects the non-cooperative kernels", where, code == COOP_ERR_FWD_WAIT ? "forward" : "backward");
+              "workgroups were not all resident at once (another kernel on the device?); its outputs are NaN (the fused Adam "
+              "step skips non-finite gradient elements: the parameters are intact).  This process now uses the streaming "
+              "(non-cooperative) recurrent kernels; cpc_coop_set_policy(0) restores the default", where,
+              code == COOP_ERR_FWD_WAIT ? "forward" : "backward");
     return CPC_ERR_HIP;
 }
 int coop_fault_injection()

@@ -54,8 +54,10 @@ const char *cpc_last_error(void);
  * the hidden state through L2 and need to be resident all at once).  Every wait inside them is bounded; a wave whose wait
  * runs out poisons its outputs with NaN AND records a code in a host-visible word.  cpc_gru_* / cpc_lstm_* / cpc_rnn_*
  * return CPC_ERR_HIP (message in cpc_last_error) at their NEXT call when the word is set; cpc_async_error_check
- * synchronises `stream`, then reports and clears it.  CPC_COOP_FAULT=1 in the environment (tests) makes one member
- * withhold one publish so that its group times out. */
+ * synchronises `stream`, then reports and clears it.  Reporting a time-out also switches the process to the streaming
+ * recurrent kernels (cpc_coop_set_policy(1)): the step that timed out is lost (NaN loss; cpc_adam_step skips non-finite gradient
+ * elements, so the parameters are intact), the following ones do not depend on co-residency.  CPC_COOP_FAULT=1 in the environment
+ * (tests) makes one member withhold one publish so that its group times out. */
 int cpc_async_error_check(cpc_stream_t stream);
 /* Cooperative recurrent launches (the GRU / LSTM kernels at hidden 256 / 512 that need every workgroup resident at once)
  * issued by this process so far.  The data-parallel glue (train.py:523-527's role) checks with it that a gradient all-reduce

@@ -2407,17 +2407,31 @@ def test_cooperative_recurrence_timeout_is_reported(monkeypatch, mode):
     monkeypatch.setenv("CPC_COOP_FAULT", "1")
     bad = ar(x)
     monkeypatch.delenv("CPC_COOP_FAULT")
-    with pytest.raises(RuntimeError, match="gave up waiting"):
+    try:
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            _lib.check(lib.cpc_async_error_check(stream))
+        assert torch.isnan(bad).any()
+        _lib.check(lib.cpc_async_error_check(stream))                 # reported once, then cleared
+        # the report switched the process to the streaming kernels (whatever kept the workgroups apart may still be there):
+        # the next call works without anybody's help, and agrees with the cooperative kernels to rounding
+        assert lib.cpc_coop_set_policy(-1) == 1
+        launches = lib.cpc_coop_launches()
+        streamed = ar(x)
         _lib.check(lib.cpc_async_error_check(stream))
-    assert torch.isnan(bad).any()
-    _lib.check(lib.cpc_async_error_check(stream))                     # reported once, then cleared
+        assert lib.cpc_coop_launches() == launches
+        assert_close(streamed, good, 2e-6, "streaming kernel after the switch")
+    finally:
+        lib.cpc_coop_set_policy(0)
     # without an explicit check the NEXT call into the recurrent kernels reports it
     monkeypatch.setenv("CPC_COOP_FAULT", "1")
     ar(x)
     monkeypatch.delenv("CPC_COOP_FAULT")
     torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match="gave up waiting"):
-        ar(x)
+    try:
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            ar(x)
+    finally:
+        lib.cpc_coop_set_policy(0)
     again = ar(x)
     _lib.check(lib.cpc_async_error_check(stream))
     assert torch.equal(again, good)
