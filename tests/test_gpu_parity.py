@@ -1806,6 +1806,46 @@ def test_context_network_on_the_context_windows_only_is_the_reference_step(name,
     assert float(diff.mean()) <= 0.02 * float(moved.mean()), f"mean parameter distance {float(diff.mean()):.2e} vs moved {float(moved.mean()):.2e}"
 
 
+@pytest.mark.parametrize("config", ["small", "transformer"])
+def test_context_windows_only_form_matches_strict_along_a_trajectory_at_full_batch(config):
+    """The bench workload itself (b = 64 windows, CPC-small / transformer AR in training mode): along ONE training trajectory of
+    cpcStep's default form, every 20 steps the gradient of the reference's 2b-window dataflow (strict=True) is evaluated on the SAME
+    parameters, negative indices and dropout seed: losses equal to 1e-6, every parameter gradient to 2e-5 of its tensor's scale
+    (measured 4e-7 .. 7e-6).  Two runs of the two forms drift apart over hundreds of Adam steps on this pure-noise input (rounding-sized
+    gradient differences grow like any perturbation of that trajectory: profiles/r05_soak.txt) -- this is the check that the drift is
+    not a difference between the forms."""
+    import bench
+    cfg = bench.CONFIGS[config]
+    dev = torch.device(DEV)
+    mA, cA, oA = bench.build(cfg, dev)
+    mB, cB, oB = bench.build(cfg, dev)
+    x = (0.05 * torch.randn(64, 1, bench.WINDOW, generator=torch.Generator().manual_seed(1000))).to(dev)
+    label = torch.zeros(64, dtype=torch.long, device=dev)
+    names = [n for n, _ in list(cA.named_parameters()) + list(mA.named_parameters())]
+    checked = 0
+    for step in range(41):
+        cA.seed(5000 + step)
+        torch.manual_seed(step)                  # (a transformer layer draws its dropout seed from torch's CPU generator)
+        tot, lA, _ = cpcStep(x, x, label, mA, cA)
+        tot.backward()
+        if step % 20 == 0:
+            oB.flat.copy_(oA.flat)
+            cB.seed(5000 + step)
+            torch.manual_seed(step)
+            totB, lB, _ = cpcStep(x, x, label, mB, cB, strict=True)
+            totB.backward()
+            assert_close(lA, lB, 1e-6, f"step {step}: losses")
+            for name, p, off in zip(names, oA.params, oA.offsets):
+                n = p.numel()
+                assert_close(oA.flat_grad[off:off + n], oB.flat_grad[off:off + n], 2e-5, f"step {step}: grad {name}")
+            oB.zero_grad()
+            checked += 1
+        oA.step()
+        oA.zero_grad()
+    assert checked == 3 and float(lA.mean()) < 4.8598
+    _lib.check(_lib.load().cpc_async_error_check(_lib.stream_ptr(dev)), "async error check")
+
+
 def test_context_windows_only_form_is_refused_where_it_would_change_the_observable():
     """The reduced dataflow is cpcStep's own and only for the bare CPCModel without state across calls: span masking (numpy draws
     over all 2b rows), keepHidden (the stored state covers 2b windows) and any wrapper keep the reference's 2b-window call."""
