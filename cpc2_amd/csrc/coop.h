@@ -120,6 +120,12 @@ static inline int coop_cu_count()
 int *coop_error_word();                         // device-visible address of the word (nullptr: allocation failed)
 int coop_error_take(const char *where);         // host: CPC_OK, or CPC_ERR_HIP (message set, word cleared)
 int coop_fault_injection();                     // tests: CPC_COOP_FAULT=1 makes member 0 of group 0 withhold one publish
+// Granule memory of the cooperative kernels: ONE buffer per (device, stream) that the library owns and nothing else ever writes,
+// zeroed once; every launch gets a range of epochs of its own ([*epoch0 + 1, *epoch0 + T]), so a granule left by an earlier launch
+// can never be taken for a current one and nothing has to be cleared between launches (rounds 2-4 carved the granules out of the
+// caller's scratch arena -- which other kernels write -- and cleared them in front of every launch: two memsets of 7-14 us on the
+// step's critical path).  The buffer grows when a launch needs more; the epoch counter wraps by clearing it once.
+int coop_comm_acquire(size_t bytes, int T, hipStream_t st, gu64_t **comm, unsigned *epoch0);
 bool coop_allowed();                            // process-wide policy (cpc_coop_set_policy): false = streaming kernels only
 void coop_count_launch();                       // every cooperative recurrent launch is counted (cpc_coop_launches)
 long coop_launches();

@@ -212,7 +212,8 @@ __global__ void gru_bwd_kernel(GruArgs a)
 // suffice.  Every spin is bounded: on time-out the workgroup poisons its outputs with NaN and leaves.
 struct GruCoopArgs {
     GruArgs g;
-    gu64_t *comm;          // granules, zeroed before the launch: fwd [groups][2][G][U][NB] (coop_fwd_slot), bwd [groups][2][G][NB][H]
+    gu64_t *comm;          // granules (coop_comm_acquire: the library's own buffer): fwd [groups][2][G][U][NB] (coop_fwd_slot), bwd [groups][2][G][NB][H]
+    unsigned epoch0;       // this launch's epochs are epoch0 + 1 .. epoch0 + T: no granule of an earlier launch carries one of them
     int groups, xcd_map;
     int *err;              // host-visible error word (coop.h), or nullptr
     int fault;             // tests: member 0 of group 0 withholds its publish of step 1
@@ -311,7 +312,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
             // members wait for this store, nobody waits for the saved activations below
             COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + coop_fwd_slot<H, NB>(group, nxt, member, u, q));
             if (!(ca.fault && group == 0 && member == 0 && t == 1))
-                __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                __hip_atomic_store(slot, ((gu64_t)(ca.epoch0 + (unsigned)(t + 1)) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine) {
                 const long row = (long)ns * T + t;
@@ -340,7 +341,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_coop_ker
 #pragma unroll
                     for (int i = 0; i < KP; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
+                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == ca.epoch0 + (unsigned)(t + 1);
                     if (ready) break;
                     if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -545,7 +546,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_mfma_ker
             hprev = hv;
             COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + coop_fwd_slot<H, NB>(group, nxt, member, u, q));
             if (!(ca.fault && group == 0 && member == 0 && t == 1))
-                __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                __hip_atomic_store(slot, ((gu64_t)(ca.epoch0 + (unsigned)(t + 1)) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine) {
                 const long row = (long)ns * T + t;
@@ -570,7 +571,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_fwd_mfma_ker
 #pragma unroll
                     for (int i = 0; i < KP; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
+                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == ca.epoch0 + (unsigned)(t + 1);
                     if (ready) break;
                     if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -655,7 +656,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_coop_ker
 #endif
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
-        const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
+        const unsigned epoch = ca.epoch0 + (unsigned)(T - t);              // 1, 2, ...
         float keep = 0.f;
         if (ew) {
             float dpr = 0.f, dpz = 0.f, dhn = 0.f;
@@ -832,7 +833,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void gru_bwd_mfma_ker
 #endif
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
-        const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
+        const unsigned epoch = ca.epoch0 + (unsigned)(T - t);              // 1, 2, ...
         float keep = 0.f;
         if (ew) {
             float dpr = 0.f, dpz = 0.f, dhn = 0.f;
@@ -1109,10 +1110,10 @@ static int gru_forward(const float *x, const float *const *prm, const float *h0,
             nb = 0;                             // not resident all at once: the streaming kernel has no such requirement
         if (nb != 0) {
             GruCoopArgs ca{};
-            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.g = a; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
             ca.err = coop_error_word(); ca.fault = coop_fault_injection();
-            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * nb * H, st));
+            CPC_TRY(coop_comm_acquire(sizeof(gu64_t) * (size_t)ca.groups * 2 * nb * H, T, st, &ca.comm, &ca.epoch0));
 #ifdef GRU_STAMPS
             static unsigned long long *stamps = nullptr;
             if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 512 * 8 * sizeof(unsigned long long)));
@@ -1172,10 +1173,10 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
             nb = 0;
         if (nb != 0) {
             GruCoopArgs ca{};
-            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.g = a; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
             ca.err = coop_error_word(); ca.fault = coop_fault_injection();
-            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(unsigned long long) * (size_t)ca.groups * 2 * G * nb * H, st));
+            CPC_TRY(coop_comm_acquire(sizeof(gu64_t) * (size_t)ca.groups * 2 * G * nb * H, T, st, &ca.comm, &ca.epoch0));
 #ifdef GRU_STAMPS
             static unsigned long long *stamps = nullptr;
             if (stamps == nullptr) CPC_CHECK_HIP(hipMalloc(&stamps, 512 * 8 * sizeof(unsigned long long)));

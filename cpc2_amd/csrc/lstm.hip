@@ -234,7 +234,8 @@ __global__ void lstm_bwd_kernel(LstmArgs a)
 // thread.  The cell state of (window q, unit j) stays in the register of the lane that finishes that pair.
 struct LstmCoopArgs {
     LstmArgs g;
-    gu64_t *comm;          // granules, zeroed before the launch: fwd [groups][2][G][U][NB] (coop_fwd_slot), bwd [groups][2][G][NB][H]
+    gu64_t *comm;          // granules (coop_comm_acquire: the library's own buffer): fwd [groups][2][G][U][NB] (coop_fwd_slot), bwd [groups][2][G][NB][H]
+    unsigned epoch0;       // this launch's epochs are epoch0 + 1 .. epoch0 + T: no granule of an earlier launch carries one of them
     int groups, xcd_map;
     int *err;              // host-visible error word (coop.h), or nullptr
     int fault;             // tests: member 0 of group 0 withholds its publish of step 1
@@ -324,7 +325,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
             // members wait for this store, nobody waits for the saved activations below
             COOP_GLOBAL gu64_t *slot = (COOP_GLOBAL gu64_t *)(ca.comm + coop_fwd_slot<H, NB>(group, nxt, member, u, q));
             if (!(ca.fault && group == 0 && member == 0 && t == 1))
-                __hip_atomic_store(slot, ((gu64_t)(unsigned)(t + 1) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
+                __hip_atomic_store(slot, ((gu64_t)(ca.epoch0 + (unsigned)(t + 1)) << 32) | (gu64_t)__float_as_uint(mine ? hv : 0.f),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine) {
                 const long row = (long)ns * T + t;
@@ -351,7 +352,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_fwd_coop_ke
 #pragma unroll
                     for (int i = 0; i < KP; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == (unsigned)(t + 1);
+                    for (int i = 0; i < KP; ++i) ready = ready && (unsigned)(x[i] >> 32) == ca.epoch0 + (unsigned)(t + 1);
                     if (ready) break;
                     if (++spins > (1u << 22)) { dead = true; coop_report(ca.err, COOP_ERR_FWD_WAIT); break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -428,7 +429,7 @@ template <int H, int NB> __global__ __launch_bounds__(512) void lstm_bwd_coop_ke
     bool dead = false;
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
-        const unsigned epoch = (unsigned)(T - t);              // 1, 2, ...
+        const unsigned epoch = ca.epoch0 + (unsigned)(T - t);              // 1, 2, ...
         if (ew) {
             float dpi = 0.f, dpf = 0.f, dpg = 0.f, dpo = 0.f;
             if (emine) {
@@ -654,10 +655,10 @@ static int lstm_forward(const float *x, const float *const *prm, const float *h0
             nb = 0;                             // not resident all at once: the streaming kernel has no such requirement
         if (nb != 0) {
             LstmCoopArgs ca{};
-            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.g = a; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
             ca.err = coop_error_word(); ca.fault = coop_fault_injection();
-            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(gu64_t) * (size_t)ca.groups * 2 * nb * H, st));
+            CPC_TRY(coop_comm_acquire(sizeof(gu64_t) * (size_t)ca.groups * 2 * nb * H, T, st, &ca.comm, &ca.epoch0));
             ProfScope prof(PROF_GRU_FWD, st);
             const dim3 grid((unsigned)(ca.groups * members));
             if (H == 256) launch_lstm_coop_fwd<256>(nb, grid, st, ca);
@@ -703,10 +704,10 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
             nb = 0;
         if (nb != 0) {
             LstmCoopArgs ca{};
-            ca.g = a; ca.comm = g.comm; ca.groups = (int)cdiv(N, nb);
+            ca.g = a; ca.groups = (int)cdiv(N, nb);
             ca.xcd_map = (ca.groups % 8 == 0) ? 1 : 0;
             ca.err = coop_error_word(); ca.fault = coop_fault_injection();
-            CPC_CHECK_HIP(hipMemsetAsync(g.comm, 0, sizeof(gu64_t) * (size_t)ca.groups * 2 * members * nb * H, st));
+            CPC_TRY(coop_comm_acquire(sizeof(gu64_t) * (size_t)ca.groups * 2 * members * nb * H, T, st, &ca.comm, &ca.epoch0));
             ProfScope prof(PROF_GRU_BWD, st);
             const dim3 grid((unsigned)(ca.groups * members));
             if (H == 256) launch_lstm_coop_bwd<256>(nb, grid, st, ca);

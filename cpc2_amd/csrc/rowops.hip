@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -71,6 +72,37 @@ int *coop_error_word()
     });
     return g_err_dev;
 }
+// ---- granule memory of the cooperative recurrent kernels (coop.h)
+struct CoopComm { gu64_t *p = nullptr; size_t bytes = 0; unsigned next = 0; };
+int coop_comm_acquire(size_t bytes, int T, hipStream_t st, gu64_t **comm, unsigned *epoch0)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, CoopComm> bufs;
+    int dev = 0;
+    CPC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    CoopComm &c = bufs[std::make_pair(dev, st)];
+    if (c.bytes < bytes) {
+        // (rare: the first launch on this stream, or a larger shape.  hipFree waits for the device, so nothing still polls the old one)
+        if (c.p != nullptr) CPC_CHECK_HIP(hipFree(c.p));
+        c.p = nullptr; c.bytes = 0;
+        const size_t want = align_up(bytes, (size_t)1 << 20);
+        CPC_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&c.p), want));
+        CPC_CHECK_HIP(hipMemsetAsync(c.p, 0, want, st));
+        c.bytes = want; c.next = 0;
+        const char *v = getenv("CPC_COOP_EPOCH_START");        // tests: a new buffer starts counting here (the wrap is 2^32 launches away otherwise)
+        if (v != nullptr) c.next = (unsigned)strtoul(v, nullptr, 0);
+    }
+    if ((unsigned long long)c.next + (unsigned)T + 2ull > 0xFFFFFFF0ull) {       // the 32-bit epoch would wrap: start over
+        CPC_CHECK_HIP(hipMemsetAsync(c.p, 0, c.bytes, st));
+        c.next = 0;
+    }
+    *comm = c.p;
+    *epoch0 = c.next;
+    c.next += (unsigned)T + 1u;
+    return CPC_OK;
+}
+
 // cooperative policy of the process (cpc_coop_set_policy): 0 = cooperative kernels wherever they fit, 1 = streaming kernels only
 static std::atomic<int> g_coop_policy{0};
 bool coop_allowed() { return g_coop_policy.load(std::memory_order_relaxed) == 0; }

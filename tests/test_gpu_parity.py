@@ -2477,6 +2477,42 @@ def test_cooperative_recurrence_timeout_is_reported(monkeypatch, mode):
     assert torch.equal(again, good)
 
 
+@pytest.mark.parametrize("mode", ["GRU", "LSTM"])
+def test_cooperative_granule_epochs_across_launches_and_the_wrap(monkeypatch, mode):
+    """The cooperative recurrent kernels exchange {epoch, value} granules through a buffer the library owns; every launch takes the
+    next T + 1 epochs instead of clearing the buffer (coop.h, coop_comm_acquire).  Many launches in a row on one stream -- forward and
+    backward, two layers, different window counts (different granule layouts over the same memory) -- give the results of a fresh
+    process' first launch, bit for bit; and a buffer whose 32-bit epoch counter is about to wrap (CPC_COOP_EPOCH_START, read when a
+    stream's buffer is created) clears itself once and goes on."""
+    lib = _lib.load()
+    ar = cpc2_amd.CPCAR(256, 256, False, 2, mode=mode).to(DEV)
+    xs = [synth.features((n, 9, 256), 5 + n).to(DEV).requires_grad_(True) for n in (8, 3, 64, 8)]
+
+    def run(x):
+        x.grad = None
+        out = ar(x)
+        out.square().sum().backward()
+        return out.detach().clone(), x.grad.clone()
+    before = lib.cpc_coop_launches()
+    first = [run(x) for x in xs]
+    assert lib.cpc_coop_launches() - before == 4 * 2 * 2          # (4 inputs x 2 layers x forward + backward)
+    for _rep in range(3):
+        for x, (out, dx) in zip(xs, first):
+            o2, d2 = run(x)
+            assert torch.equal(o2, out) and torch.equal(d2, dx)
+    assert torch.equal(first[0][0], first[3][0])                  # the same input after other shapes have used the buffer
+    # a fresh stream = a fresh buffer, started 25 epochs below the wrap: T + 1 = 10 epochs per launch, four launches per run
+    monkeypatch.setenv("CPC_COOP_EPOCH_START", str(0xFFFFFFF0 - 25))
+    side = torch.cuda.Stream(torch.device(DEV))
+    side.wait_stream(torch.cuda.current_stream(torch.device(DEV)))
+    with torch.cuda.stream(side):
+        for _rep in range(3):
+            o2, d2 = run(xs[0])
+            assert torch.equal(o2, first[0][0]) and torch.equal(d2, first[0][1])
+    side.synchronize()
+    _lib.check(lib.cpc_async_error_check(_lib.stream_ptr(torch.device(DEV))), "async error check")
+
+
 def test_adam_leaves_non_finite_gradient_elements_alone_and_reports_them():
     """A NaN / inf gradient element (what a timed-out cooperative kernel leaves behind, on every rank after the all-reduce)
     must not reach the weights: parameter and moments of that element stay, the others step, and the asynchronous error
