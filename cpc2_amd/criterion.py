@@ -349,6 +349,7 @@ class _InfoNCEFn(torch.autograd.Function):
         ctx.param_refs = wk
         ctx.dims = (b, t, k, dim_ar, dim_enc, n_neg)
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)       # (no zeros tensor -- a launch -- for the gradient of `acc`, which nobody has)
         return losses, acc
 
     @staticmethod
@@ -356,6 +357,8 @@ class _InfoNCEFn(torch.autograd.Function):
         lib = _lib.load()
         c, z, wpred, ext_idx, w, saved = ctx.saved_tensors
         b, t, k, dim_ar, dim_enc, n_neg = ctx.dims
+        if dlosses is None:                    # (materialize_grads is off: a loss nobody differentiated)
+            dlosses = torch.zeros(k, dtype=torch.float32, device=c.device)
         dlosses = f32c(dlosses)
         if ctx.c_first_of is not None:       # (first_windows: dc goes where the slice's backward looks for it, the rest stays zero)
             dc = _cached_grad_buffer(ctx.c_first_of[0], c.device, ("context", ctx.c_first_of[1]))[:c.shape[0]]
@@ -427,6 +430,7 @@ class _InfoNCEPredFn(torch.autograd.Function):
         ctx.save_for_backward(z, ext_idx, w, saved, *preds)
         ctx.dims = (b, t, k, dim_enc, n_neg)
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)
         return losses, acc
 
     @staticmethod
@@ -434,6 +438,8 @@ class _InfoNCEPredFn(torch.autograd.Function):
         lib = _lib.load()
         z, ext_idx, w, saved, *preds = ctx.saved_tensors
         b, t, k, dim_enc, n_neg = ctx.dims
+        if dlosses is None:
+            dlosses = torch.zeros(k, dtype=torch.float32, device=z.device)
         dlosses = f32c(dlosses)
         dz = torch.empty_like(z)
         dpreds = [torch.empty_like(p) for p in preds]
