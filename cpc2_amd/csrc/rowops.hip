@@ -402,7 +402,7 @@ __global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n
 
 }  // namespace cpc
 
-extern "C" int cpc_version(void) { return 100; }
+extern "C" int cpc_version(void) { return 105; }     // 105: round 5 (cpc_encoder_forward2 / backward2, cpc_coop_set_policy, cpc_side_tail_wait, ...)
 
 extern "C" int cpc_prof_enable(int on)
 {

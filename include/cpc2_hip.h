@@ -41,7 +41,8 @@ enum cpc_status {
     CPC_ERR_WORKSPACE = -3 /* workspace / scratch too small */
 };
 
-int cpc_version(void);
+int cpc_version(void);          /* 100 x major + minor; 105 = the entry points of round 5 (cpc_encoder_forward2 / backward2, cpc_coop_set_policy,
+                                  * cpc_recurrent_backward_calls, cpc_side_tail_wait) */
 const char *cpc_last_error(void);
 
 /* In-situ kernel timing for bench.py: when enabled, the launchers bracket each launch of the named
