@@ -81,6 +81,7 @@ SIGNATURES = {
     "cpc_mt_draw_host": (c_int, [c_ptr, c_ptr, c_size_t]),
     "cpc_mt_draw_host_async": (c_int, [c_ptr, c_ptr, c_size_t]),
     "cpc_mt_draw_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_size_t, c_int]),
+    "cpc_mt_draw_expand_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int]),
     "cpc_negidx_expand": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_infonce_saved_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),

@@ -33,8 +33,9 @@ class NegativeSampler:
         if not self._h:
             raise MemoryError("cpc_mt_create failed")
         self.follow_torch = True      # consume torch's global CPU generator (reference semantics)
-        self._ring, self._dev_ring, self._events, self._slot = {}, {}, {}, 0
+        self._ring, self._dev_ring, self._ext_ring, self._events, self._slot = {}, {}, {}, {}, 0
         self._prefetched = None
+        self._last = None             # (key, slot) of the previous device-side call: its buffers' release event is recorded by the next one
         self.prefetch = False         # opt-in: draw step i+1's words during step i (private stream, fixed shapes)
 
     def __del__(self):
@@ -99,16 +100,30 @@ class NegativeSampler:
         if key not in self._ring:
             self._ring[key] = [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
             self._dev_ring[key] = [torch.empty(2 * n, dtype=torch.int32, device=device) for _ in range(self.RING)]
+            self._ext_ring[key] = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(self.RING)]
             self._events[key] = [None] * self.RING
             self._prefetched = None
         ring, dev_ring, events = self._ring[key], self._dev_ring[key], self._events[key]
+        # The buffers of the PREVIOUS call's slot are free again once everything enqueued since -- that call's expansion and the
+        # criterion kernels that read its index tensor -- has run: marked here, one call later, on the stream those kernels are on.
+        if self._last is not None and self._last[0] in self._events:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            self._events[self._last[0]][self._last[1]] = ev
         slot = self._slot % self.RING
         self._slot += 1
         host = ring[slot]
-        if self._prefetched == (key, slot):
-            # drawn AND uploaded (on the worker's own stream) while the GPU was busy with the previous step
+        shape = (batch, seq_len, window, n_neg)
+        if self._prefetched is not None and self._prefetched[:2] == (key, slot):
+            # drawn, uploaded AND expanded (on the worker's own stream) while the GPU was busy with the previous step: the index
+            # tensor is one of RING buffers, valid until RING - 1 further calls (prefetch is the caller's opt-in)
             check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")
-            raw = dev_ring[slot]
+            if self._prefetched[2] == shape:
+                ext = self._ext_ring[key][slot]
+            else:                              # (the same number of words for another shape: the words are right, the expansion is not)
+                ext = torch.empty(n, dtype=torch.int32, device=device)
+                check(self._lib.cpc_negidx_expand(ptr(dev_ring[slot]), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
+                      "negidx_expand")
         else:
             if events[slot] is not None:
                 events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
@@ -118,12 +133,10 @@ class NegativeSampler:
                 self._push_torch_state(st)
             raw = dev_ring[slot]
             raw.copy_(host, non_blocking=True)
-        ext = torch.empty(n, dtype=torch.int32, device=device)
-        check(self._lib.cpc_negidx_expand(ptr(raw), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
-              "negidx_expand")
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        events[slot] = ev
+            ext = torch.empty(n, dtype=torch.int32, device=device)
+            check(self._lib.cpc_negidx_expand(ptr(raw), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
+                  "negidx_expand")
+        self._last = (key, slot)
         self._prefetched = None
         if self.prefetch and not self.follow_torch:
             # private stream: draw the NEXT step's words now, on the library's worker thread (the caller promises
@@ -132,9 +145,9 @@ class NegativeSampler:
             if events[nslot] is not None:
                 events[nslot].synchronize()
             dev_index = device.index if device.index is not None else torch.cuda.current_device()
-            check(self._lib.cpc_mt_draw_device_async(self._h, ptr(ring[nslot]), ptr(dev_ring[nslot]), 2 * n, dev_index),
-                  "mt_draw_device_async")
-            self._prefetched = (key, nslot)
+            check(self._lib.cpc_mt_draw_expand_device_async(self._h, ptr(ring[nslot]), ptr(dev_ring[nslot]), ptr(self._ext_ring[key][nslot]),
+                                                            dev_index, batch, seq_len, window, n_neg), "mt_draw_expand_device_async")
+            self._prefetched = (key, nslot, shape)
         return ext
 
 

@@ -233,6 +233,33 @@ extern "C" int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint
     return CPC_OK;
 }
 
+// The same, and the worker also EXPANDS the words into extIdx on its stream (cpc_negidx_expand): step i + 1's index tensor is
+// complete on the device before step i has ended, and nothing of the sampler is left on the training stream.
+extern "C" int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
+                                               int batch, int seq_len, int window, int n_neg)
+{
+    if (g == nullptr || raw_host == nullptr || raw_dev == nullptr || ext_dev == nullptr || batch < 1 || seq_len < 2 || window < 1 || n_neg < 1) {
+        cpc::set_error("cpc_mt_draw_expand_device_async: bad argument");
+        return CPC_ERR_INVALID;
+    }
+    const size_t n = 2 * (size_t)batch * n_neg * window;
+    cpc_negidx_wait(g);
+    g->worker = std::thread([=] {
+        draw(g, raw_host, n);
+        hipStream_t st = nullptr;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(raw_dev, raw_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        int rc = CPC_OK;
+        if (e == hipSuccess) rc = cpc_negidx_expand(raw_dev, ext_dev, batch, seq_len, window, n_neg, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st != nullptr) (void)hipStreamDestroy(st);
+        if (e != hipSuccess) cpc::set_error("cpc_mt_draw_expand_device_async: %s", hipGetErrorString(e));
+        g->worker_status = e != hipSuccess ? CPC_ERR_HIP : rc;
+    });
+    return CPC_OK;
+}
+
 // Same as cpc_negidx_sample_host but on a worker thread: returns at once, ext_idx_host is valid after
 // cpc_negidx_wait(g).  Lets the host draw step i+1's indices while the GPU is busy with step i.
 extern "C" int cpc_negidx_sample_host_async(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major,

@@ -324,6 +324,11 @@ int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
 /* ... and uploaded by the worker on its own stream (raw_host pinned): raw_dev holds the words once
  * cpc_negidx_wait returns, so no copy sits on the training stream. */
 int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device);
+/* ... and expanded there too (cpc_negidx_expand on the worker's stream): ext_dev [batch * window * n_neg] is complete once
+ * cpc_negidx_wait returns -- the two torch.randint calls AND the index arithmetic of criterion.py:247-266 for step i + 1, done
+ * while step i runs. */
+int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
+                                    int batch, int seq_len, int window, int n_neg);
 int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
                       cpc_stream_t stream);
 
