@@ -8,7 +8,8 @@ One "step" = one optimisation step of the reference's trainStep (train.py:95-113
 synthetic windows already resident in HBM: encoder on cat([past, future]) (2b windows), the context
 network on the b windows whose context train.py:102 keeps (the other half's context is sliced away
 there and its gradient is identically zero: same outputs, gradients and update -- the reference's own
-2b-window dataflow is measured beside it as `small_strict`), InfoNCE criterion, backward, gradient
+2b-window, T-frame dataflow is measured beside it as `small_strict`; a recurrent context network also
+stops after the W = T - nPredicts frames criterion.py:296 keeps), InfoNCE criterion, backward, gradient
 all-reduce (N > 1), fused Adam.
 Workload at every N: BASELINE.json configs[1] per GPU -- CPC-small (hiddenEncoder = hiddenGar = 256,
 GRU x1, nPredicts = 12, 128 negatives, linear predictors), 64 windows of 20480 samples per GPU
@@ -101,12 +102,15 @@ def gemm_nt_algorithmic_flops(b, cfg, dedup=False):
     t_len = lens[5]
     din = h
     n = ar_windows(b, cfg, dedup)                       # (the context network's share: encoder 2 passes, context network 1)
+    # (a recurrent context network only runs the W frames the criterion reads -- criterion.py:296 -- unless the reference's own
+    #  dataflow is asked for)
+    t_ar = t_len if (cfg.get("strict") or cfg["ar"] == "transformer") else t_len - cfg["npred"]
     for _layer in range(cfg["layers"]):
         if cfg["ar"] == "transformer":                # QKV(3) + Wo + lin1 + lin2 + last_linear, and their 5 dX GEMMs
             flops += 2 * (2.0 * n * t_len * (5 * h * h + 2 * h * 2048))
             launches += 12
         else:
-            flops += 2 * (2.0 * n * t_len * din * GATES[cfg["ar"]] * h)   # GI and dX
+            flops += 2 * (2.0 * n * t_ar * din * GATES[cfg["ar"]] * h)    # GI and dX
             launches += 2
         din = h
     w = t_len - cfg["npred"]
@@ -355,7 +359,8 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                                                          "reference trainStep dataflow (encoder+AR on 2b windows), " if strict else
                                                          "reference trainStep semantics: encoder on the 2b windows of cat([past, future]), "
                                                          "context network on the b context windows (train.py:102 drops the other "
-                                                         "half's context; identical outputs, gradients and update), ")
+                                                         "half's context) and, when recurrent, on the W = T - nPredicts frames the criterion "
+                                                         "reads (criterion.py:296 drops the rest); identical outputs, gradients and update, ")
                                + "fwd+bwd+allreduce+Adam",
                    "windows_per_gpu": args.batch, "global_batch": world * args.batch,
                    "parallelism": f"dp{world}", "final_losses": final_loss,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "cpc_infonce_backward": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_backward_deferred": (c_int, [c_ptr] * 11 + [c_int] * 6 + [c_ptr]),
     "cpc_infonce_join": (c_int, [c_ptr]),
+    "cpc_infonce_forward_cw": (c_int, [c_ptr] * 9 + [c_int] * 6 + [c_ptr]),
+    "cpc_infonce_backward_cw": (c_int, [c_ptr] * 11 + [c_int] * 7 + [c_ptr]),
     "cpc_infonce_forward_pred": (c_int, [c_ptr] * 8 + [c_int] * 5 + [c_ptr]),
     "cpc_infonce_backward_pred": (c_int, [c_ptr] * 9 + [c_int] * 5 + [c_ptr]),
     "cpc_flac_info": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),

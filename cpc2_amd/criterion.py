@@ -272,8 +272,8 @@ class _SplitWindows(torch.autograd.Function):
     joined here -- autograd runs this node when BOTH gradients are due, i.e. after the context network's backward."""
 
     @staticmethod
-    def forward(ctx, x, n):
-        ctx.full_shape, ctx.n = tuple(x.shape), n
+    def forward(ctx, x, n, tag):
+        ctx.full_shape, ctx.n, ctx.tag = tuple(x.shape), n, tag
         ctx.set_materialize_grads(False)
         first, rest = x[:n], x[n:]
         return first.view_as(first), rest.view_as(rest)
@@ -283,28 +283,59 @@ class _SplitWindows(torch.autograd.Function):
         n = ctx.n
         device = (g_first if g_first is not None else g_rest).device
         join_deferred(device)
-        buf = _cached_grad_buffer(ctx.full_shape, device, ("split", n))
+        buf = _cached_grad_buffer(ctx.full_shape, device, (ctx.tag, n))
         row = buf.stride(0) * buf.element_size()
         for g, part, at in ((g_first, buf[:n], 0), (g_rest, buf[n:], n)):
             if g is None:
                 part.zero_()
             elif not (g.data_ptr() == buf.data_ptr() + at * row and g.is_contiguous() and g.dtype == torch.float32):
                 part.copy_(g)
-        return buf, None
+        return buf, None, None
 
 
-def split_windows(x, n):
+def split_windows(x, n, tag="split"):
     """cpcStep's split of the encoder output [2b, T, H] into the context network's windows x[:n] and the criterion's target windows
     x[n:] (train.py:99-103 keeps exactly these: the context of the first half, the encoded data of the second).  Each part is marked
     with its home in the gradient buffer (`_cpc_grad_home`, honoured by the recurrent / transformer / criterion backward) and the
     second with `_cpc_join`: whoever consumes the gradient of `x` sits behind the join of a deferred criterion backward."""
     if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.is_contiguous() and x.dtype == torch.float32):
         return x[:n], x[n:]
-    first, rest = _SplitWindows.apply(x, n)
-    first._cpc_grad_home = (tuple(x.shape), ("split", n), 0)
-    rest._cpc_grad_home = (tuple(x.shape), ("split", n), n)
+    first, rest = _SplitWindows.apply(x, n, tag)
+    first._cpc_grad_home = (tuple(x.shape), (tag, n), 0)
+    rest._cpc_grad_home = (tuple(x.shape), (tag, n), n)
     rest._cpc_join = True
     return first, rest
+
+
+class _FirstFrames(torch.autograd.Function):
+    """x[:, :w] (the frames the criterion uses) as a contiguous tensor; the gradient goes back into x's home in the gradient buffer
+    (grad_home), whose frames w.. nobody writes: they stay zero from the buffer's allocation on (its slot is this form's own)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.home, ctx.shape, ctx.w = grad_home(x), tuple(x.shape), w
+        return x[:, :w].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.home is not None:
+            full_shape, slot, start = ctx.home
+            buf = _cached_grad_buffer(full_shape, g.device, slot)[start:start + ctx.shape[0]]
+        else:
+            buf = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        buf[:, :ctx.w].copy_(g)
+        return buf, None
+
+
+def first_frames(x, w, total):
+    """x[:, :w] of a `total`-frame sequence for a causal context network whose later frames nobody uses (criterion.py:296 keeps
+    cFeature[:, :windowSize]); the result is marked `_cpc_frames_of = total` so that the criterion knows it was handed the slice."""
+    if x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.dtype == torch.float32 and x.is_contiguous():
+        out = _FirstFrames.apply(x, w)
+    else:
+        out = x[:, :w].contiguous()
+    out._cpc_frames_of = total
+    return out
 
 
 class _DeferScope:
@@ -340,10 +371,13 @@ class _InfoNCEFn(torch.autograd.Function):
         wpred = _packed_view([w.detach() for w in wk])
         if wpred is None:
             wpred = torch.stack([f32c(w.detach()) for w in wk], dim=0)
-        b, t, dim_ar = c.shape
+        b, tc, dim_ar = c.shape
         k, dim_enc, _ = wpred.shape
-        if z.shape != (b, t, dim_enc) or wpred.shape[2] != dim_ar:
+        t = z.shape[1]
+        # c holds the t frames of the sequence, or only the W = t - k the criterion uses (criterion.py:296: cFeature[:, :windowSize])
+        if z.shape != (b, t, dim_enc) or wpred.shape[2] != dim_ar or tc not in (t, t - k):
             raise ValueError(f"shape mismatch c={tuple(c.shape)} z={tuple(z.shape)} W={tuple(wpred.shape)}")
+        ctx.cw = tc != t
         if ext_idx.dtype != torch.int32 or ext_idx.numel() != b * n_neg * (t - k):
             raise ValueError("ext_idx must be int32 [b, W, n_neg]")
         w = f32c(weights) if weights is not None else None
@@ -355,9 +389,9 @@ class _InfoNCEFn(torch.autograd.Function):
         acc = torch.empty(k, dtype=torch.float32, device=c.device)
         saved = torch.empty(nsaved, dtype=torch.uint8, device=c.device)
         sc = scratch(nscratch, c.device)
-        check(lib.cpc_infonce_forward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(losses), ptr(acc),
-                                      ptr(saved), ptr(sc), b, t, k, dim_ar, dim_enc, n_neg, stream_ptr(c.device)),
-              "infonce_forward")
+        fwd = lib.cpc_infonce_forward_cw if ctx.cw else lib.cpc_infonce_forward
+        check(fwd(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(losses), ptr(acc),
+                  ptr(saved), ptr(sc), b, t, k, dim_ar, dim_enc, n_neg, stream_ptr(c.device)), "infonce_forward")
         ctx.save_for_backward(c, z, wpred, ext_idx, w, saved)
         ctx.param_refs = wk
         ctx.dims = (b, t, k, dim_ar, dim_enc, n_neg)
@@ -395,18 +429,28 @@ class _InfoNCEFn(torch.autograd.Function):
         if defer and direct:
             join_deferred(c.device)            # (one pending backward per device)
             sc = scratch(nscratch, c.device, tag="infonce_deferred")
-            check(lib.cpc_infonce_backward_deferred(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
-                                                    ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
-                                                    stream_ptr(c.device)), "infonce_backward_deferred")
+            if ctx.cw:
+                check(lib.cpc_infonce_backward_cw(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                                  ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg, 1,
+                                                  stream_ptr(c.device)), "infonce_backward_cw")
+            else:
+                check(lib.cpc_infonce_backward_deferred(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                                        ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
+                                                        stream_ptr(c.device)), "infonce_backward_deferred")
             idx = c.device.index if c.device.index is not None else torch.cuda.current_device()
             _deferred[idx] = (c, z, wpred, ext_idx, w, dlosses, saved, sc, dz_out, dw)
             device = c.device
             torch.autograd.Variable._execution_engine.queue_callback(lambda: join_deferred(device))
         else:
             sc = scratch(nscratch, c.device)
-            check(lib.cpc_infonce_backward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
-                                           ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
-                                           stream_ptr(c.device)), "infonce_backward")
+            if ctx.cw:
+                check(lib.cpc_infonce_backward_cw(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                                  ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg, 0,
+                                                  stream_ptr(c.device)), "infonce_backward_cw")
+            else:
+                check(lib.cpc_infonce_backward(ptr(c), ptr(z), ptr(wpred), ptr(ext_idx), ptr(w), ptr(dlosses), ptr(saved),
+                                               ptr(sc), ptr(dc), ptr(dz), ptr(dw), b, t, k, dim_ar, dim_enc, n_neg,
+                                               stream_ptr(c.device)), "infonce_backward")
         if not direct:
             gw = list(dw.unbind(0))
         return (dc, dz_out, None, None, None, None) + tuple(gw)
@@ -747,6 +791,10 @@ class CPCUnsupersivedCriterion(BaseCriterion):
     def forward(self, cFeature, encodedData, label, signal_quality=None):
         batchSize, seqSize, _ = cFeature.size()
         windowSize = seqSize - self.nPredicts
+        if getattr(cFeature, "_cpc_frames_of", None) == encodedData.size(1) and seqSize == encodedData.size(1) - self.nPredicts \
+                and self.mode != "reverse":
+            # the caller (cpcStep) handed over cFeature[:, :windowSize] of a causal context network -- what :296 slices out itself
+            seqSize, windowSize = encodedData.size(1), seqSize
         # deferred backward: only inside an explicit deferred_backward() scope of the caller's whose tensor this encodedData is
         # (or is a window slice of: carry_join), and not in reverse mode (the flip is an autograd node of its own that would
         # read dz at once)

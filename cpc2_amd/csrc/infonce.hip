@@ -1098,6 +1098,7 @@ __global__ void negidx_expand_kernel(const uint32_t *raw, int32_t *ext, int b, i
 // ------------------------------------------------------------------------------------------------
 struct NceLayout {
     int b, T, K, W, Har, Henc, Nneg, lw;
+    int Pr;                             // frames per window the context (and P, dP, dc) holds: T, or W when the caller hands over c[:, :W]
     float *P, *logits, *lse;            // saved
     int32_t *ext_sorted;                // saved: the negatives of every (b,t) sorted by z-row block
     unsigned short *perm;               // saved: slot -> the caller's negative number
@@ -1118,7 +1119,7 @@ static int nce_layout(NceLayout &l, int b, int T, int K, int Har, int Henc, int 
     CPC_REQUIRE(nce_supported(Henc), "infonce: encoder dim %d not supported (32, 64, 128, 256, 512)", Henc);
     CPC_REQUIRE(b > 0 && K >= 1 && K <= 16 && T > K && Nneg >= 1 && Har >= 1,
                 "infonce: bad shape b=%d T=%d K=%d (1..16) dim_ar=%d n_neg=%d", b, T, K, Har, Nneg);
-    l.b = b; l.T = T; l.K = K; l.W = T - K; l.Har = Har; l.Henc = Henc; l.Nneg = Nneg;
+    l.b = b; l.T = T; l.K = K; l.W = T - K; l.Har = Har; l.Henc = Henc; l.Nneg = Nneg; l.Pr = T;
     l.lw = (int)cdiv(NCE_POS + Nneg, 32) * 32 + 4;
     Carver sv(saved);
     l.P = sv.take<float>((size_t)b * T * K * Henc);
@@ -1399,34 +1400,44 @@ static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t
     return CPC_OK;
 }
 
+// c_frames: frames per window of c (and of dc): T (criterion.py:296 slices c[:, :W] itself), or W = T - K when the caller hands over
+// that slice (cpcStep: the context network then only runs the W steps whose output is used)
 static int infonce_forward(const float *c, const float *z, const float *wpred, const int32_t *ext, const float *weights,
                            float *losses, float *acc, void *saved, void *scratch, int b, int T, int K, int Har, int Henc,
-                           int Nneg, hipStream_t st)
+                           int Nneg, hipStream_t st, int c_frames = 0)
 {
     NceLayout l;
     CPC_TRY(nce_layout(l, b, T, K, Har, Henc, Nneg, saved, scratch));
+    if (c_frames != 0) {
+        CPC_REQUIRE(c_frames == T || c_frames == l.W, "infonce: the context holds %d frames per window (expected %d or %d)", c_frames, T, l.W);
+        l.Pr = c_frames;
+    }
     RowMap none{};
     // all K predictors in one GEMM: P[(b,t)][k*Henc + e] = sum_a c[b,t,a] * W_k[e][a]     (criterion.py:163)
-    CPC_TRY(gemm_nt(c, Har, wpred, Har, l.P, (long)K * Henc, nullptr, (long)b * T, K * Henc, Har, none, st));
+    CPC_TRY(gemm_nt(c, Har, wpred, Har, l.P, (long)K * Henc, nullptr, (long)b * l.Pr, K * Henc, Har, none, st));
     CPC_TRY(nce_sort_negatives(l, ext, st));
     NceArgs a{};
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) a.Pk[k] = l.P + (size_t)k * Henc;
-    a.p_stride = (long)K * Henc; a.p_rows = T;
+    a.p_stride = (long)K * Henc; a.p_rows = l.Pr;
     a.p_packed = (size_t)b * T * K * Henc * sizeof(float) < (1ull << 32) ? 1 : 0;      // (32-bit byte offsets in the streaming kernel)
     return nce_launch_fwd(a, l, losses, acc, st);
 }
 
 static int infonce_backward(const float *c, const float *z, const float *wpred, const int32_t *ext, const float *weights,
                             const float *dlosses, void *saved, void *scratch, float *dc, float *dz, float *dwpred, int b, int T,
-                            int K, int Har, int Henc, int Nneg, hipStream_t st, bool defer)
+                            int K, int Har, int Henc, int Nneg, hipStream_t st, bool defer, int c_frames = 0)
 {
     NceLayout l;
     CPC_TRY(nce_layout(l, b, T, K, Har, Henc, Nneg, saved, scratch));
+    if (c_frames != 0) {
+        CPC_REQUIRE(c_frames == T || c_frames == l.W, "infonce: the context holds %d frames per window (expected %d or %d)", c_frames, T, l.W);
+        l.Pr = c_frames;
+    }
     NceArgs a{};
     nce_common(a, l, z, ext, weights);
     for (int k = 0; k < K; ++k) { a.Pk[k] = l.P + (size_t)k * Henc; a.dPk[k] = l.dP + (size_t)k * Henc; }
-    a.p_stride = (long)K * Henc; a.p_rows = T;
+    a.p_stride = (long)K * Henc; a.p_rows = l.Pr;
     a.dloss = dlosses;
     // Deferred form: only dc -- what the context network's backward waits for -- is produced on `st`.  dz (a memory-bound sum
     // over ~1 GB of contribution rows) and the predictors' weight gradients run on the side stream, beside whatever the caller
@@ -1437,7 +1448,7 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
     CPC_TRY(transpose2d(wpred, l.wt, K * Henc, Har, st));                        // [Har][K*Henc]
     RowMap none{};
     none.splitk_scratch = l.tn; none.splitk_bytes = l.tn_bytes;                  // few tiles, K = 12 H: ordered K split
-    CPC_TRY(gemm_nt(l.dP, (long)K * Henc, l.wt, (long)K * Henc, dc, Har, nullptr, (long)b * T, Har, K * Henc, none, st));
+    CPC_TRY(gemm_nt(l.dP, (long)K * Henc, l.wt, (long)K * Henc, dc, Har, nullptr, (long)b * l.Pr, Har, K * Henc, none, st));
     // dW_k[e][a] = sum_{b,t} dP[(b,t)][k*Henc + e] * c[b,t,a]
     if (late != nullptr) {
         // nothing is queued on the side stream yet: queued here, beside the product above, it took the chip from it (85 -> 280 us)
@@ -1446,7 +1457,7 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
         late->started = false; late->marked = false;
         late->pending.store(true);
     } else {
-        CPC_TRY(gemm_tn(l.dP, (long)K * Henc, c, Har, dwpred, Har, K * Henc, Har, (long)b * T, l.tn, l.tn_bytes, 0, 0, st));
+        CPC_TRY(gemm_tn(l.dP, (long)K * Henc, c, Har, dwpred, Har, K * Henc, Har, (long)b * l.Pr, l.tn, l.tn_bytes, 0, 0, st));
     }
     return CPC_OK;
 }
@@ -1474,7 +1485,7 @@ int infonce_deferred_start(hipStream_t st)
     CPC_TRY(infonce_deferred_mark(st));
     CPC_CHECK_HIP(hipStreamWaitEvent(side->stream, side->mid, 0));
     CPC_TRY(nce_launch_gather(l, side->dz, side->late_fused, side->stream));
-    CPC_TRY(gemm_tn(l.dP, (long)l.K * l.Henc, side->c, l.Har, side->dwpred, l.Har, l.K * l.Henc, l.Har, (long)l.b * l.T, l.tn_late, l.tn_bytes, 0,
+    CPC_TRY(gemm_tn(l.dP, (long)l.K * l.Henc, side->c, l.Har, side->dwpred, l.Har, l.K * l.Henc, l.Har, (long)l.b * l.Pr, l.tn_late, l.tn_bytes, 0,
                     0, side->stream));
     CPC_CHECK_HIP(hipEventRecord(side->late, side->stream));
     side->started = true;
@@ -1630,6 +1641,22 @@ extern "C" int cpc_infonce_backward_deferred(const float *c, const float *z, con
 {
     return cpc::infonce_backward(c, z, wpred, ext_idx, weights, dlosses, saved, scratch, dc, dz, dwpred, b, t, k, dim_ar, dim_enc,
                                  n_neg, static_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int cpc_infonce_forward_cw(const float *c, const float *z, const float *wpred, const int32_t *ext_idx, const float *weights,
+                                      float *losses, float *acc, void *saved, void *scratch, int b, int t, int k, int dim_ar,
+                                      int dim_enc, int n_neg, cpc_stream_t stream)
+{
+    return cpc::infonce_forward(c, z, wpred, ext_idx, weights, losses, acc, saved, scratch, b, t, k, dim_ar, dim_enc, n_neg,
+                                static_cast<hipStream_t>(stream), t - k);
+}
+
+extern "C" int cpc_infonce_backward_cw(const float *c, const float *z, const float *wpred, const int32_t *ext_idx, const float *weights,
+                                       const float *dlosses, void *saved, void *scratch, float *dc, float *dz, float *dwpred, int b,
+                                       int t, int k, int dim_ar, int dim_enc, int n_neg, int deferred, cpc_stream_t stream)
+{
+    return cpc::infonce_backward(c, z, wpred, ext_idx, weights, dlosses, saved, scratch, dc, dz, dwpred, b, t, k, dim_ar, dim_enc,
+                                 n_neg, static_cast<hipStream_t>(stream), deferred != 0, t - k);
 }
 
 extern "C" int cpc_infonce_join(cpc_stream_t stream) { return cpc::infonce_join(static_cast<hipStream_t>(stream)); }

@@ -233,6 +233,10 @@ extern "C" int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint
     return CPC_OK;
 }
 
+// (cpc_negidx_expand lives in the device half of the library; a host-only build of this file -- the sanitizer test -- links without it)
+extern "C" int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
+                                 cpc_stream_t stream) __attribute__((weak));
+
 // The same, and the worker also EXPANDS the words into extIdx on its stream (cpc_negidx_expand): step i + 1's index tensor is
 // complete on the device before step i has ended, and nothing of the sampler is left on the training stream.
 extern "C" int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
@@ -242,6 +246,7 @@ extern "C" int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_hos
         cpc::set_error("cpc_mt_draw_expand_device_async: bad argument");
         return CPC_ERR_INVALID;
     }
+    if (cpc_negidx_expand == nullptr) { cpc::set_error("cpc_mt_draw_expand_device_async: built without the device kernels"); return CPC_ERR_HIP; }
     const size_t n = 2 * (size_t)batch * n_neg * window;
     cpc_negidx_wait(g);
     g->worker = std::thread([=] {

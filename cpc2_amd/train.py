@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join, first_windows, split_windows
+from .criterion import CPCUnsupersivedCriterion, NoneCriterion, carry_join, first_frames, first_windows, split_windows
 from .model import CPCAR, CPCEncoder, CPCModel, join_tail
 
 
@@ -439,6 +439,21 @@ def _guard_cooperative_kernels(cpcModel, cpcCriterion):
         _lib.load().cpc_coop_set_policy(1)
 
 
+def _context_frames_only(cpcModel, cpcCriterion, frames):
+    """May the context network stop after the W = frames - nPredicts steps whose output the criterion reads?  criterion.py:296 keeps
+    `cFeature[:, :windowSize]`; a context network that is CAUSAL in time (the recurrent ones, forward direction) and keeps no state
+    across calls computes those W frames without the nPredicts behind them, and their gradient is identically zero -- the same
+    argument as for the context windows, on the time axis.  Returns W, or 0."""
+    import os
+    if os.environ.get("CPC_STRICT_FRAMES") or type(cpcCriterion) is not CPCUnsupersivedCriterion or cpcCriterion.mode == "reverse":
+        return 0
+    ar = cpcModel.gAR
+    if not isinstance(ar, CPCAR) or ar.reverse or ar.keepHidden or ar.hidden is not None:
+        return 0
+    w = frames - cpcCriterion.nPredicts
+    return w if w >= 1 else 0
+
+
 def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, dedup=False, dp=None, strict=False):
     """train.py:95-108: model on cat([past, future]); context from the past half, targets from the
     future half; returns (totLoss, allLosses [1,K], allAcc [1,K]).
@@ -465,8 +480,16 @@ def cpcStep(past, future, label, cpcModel, cpcCriterion, signal_quality=None, de
         with _ar_scope(cpcModel):
             # (train.py:99's cat([past, future]) as two pointers: only the first layer reads the waveform)
             encoded_full = cpcModel.gEncoder.forward_channel_last(past, future)      # [2b, T, H]
-            context_in, encoded_data = split_windows(encoded_full, b)
-            c_feature = cpcModel.gAR(context_in)                                      # [b, T, H]: train.py:102's c_feature[:b]
+            frames = encoded_full.size(1)
+            w = _context_frames_only(cpcModel, cpcCriterion, frames)
+            if w:
+                # ... and only over the W frames criterion.py:296 keeps of it (a causal recurrent network: _context_frames_only)
+                context_in, encoded_data = split_windows(encoded_full, b, tag=("split_w", w))
+                c_feature = cpcModel.gAR(first_frames(context_in, w, frames))         # [b, W, H]
+                c_feature._cpc_frames_of = frames
+            else:
+                context_in, encoded_data = split_windows(encoded_full, b)
+                c_feature = cpcModel.gAR(context_in)                                  # [b, T, H]: train.py:102's c_feature[:b]
         if dp is not None:
             dp.attach(encoded_full)
         with _defer_scope(cpcCriterion, encoded_data):

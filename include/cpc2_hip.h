@@ -378,6 +378,17 @@ int cpc_infonce_backward_deferred(const float *c, const float *z, const float *w
                                   float *dc, float *dz, float *dwpred, int b, int t, int k, int dim_ar,
                                   int dim_enc, int n_neg, cpc_stream_t stream);
 int cpc_infonce_join(cpc_stream_t stream);
+/* The same criterion when the caller hands over ONLY the W = t - k context frames it uses: c and dc are [b, t - k, dim_ar] (z stays
+ * [b, t, dim_enc]).  criterion.py:296 slices `cFeature[:, :windowSize]` itself; a causal context network that keeps no state across
+ * calls need not compute the k frames behind it (cpc2_amd.train.cpcStep runs it on W steps and calls these).  deferred != 0: the
+ * deferred form of the backward (cpc_infonce_backward_deferred). */
+int cpc_infonce_forward_cw(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
+                           const float *weights, float *losses, float *acc, void *saved, void *scratch,
+                           int b, int t, int k, int dim_ar, int dim_enc, int n_neg, cpc_stream_t stream);
+int cpc_infonce_backward_cw(const float *c, const float *z, const float *wpred, const int32_t *ext_idx,
+                            const float *weights, const float *dlosses, void *saved, void *scratch,
+                            float *dc, float *dz, float *dwpred, int b, int t, int k, int dim_ar,
+                            int dim_enc, int n_neg, int deferred, cpc_stream_t stream);
 
 /* The same criterion when the K predictions come from predictor MODULES instead of linear maps
  * (rnnMode="transformer": criterion.py:136-143; the predictions are produced by cpc_transformer_*):

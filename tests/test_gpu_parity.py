@@ -1758,9 +1758,10 @@ def _step_model(hidden, layers, mode, nneg, seed=3):
                                                           ("transformer_x2", 256, 2, "transformer", 3, 32), ("gru_64", 64, 1, "GRU", 3, 16),
                                                           ("rnn", 256, 1, "RNN", 4, 32), ("gru_many", 256, 1, "GRU", 40, 32)])
 def test_context_network_on_the_context_windows_only_is_the_reference_step(name, hidden, layers, mode, b, nneg):
-    """train.py:99-103 keeps c_feature[:b] and encoded_data[b:] of the model's 2b-window outputs.  cpcStep's default form runs the
-    context network on the b context windows only; `strict=True` is the reference's own dataflow (CPCModel.forward on all 2b
-    windows).  With past != future, three Adam steps (transformer: dropout 0.1 on, the masks are keyed by element position):
+    """train.py:99-103 keeps c_feature[:b] and encoded_data[b:] of the model's 2b-window outputs, criterion.py:296 the first
+    W = T - nPredicts frames of that context.  cpcStep's default form runs the context network on the b context windows only and,
+    when it is recurrent, over those W frames only; `strict=True` is the reference's own dataflow (CPCModel.forward on all 2b
+    windows, T frames).  With past != future, three Adam steps (transformer: dropout 0.1 on, the masks are keyed by element position):
     losses, every gradient and the parameters agree -- bit for bit where the row count does not change a K split or a
     summation order, else to rounding (2e-6 of scale; parameters within 2 % of the distance Adam moved them)."""
     lr, steps = 2e-4, 3
@@ -1849,9 +1850,22 @@ def test_context_windows_only_form_matches_strict_along_a_trajectory_at_full_bat
 def test_context_windows_only_form_is_refused_where_it_would_change_the_observable():
     """The reduced dataflow is cpcStep's own and only for the bare CPCModel without state across calls: span masking (numpy draws
     over all 2b rows), keepHidden (the stored state covers 2b windows) and any wrapper keep the reference's 2b-window call."""
-    from cpc2_amd.train import _context_windows_only
+    from cpc2_amd.train import _context_frames_only, _context_windows_only
+    from cpc2_amd.transformers import buildTransformerAR
     hidden = 64
     enc = cpc2_amd.CPCEncoder(hidden)
+    # the time axis (criterion.py:296 keeps cFeature[:, :windowSize]): only a causal recurrent network without carried state stops
+    # after the W frames the criterion reads; a reversed one, the transformer (its blocks are padded to sizeSeq anyway), a criterion
+    # in reverse mode or a wrapped one keep all T frames
+    crit12 = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 16, rnnMode="linear", sizeInputSeq=128)
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1)), crit12, 128) == 116
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 2, mode="LSTM")), crit12, 128) == 116
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1, reverse=True)), crit12, 128) == 0
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, True, 1)), crit12, 128) == 0
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, buildTransformerAR(hidden, hidden, 1, 128, False)), crit12, 128) == 0
+    rev = cpc2_amd.CPCUnsupersivedCriterion(12, hidden, hidden, 16, mode="reverse", rnnMode="linear", sizeInputSeq=128)
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1)), rev, 128) == 0
+    assert _context_frames_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1)), torch.nn.DataParallel(crit12), 128) == 0
     assert _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 1)))
     assert _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, False, 2, mode="LSTM")))
     assert not _context_windows_only(cpc2_amd.CPCModel(enc, cpc2_amd.CPCAR(hidden, hidden, True, 1)))
