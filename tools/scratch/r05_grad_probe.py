@@ -7,6 +7,8 @@ import bench
 from cpc2_amd.train import backward, cpcStep
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 61
 cfg = bench.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "small"]
+lead_strict = len(sys.argv) > 3 and sys.argv[3] == "strict"      # the trajectory is the STRICT form's, the default form is evaluated beside it
+every = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 dev = torch.device("cuda:0")
 mA, cA, oA = bench.build(cfg, dev)
 mB, cB, oB = bench.build(cfg, dev)
@@ -17,13 +19,13 @@ names = [n for n, _ in list(cA.named_parameters()) + list(mA.named_parameters())
 for step in range(steps):
     cA.seed(5000 + step)
     torch.manual_seed(step)                  # (a transformer layer draws its dropout seed from torch's CPU generator)
-    tot, lA, _ = cpcStep(x, x, label, mA, cA)
+    tot, lA, _ = cpcStep(x, x, label, mA, cA, strict=lead_strict)
     backward(tot)
-    if step % 20 == 0:
+    if step % every == 0:
         oB.flat.copy_(oA.flat)
         cB.seed(5000 + step)
         torch.manual_seed(step)
-        totB, lB, _ = cpcStep(x, x, label, mB, cB, strict=True)
+        totB, lB, _ = cpcStep(x, x, label, mB, cB, strict=not lead_strict)
         backward(totB)
         torch.cuda.synchronize()
         worst, wname = 0.0, ""
@@ -33,7 +35,7 @@ for step in range(steps):
             e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
             if e > worst:
                 worst, wname = e, name
-        print("step %3d: loss default %.5f strict %.5f (max rel diff %.2e); worst gradient difference %.2e of its tensor's scale (%s); |grad| %.3e"
+        print("step %3d: loss (trajectory form) %.5f (other form) %.5f (max rel diff %.2e); worst gradient difference %.2e of its tensor's scale (%s); |grad| %.3e"
               % (step, float(lA.mean()), float(lB.mean()), float(((lA - lB).abs() / lB.abs()).max()), worst, wname, float(oB.flat_grad.abs().max())))
         oB.zero_grad()
     oA.step(); oA.zero_grad()
