@@ -314,6 +314,70 @@ def criterion_forward(c, z, predictors, ext_idx, n_neg, mode=None, n_skipped=0, 
     return torch.cat(losses, dim=1), torch.cat(accs, dim=1) / (w_len * b)
 
 
+def criterion_forward_sparse(c, z, predictors, ext_idx, n_neg, mode=None, n_skipped=0, weights=None, dlosses=None,
+                             windows_per_chunk=8):
+    """The same criterion (criterion.py:237-286 sampleClean, :144-171 linear predictors + mean-dot, :329-363 CE / acc) with its
+    gradients written out by hand, for batch sizes at which the dense restatement above (K tensors [b, 1+n, W, H] under autograd)
+    does not fit: the negatives are gathered once per chunk of windows, every step k reuses them (criterion.py:267-284: one
+    draw serves all K), dz collects the contributions of the negatives by index_add_.  Computes in the dtype of z (use float64).
+
+    dlosses [K - n_skipped]: gradient of the returned losses (default ones = `losses.sum().backward()`, train.py:108).
+    Returns dict(losses [1, K-s], acc [1, K-s], dc like c, dz like z, dW list of K [Henc, Har])."""
+    if mode == "reverse":            # criterion.py:292-294
+        z, c = torch.flip(z, [1]), torch.flip(c, [1])
+    c, z = c.detach(), z.detach()
+    b, t_len, h_enc = z.shape
+    k_steps = len(predictors)
+    w_len = t_len - k_steps
+    dt = z.dtype
+    idx = torch.as_tensor(np.asarray(ext_idx), dtype=torch.long).view(b, n_neg, w_len)   # criterion.py:263-265
+    wts = (torch.ones(b * w_len, dtype=dt) if weights is None else weights.to(dt)).view(b, w_len)
+    g_loss = torch.zeros(k_steps, dtype=dt)
+    g_loss[n_skipped:] = 1.0 if dlosses is None else torch.as_tensor(dlosses, dtype=dt).reshape(-1)
+    preds_w = [p.detach().to(dt) for p in predictors]
+    zflat = z.reshape(-1, h_enc)
+    loss = torch.zeros(k_steps, dtype=dt)
+    hits = torch.zeros(k_steps, dtype=dt)
+    dc = torch.zeros_like(c)
+    dz = torch.zeros_like(z)
+    dzflat = dz.view(-1, h_enc)
+    dws = [torch.zeros_like(p) for p in preds_w]
+    scale = 1.0 / (b * w_len)        # torch.mean over the b * W rows (criterion.py:349)
+    rows = torch.arange(b).view(b, 1) * t_len + torch.arange(w_len).view(1, w_len)       # flat z row of frame t of window b
+    for lo in range(0, b, windows_per_chunk):
+        hi = min(b, lo + windows_per_chunk)
+        neg = zflat[idx[lo:hi].reshape(-1)].view(hi - lo, n_neg, w_len, h_enc)           # criterion.py:266
+        g_neg = torch.zeros_like(neg)
+        cw = c[lo:hi, :w_len]
+        for k in range(1, k_steps + 1):
+            wk = preds_w[k - 1]
+            pred = cw @ wk.t()                                                           # [cb, W, Henc]
+            pos = z[lo:hi, k:k + w_len]
+            s_pos = (pred * pos).sum(-1) / h_enc                                         # mean over features, criterion.py:171
+            s_neg = torch.einsum("bwh,bnwh->bwn", pred, neg) / h_enc
+            # a negative that IS the positive's row scores the same bit for bit in the reference (one product, one mean), and
+            # max(1) then answers 0 (criterion.py:356); two summation orders here would decide that tie by rounding
+            same = idx[lo:hi].permute(0, 2, 1) == (rows[lo:hi] + k).unsqueeze(-1)
+            s_neg = torch.where(same, s_pos.unsqueeze(-1), s_neg)
+            logits = torch.cat([s_pos.unsqueeze(-1), s_neg], dim=-1)                     # positive first = label 0
+            lse = torch.logsumexp(logits, dim=-1)
+            loss[k - 1] += (wts[lo:hi] * (lse - s_pos)).sum() * scale
+            hits[k - 1] += (s_pos >= s_neg.max(dim=-1).values).sum()
+            d_logits = torch.exp(logits - lse.unsqueeze(-1))
+            d_logits[..., 0] -= 1.0
+            d_logits *= (g_loss[k - 1] * scale * wts[lo:hi]).unsqueeze(-1) / h_enc
+            d_pos, d_neg = d_logits[..., 0], d_logits[..., 1:]
+            d_pred = d_pos.unsqueeze(-1) * pos + torch.einsum("bwn,bnwh->bwh", d_neg, neg)
+            dz[lo:hi, k:k + w_len] += d_pos.unsqueeze(-1) * pred
+            g_neg += d_neg.permute(0, 2, 1).unsqueeze(-1) * pred.unsqueeze(1)
+            dc[lo:hi, :w_len] += d_pred @ wk
+            dws[k - 1] += d_pred.reshape(-1, h_enc).t() @ cw.reshape(-1, cw.shape[-1])
+        dzflat.index_add_(0, idx[lo:hi].reshape(-1), g_neg.view(-1, h_enc))
+    if mode == "reverse":
+        dc, dz = torch.flip(dc, [1]), torch.flip(dz, [1])
+    return {"losses": loss[n_skipped:].view(1, -1), "acc": (hits[n_skipped:] * scale).view(1, -1), "dc": dc, "dz": dz, "dW": dws}
+
+
 def candidates(z, ext_idx, n_neg, k_steps):
     """sampleClean (criterion.py:237-286) given the indices: K tensors [b, 1 + n_neg, W, Henc], positive first."""
     b, t_len, h_enc = z.shape

@@ -1064,6 +1064,93 @@ def test_device_index_expansion_and_prefetch_are_bit_exact():
         assert torch.equal(p.sample(b, t_len, t_len - k, nn, torch.device(DEV)).cpu(), want)
 
 
+_FULL_BATCH_ORACLE = {}
+
+
+def _full_batch_criterion_case(h, nn):
+    """Inputs and the sparse fp64 oracle's outputs of the criterion at b = 64 (C2: the very case of golden g18; C5 per GPU)."""
+    if (h, nn) not in _FULL_BATCH_ORACLE:
+        b, t_len, k, seed, pseed = 64, 128, 12, 4321, 160
+        cp = synth.predictor_params(k, h, h, seed=pseed, scale=2.0)              # trained-scale predictors
+        c = synth.features((b, t_len, h), pseed + 1)
+        z = synth.features((b, t_len, h), pseed + 2, relu=True)
+        _, _, ext = negative_indices(MT19937(seed), b, t_len, t_len - k, nn)
+        dl = torch.linspace(0.5, 1.5, k, dtype=torch.float64)
+        ones = O.criterion_forward_sparse(c.double(), z.double(), O.predictor_list({n: v.double() for n, v in cp.items()}, k), ext, nn)
+        ramp = O.criterion_forward_sparse(c.double(), z.double(), O.predictor_list({n: v.double() for n, v in cp.items()}, k), ext, nn,
+                                          dlosses=dl)
+        ext_tm = torch.as_tensor(np.asarray(ext).reshape(b, nn, t_len - k).transpose(0, 2, 1).copy(), dtype=torch.int32)
+        _FULL_BATCH_ORACLE[(h, nn)] = (cp, c, z, ext_tm, dl, ones, ramp)
+    return _FULL_BATCH_ORACLE[(h, nn)]
+
+
+@pytest.mark.parametrize("h,nn", [(256, 128), (512, 256)])
+def test_criterion_at_full_batch_vs_oracle_module_call(golden, h, nn):
+    """The criterion's kernels at the launch geometry of the benchmark -- b = 64: 7 424 (b,t) items, 950 272 / 1 900 544
+    references in the counting-sorted dz lists, 8 192 z rows -- against the sparse fp64 oracle, EVERY element of every gradient
+    (criterion.py:237-286, 329-363); predictors at trained scale, so a wrong gather row or a dropped reference shows.  At C2 the
+    oracle is itself pinned to the reference's own b = 64 run (g18, tests/test_oracle_golden.py) and the kernels are compared with
+    that golden directly as well.  This is the module call: the immediate backward, T context frames, indices from the sampler."""
+    cp, c, z, _ext, _dl, ref, _ = _full_batch_criterion_case(h, nn)
+    b, t_len, k = 64, 128, 12
+    crit = cpc2_amd.CPCUnsupersivedCriterion(k, h, h, nn, rnnMode="linear", sizeInputSeq=t_len)
+    crit.load_state_dict(cp)
+    crit = crit.to(DEV)
+    cd, zd = c.to(DEV).requires_grad_(True), z.to(DEV).requires_grad_(True)
+    torch.manual_seed(4321)                     # the reference drew its negatives from this CPU stream
+    losses, acc = crit(cd, zd, None)
+    losses.sum().backward()
+    assert_close(losses, ref["losses"], 1e-5, "losses")
+    assert torch.allclose(acc.cpu().double(), ref["acc"], atol=2.5 / (b * (t_len - k)))
+    assert_close(cd.grad, ref["dc"], 1e-4, "dc, all elements")
+    assert_close(zd.grad, ref["dz"], 1e-4, "dz, all elements")
+    for i in range(k):
+        assert_close(crit.wPrediction.predictors[i].weight.grad, ref["dW"][i], 2e-4, f"dW{i}, all elements")
+    if (h, nn) == (256, 128):
+        g = golden("g18_criterion_b64.npz")
+        assert_close(losses, t(g["losses"]), 1e-5, "losses vs the reference's b = 64 run")
+        assert_close(zd.grad[::9, ::5, ::37], t(g["dz_sample"]), 1e-4, "dz sample vs reference")
+        assert_close(cd.grad[::9, ::5, ::37], t(g["dc_sample"]), 1e-4, "dc sample vs reference")
+        assert_close(zd.grad[:, -14:, :8], t(g["dz_tail"]), 1e-4, "dz tail vs reference")
+        for i in range(k):
+            assert_close(crit.wPrediction.predictors[i].weight.grad[::17, ::13], t(g[f"dW{i}_sample"]), 2e-4, f"dW{i} sample vs reference")
+
+
+@pytest.mark.parametrize("deferred", [0, 1])
+@pytest.mark.parametrize("h,nn", [(256, 128), (512, 256)])
+def test_criterion_at_full_batch_vs_oracle_step_form(h, nn, deferred):
+    """The form cpcStep runs (cpc_infonce_forward_cw / backward_cw: the context handed over as its W frames; deferred = 1: dz and
+    the predictor gradients on the library's side stream, joined afterwards) at b = 64 against the sparse fp64 oracle, with a
+    non-uniform gradient of the losses."""
+    lib = _lib.load()
+    cp, c, z, ext_tm, dl, _, ref = _full_batch_criterion_case(h, nn)
+    b, t_len, k = 64, 128, 12
+    w_len = t_len - k
+    cw = c[:, :w_len].contiguous().to(DEV)
+    zd, ext = z.to(DEV), ext_tm.to(DEV)
+    wpred = torch.stack([cp[f"wPrediction.predictors.{i}.weight"] for i in range(k)]).to(DEV)
+    dld = dl.float().to(DEV)
+    st = _lib.stream_ptr(cw.device)
+    saved = torch.empty(lib.cpc_infonce_saved_bytes(b, t_len, k, h, h, nn), dtype=torch.uint8, device=DEV)
+    scr = torch.empty(lib.cpc_infonce_scratch_bytes(b, t_len, k, h, h, nn), dtype=torch.uint8, device=DEV)
+    losses, acc = torch.empty(k, device=DEV), torch.empty(k, device=DEV)
+    _lib.check(lib.cpc_infonce_forward_cw(_lib.ptr(cw), _lib.ptr(zd), _lib.ptr(wpred), _lib.ptr(ext), None, _lib.ptr(losses), _lib.ptr(acc),
+                                          _lib.ptr(saved), _lib.ptr(scr), b, t_len, k, h, h, nn, st), "fwd")
+    dc, dz, dw = torch.full_like(cw, float("nan")), torch.full_like(zd, float("nan")), torch.full_like(wpred, float("nan"))
+    _lib.check(lib.cpc_infonce_backward_cw(_lib.ptr(cw), _lib.ptr(zd), _lib.ptr(wpred), _lib.ptr(ext), None, _lib.ptr(dld), _lib.ptr(saved),
+                                           _lib.ptr(scr), _lib.ptr(dc), _lib.ptr(dz), _lib.ptr(dw), b, t_len, k, h, h, nn, deferred, st), "bwd")
+    if deferred:
+        _lib.check(lib.cpc_infonce_join(st), "join")
+    torch.cuda.synchronize()
+    _lib.check(lib.cpc_async_error_check(st), "async errors")
+    assert_close(losses.view(1, -1), ref["losses"], 1e-5, "losses")
+    assert torch.allclose(acc.cpu().double().view(1, -1), ref["acc"], atol=2.5 / (b * w_len))
+    assert_close(dc, ref["dc"][:, :w_len], 1e-4, "dc, all elements")
+    assert_close(dz, ref["dz"], 1e-4, "dz, all elements")
+    for i in range(k):
+        assert_close(dw[i], ref["dW"][i], 2e-4, f"dW{i}, all elements")
+
+
 @pytest.mark.parametrize("h,nn", [(256, 128), (512, 256)])
 def test_criterion_properties_at_full_size(h, nn):
     """b=64 (BASELINE configs C2 and, hidden 512 / 256 negatives, C5 per GPU): untrained-predictor loss is ln(1+Nneg) for every

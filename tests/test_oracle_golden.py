@@ -228,6 +228,79 @@ def test_criterion_full_shapes(golden):
         assert torch.allclose(w[:4, :8], t(g[f"dW{i}_head"]), atol=1e-8, rtol=1e-4)
 
 
+def _sparse_vs(ref_losses, ref_acc, ref_dc, ref_dz, ref_dw, got, tol):
+    def close(a, b_, what):
+        err = float((a.double() - b_.double()).abs().max() / (b_.double().abs().max() + 1e-300))
+        assert err <= tol, f"{what}: {err:.2e}"
+    close(got["losses"], ref_losses, "losses")
+    close(got["acc"], ref_acc, "acc")
+    close(got["dc"], ref_dc, "dc")
+    close(got["dz"], ref_dz, "dz")
+    for i, w in enumerate(ref_dw):
+        if w is None or float(w.abs().max()) == 0.0:
+            assert float(got["dW"][i].abs().max()) == 0.0
+        else:
+            close(got["dW"][i], w, f"dW{i}")
+
+
+@pytest.mark.parametrize("tag", ["plain", "skip", "reverse", "quality", "rect", "many_negatives", "full_b8"])
+def test_sparse_criterion_is_the_dense_one(golden, tag):
+    """oracle.criterion_forward_sparse (hand-written gradients, negatives gathered per chunk of windows: the checker of the HIP
+    criterion at b = 64) against the autograd restatement that the goldens above pin, in float64, chunk sizes that do not
+    divide the batch."""
+    kw = dict(b=4, t_len=32, har=32, henc=32, k=4, nn=16, seed=99, pseed=50)
+    okw = {}
+    if tag == "skip":
+        okw["n_skipped"] = 1
+    if tag == "reverse":
+        okw["mode"] = "reverse"
+    if tag == "rect":
+        kw["har"] = 24
+    if tag == "quality":
+        okw["weights"] = O.quality_weights(t(golden("g5_criterion_small.npz")["quality_signal"]).double(), 2.0, 0.1, 28)
+    if tag == "many_negatives":
+        kw = dict(b=5, t_len=33, har=128, henc=128, k=7, nn=129, seed=7, pseed=3)
+    if tag == "full_b8":
+        kw = dict(b=8, t_len=128, har=256, henc=256, k=12, nn=128, seed=1234, pseed=60)
+    b, t_len, k, nn = kw["b"], kw["t_len"], kw["k"], kw["nn"]
+    p = {n: v.double().requires_grad_(True) for n, v in synth.predictor_params(k, kw["har"], kw["henc"], seed=kw["pseed"], scale=4.0).items()}
+    c = synth.features((b, t_len, kw["har"]), kw["pseed"] + 1).double().requires_grad_(True)
+    z = synth.features((b, t_len, kw["henc"]), kw["pseed"] + 2, relu=True).double().requires_grad_(True)
+    _, _, ext = negative_indices(MT19937(kw["seed"]), b, t_len, t_len - k, nn)
+    losses, acc = O.criterion_forward(c, z, O.predictor_list(p, k), ext, nn, **okw)
+    dl = torch.linspace(0.5, 1.5, losses.shape[1], dtype=torch.float64)           # (a non-uniform gradient of the losses)
+    (losses * dl).sum().backward()
+    got = O.criterion_forward_sparse(c, z, O.predictor_list(p, k), ext, nn, dlosses=dl, windows_per_chunk=3, **okw)
+    _sparse_vs(losses.detach(), acc, c.grad, z.grad, [p[f"wPrediction.predictors.{i}.weight"].grad for i in range(k)], got, 1e-12)
+
+
+def test_sparse_criterion_at_full_batch_vs_reference_golden(golden):
+    """g18: the reference's criterion at b = 64 (BASELINE configs[1]: T 128, H 256, K 12, 128 negatives), predictors at trained
+    scale.  The reference ran in float32; the sparse oracle in float64 agrees with its losses to 1e-6 and with every stored
+    gradient element (heads, tails, a strided sample) and digest to float32 rounding."""
+    g = golden("g18_criterion_b64.npz")
+    b, t_len, har, henc, k, nn, seed, pseed = (int(v) for v in g["cfg"])
+    p = {n: v.double() for n, v in synth.predictor_params(k, har, henc, seed=pseed, scale=float(g["scale"])).items()}
+    c = synth.features((b, t_len, har), pseed + 1).double()
+    z = synth.features((b, t_len, henc), pseed + 2, relu=True).double()
+    _, _, ext = negative_indices(MT19937(seed), b, t_len, t_len - k, nn)
+    got = O.criterion_forward_sparse(c, z, O.predictor_list(p, k), ext, nn)
+    assert torch.allclose(got["losses"], t(g["losses"]).double(), atol=0, rtol=2e-6)
+    assert torch.allclose(got["acc"], t(g["acc"]).double(), atol=2.5 / (b * (t_len - k)))          # float32 argmax ties
+    for name in ("dc", "dz"):
+        ten = got[name]
+        scale = float(ten.abs().max())
+        for part, view in (("head", ten[:, :3, :8]), ("tail", ten[:, -14:, :8]), ("sample", ten[::9, ::5, ::37])):
+            assert torch.allclose(view, t(g[f"{name}_{part}"]).double(), atol=2e-6 * scale, rtol=1e-4), (name, part)
+        assert abs(float(ten.abs().sum()) - float(g[f"{name}_abs"])) <= 1e-5 * float(g[f"{name}_abs"])
+        assert abs(float(ten.sum()) - float(g[f"{name}_sum"])) <= 1e-5 * float(g[f"{name}_abs"])
+    assert float(got["dc"][:, t_len - k:].abs().max()) == 0.0
+    for i in range(k):
+        w = got["dW"][i]
+        assert torch.allclose(w[::17, ::13], t(g[f"dW{i}_sample"]).double(), atol=2e-6 * float(w.abs().max()), rtol=1e-4)
+        assert abs(float(w.abs().sum()) - float(g[f"dW{i}_abs"])) <= 1e-5 * float(g[f"dW{i}_abs"])
+
+
 # ----------------------------------------------------------------------------- G6
 def test_train_steps_loss_curve(golden):
     g = golden("g6_trainsteps.npz")
