@@ -28,6 +28,21 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Eight hardware queues per priority instead of the runtime's four (read when HIP initialises, i.e. at the first GPU call): the
+# library places its own streams on queues it has TESTED to run beside the training stream's, but RCCL's stream is torch's to pick,
+# and with four queues it shares the training stream's one time in four (profiles/r06_process_group_queues.md).  No effect on the
+# one-GPU step (profiles/r06_ab_hw_queues_8.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+# CPC_BENCH_PIN_CORES=n: run this process (and every thread it starts: the sampler's worker, RCCL's proxy and watchdog) on the first
+# n cores of its affinity mask -- the CPU share a rank gets when eight ranks share one host.  Before any GPU call, in-process (not
+# `taskset`: under a profiler that would be an exec behind an initialised GPU).
+PINNED_CORES = None
+if os.environ.get("CPC_BENCH_PIN_CORES"):
+    _cores = sorted(os.sched_getaffinity(0))[:max(1, int(os.environ["CPC_BENCH_PIN_CORES"]))]
+    os.sched_setaffinity(0, _cores)
+    PINNED_CORES = len(_cores)
+
 T_START = time.perf_counter()
 WINDOW = 20480
 SECONDS_PER_WINDOW = WINDOW / 16000.0
@@ -296,11 +311,42 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         lib.cpc_prof_enable(2 if roof == "gemm_planes_nt" else 3)   # the roofline kernel only inside the timed region
     torch.cuda.synchronize()
     dp.timing_reset()
+    # what a step costs the HOST, and whether any one step stands out: one event per step on the compute stream (a barrier packet,
+    # ~1 us), the host's clocks around step(), the seconds the host spent blocked by cause (cpc2_amd._lib.HOST_WAITS)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    _lib.HOST_WAITS.clear()
+    enqueue_s = 0.0
+    cpu0, thr0 = time.process_time(), time.thread_time()
+    marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        ta = time.perf_counter()
         losses = step()
+        enqueue_s += time.perf_counter() - ta
+        marks[i + 1].record()
+    t_enqueued = time.perf_counter() - t0
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0                  # this rank's own clock (before the closing barrier)
+    cpu_s, thr_s = time.process_time() - cpu0, time.thread_time() - thr0
+    waits = dict(_lib.HOST_WAITS)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    med = sorted(step_ms)[steps // 2]
+    worst = max(range(steps), key=lambda i: step_ms[i])
+    host_rec = {
+        "cores": PINNED_CORES if PINNED_CORES is not None else host_cores(), "pinned": PINNED_CORES is not None,
+        # wall time the host spent inside step() (cpcStep + backward + reduce_and_step + zero_grad), waits included
+        "enqueue_ms_per_step": round(1e3 * enqueue_s / steps, 3),
+        # ... of which blocked: the sampler's worker thread, its buffer-release events (they keep the host <= 2 steps ahead of the
+        # device), a collective's work.wait()
+        "blocked_ms_per_step": {k: round(1e3 * v / steps, 3) for k, v in sorted(waits.items())},
+        "busy_ms_per_step": round(1e3 * (enqueue_s - sum(waits.values())) / steps, 3),
+        "thread_cpu_ms_per_step": round(1e3 * thr_s / steps, 3),        # CPU time of the training thread
+        "process_cpu_ms_per_step": round(1e3 * cpu_s / steps, 3),       # ... of the whole process (worker, RCCL threads)
+        "host_done_before_device_ms": round(1e3 * (own_elapsed - t_enqueued), 3),   # device work left when the last step() returned
+        # per step on the compute stream (events): a one-off stall reads here, not as a slower average
+        "step_ms_median": round(med, 3), "step_ms_min": round(min(step_ms), 3), "step_ms_max": round(step_ms[worst], 3),
+        "step_ms_max_index": worst, "steps_over_2x_median": [i for i in range(steps) if step_ms[i] > 2 * med],
+    }
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -401,6 +447,18 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                                       "algorithmic_gflop_per_launch": round(sim / 1e9, 3), "avg_launch_us": k["avg_launch_us"],
                                       "traffic": measured_traffic(sim_kernel + ":" + cfg_name) if default_workload else None}
     out["kernels"] = kernels
+    if kernels:
+        # the ten timed classes against the step (caller's stream and the library's side stream together; the small kernels
+        # between them are not timed): what is left is launch gaps + untimed kernels, or -- when it jumps -- a stream that idled
+        host_rec["timed_kernel_classes_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels.values()), 3)
+    # the library's side stream (deferred backward work) and the training stream on different hardware queues?  Tested, not assumed
+    # (cpc2_hip.h, cpc_stream_create_apart; 200 us, after the clock has stopped)
+    side = ctypes.c_void_p()
+    cur = _lib.stream_ptr(device)
+    if lib.cpc_side_stream(cur, ctypes.byref(side)) == 0:
+        host_rec["side_stream_runs_beside_training_stream"] = lib.cpc_streams_overlap(cur, side) == 1
+    host_rec["streams_handed_out_untested"] = int(lib.cpc_stream_apart_failures())
+    out["host"] = host_rec
     out["_gradient_bytes"] = 4 * opt.flat_grad.numel()
     out["_comm"] = {"early_bytes": 4 * sum(hi - lo for lo, hi in dp.early), "late_bytes": 4 * sum(hi - lo for lo, hi in dp.late)
                     if dp.early else 4 * opt.flat_grad.numel(),

@@ -5,6 +5,7 @@ instructions.  Every call goes through `check()` which raises with cpc_last_erro
 """
 import ctypes
 import os
+import time
 
 import torch
 
@@ -80,8 +81,13 @@ SIGNATURES = {
     "cpc_negidx_wait": (c_int, [c_ptr]),
     "cpc_mt_draw_host": (c_int, [c_ptr, c_ptr, c_size_t]),
     "cpc_mt_draw_host_async": (c_int, [c_ptr, c_ptr, c_size_t]),
-    "cpc_mt_draw_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_size_t, c_int]),
-    "cpc_mt_draw_expand_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int]),
+    "cpc_mt_draw_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_size_t, c_int, c_ptr]),
+    "cpc_mt_draw_expand_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_negidx_wait_on": (c_int, [c_ptr, c_ptr]),
+    "cpc_stream_create_apart": (c_int, [c_ptr, c_int, c_ptr]),
+    "cpc_streams_overlap": (c_int, [c_ptr, c_ptr]),
+    "cpc_stream_apart_failures": (c_long, []),
+    "cpc_side_stream": (c_int, [c_ptr, c_ptr]),
     "cpc_negidx_expand": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_infonce_saved_bytes": (c_size_t, [c_int] * 6),
     "cpc_infonce_scratch_bytes": (c_size_t, [c_int] * 6),
@@ -119,6 +125,26 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+# Seconds the HOST thread has spent blocked on something other than enqueueing work, by cause (bench.py's `host` record reads and
+# resets it): the sampler's worker thread (cpc_negidx_wait), the sampler's buffer-release events, a collective's work.wait().
+HOST_WAITS = {}
+
+
+class host_wait:
+    """`with host_wait("cause"):` around a call that may block the host."""
+    __slots__ = ("cause", "t0")
+
+    def __init__(self, cause):
+        self.cause = cause
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        HOST_WAITS[self.cause] = HOST_WAITS.get(self.cause, 0.0) + time.perf_counter() - self.t0
+        return False
 
 
 def check(status, what=""):

@@ -107,7 +107,7 @@ class NegativeSampler:
         # The buffers of the PREVIOUS call's slot are free again once everything enqueued since -- that call's expansion and the
         # criterion kernels that read its index tensor -- has run: marked here, one call later, on the stream those kernels are on.
         if self._last is not None and self._last[0] in self._events:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(blocking=True)       # (a host that has to wait for it sleeps instead of spinning on a core)
             ev.record(torch.cuda.current_stream(device))
             self._events[self._last[0]][self._last[1]] = ev
         slot = self._slot % self.RING
@@ -117,7 +117,10 @@ class NegativeSampler:
         if self._prefetched is not None and self._prefetched[:2] == (key, slot):
             # drawn, uploaded AND expanded (on the worker's own stream) while the GPU was busy with the previous step: the index
             # tensor is one of RING buffers, valid until RING - 1 further calls (prefetch is the caller's opt-in)
-            check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")
+            # (waits for the worker's HOST part -- the draw, the enqueue of copy + expansion on its stream -- and orders the
+            #  training stream behind the event recorded there: the host is not held up by the device)
+            with _lib.host_wait("sampler_worker"):
+                check(self._lib.cpc_negidx_wait_on(self._h, _lib.stream_ptr(device)), "negidx_wait_on")
             if self._prefetched[2] == shape:
                 ext = self._ext_ring[key][slot]
             else:                              # (the same number of words for another shape: the words are right, the expansion is not)
@@ -126,7 +129,8 @@ class NegativeSampler:
                       "negidx_expand")
         else:
             if events[slot] is not None:
-                events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
+                with _lib.host_wait("sampler_buffer_event"):
+                    events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
             st = self._pull_torch_state() if self.follow_torch else None
             check(self._lib.cpc_mt_draw_host(self._h, ptr(host), 2 * n), "mt_draw_host")
             if st is not None:
@@ -143,10 +147,12 @@ class NegativeSampler:
             # that the next call has the same shape -- the words are consumed from the stream either way)
             nslot = self._slot % self.RING
             if events[nslot] is not None:
-                events[nslot].synchronize()
+                with _lib.host_wait("sampler_buffer_event"):
+                    events[nslot].synchronize()
             dev_index = device.index if device.index is not None else torch.cuda.current_device()
             check(self._lib.cpc_mt_draw_expand_device_async(self._h, ptr(ring[nslot]), ptr(dev_ring[nslot]), ptr(self._ext_ring[key][nslot]),
-                                                            dev_index, batch, seq_len, window, n_neg), "mt_draw_expand_device_async")
+                                                            dev_index, batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
+                  "mt_draw_expand_device_async")
             self._prefetched = (key, nslot, shape)
         return ext
 

@@ -231,5 +231,7 @@ int side_tail_begin(hipStream_t st, hipStream_t *side_stream);
 int side_tail_end();
 int side_tail_join(hipStream_t st);
 int side_tail_wait(hipStream_t st);       // `st` waits for the tail, which stays pending (a later side_tail_join still joins)
+// rowops.hip: a non-blocking stream of default priority that demonstrably runs BESIDE avoid[0 .. n) (not on their hardware queues)
+int stream_create_apart(const hipStream_t *avoid, int n_avoid, hipStream_t *out);
 
 }  // namespace cpc

@@ -1271,7 +1271,7 @@ struct NceSide {
     const float *c = nullptr;
 };
 
-static int nce_side(NceSide **out)
+static int nce_side(NceSide **out, hipStream_t caller)
 {
     static std::mutex mu;
     static std::map<int, NceSide> sides;
@@ -1283,7 +1283,8 @@ static int nce_side(NceSide **out)
         // DEFAULT priority, deliberately.  A lowest-priority stream looked right for work that runs beside the caller's, and costs
         // nothing in a single-process run -- but in a process that has also initialised RCCL every kernel of the step ran ~45 %
         // slower (7.7 against 5.3 ms per step with one rank; found by bisection, profiles/r03_dist_priority_bisect.txt).
-        CPC_CHECK_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+        // ... and on a hardware queue of its own: tested against the caller's stream (stream_create_apart, rowops.hip)
+        CPC_TRY(stream_create_apart(&caller, 1, &sd.stream));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
         CPC_CHECK_HIP(hipEventCreateWithFlags(&sd.mid, hipEventDisableTiming));
@@ -1331,7 +1332,7 @@ static int nce_launch_bwd(NceArgs &a, const NceLayout &l, float *dz, hipStream_t
     if (atomic_dz) {
         CPC_CHECK_HIP(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)rows * l.Henc, st));
     } else {
-        CPC_TRY(nce_side(&side));
+        CPC_TRY(nce_side(&side, st));
         CPC_CHECK_HIP(hipEventRecord(side->fork, st));
         CPC_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
         const unsigned blocks = (unsigned)std::min<long>(cdiv(n, 256), 4096);
@@ -1469,7 +1470,7 @@ static int infonce_backward(const float *c, const float *z, const float *wpred, 
 int infonce_deferred_mark(hipStream_t st)
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, st));
     if (!side->pending.load() || side->started || side->marked) return CPC_OK;
     CPC_CHECK_HIP(hipEventRecord(side->mid, st));
     side->marked = true;
@@ -1479,7 +1480,7 @@ int infonce_deferred_mark(hipStream_t st)
 int infonce_deferred_start(hipStream_t st)
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, st));
     if (!side->pending.load() || side->started) return CPC_OK;
     const NceLayout &l = side->l;
     CPC_TRY(infonce_deferred_mark(st));
@@ -1497,7 +1498,7 @@ int infonce_deferred_start(hipStream_t st)
 int side_tail_begin(hipStream_t st, hipStream_t *side_stream)
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, st));
     CPC_CHECK_HIP(hipEventRecord(side->tail_fork, st));
     CPC_CHECK_HIP(hipStreamWaitEvent(side->stream, side->tail_fork, 0));
     *side_stream = side->stream;
@@ -1506,7 +1507,7 @@ int side_tail_begin(hipStream_t st, hipStream_t *side_stream)
 int side_tail_end()
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, nullptr));
     CPC_CHECK_HIP(hipEventRecord(side->tail, side->stream));
     side->tail_pending = true;
     return CPC_OK;
@@ -1514,11 +1515,19 @@ int side_tail_end()
 int side_tail_join(hipStream_t st)
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, st));
     if (side->tail_pending) {
         CPC_CHECK_HIP(hipStreamWaitEvent(st, side->tail, 0));
         side->tail_pending = false;
     }
+    return CPC_OK;
+}
+
+int side_stream_peek(hipStream_t caller, hipStream_t *out)
+{
+    NceSide *side = nullptr;
+    CPC_TRY(nce_side(&side, caller));
+    *out = side->stream;
     return CPC_OK;
 }
 
@@ -1527,7 +1536,7 @@ int side_tail_join(hipStream_t st)
 int side_tail_wait(hipStream_t st)
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, st));
     if (side->tail_pending) CPC_CHECK_HIP(hipStreamWaitEvent(st, side->tail, 0));
     return CPC_OK;
 }
@@ -1536,7 +1545,7 @@ int side_tail_wait(hipStream_t st)
 static int infonce_join(hipStream_t st)
 {
     NceSide *side = nullptr;
-    CPC_TRY(nce_side(&side));
+    CPC_TRY(nce_side(&side, st));
     if (side->pending.load()) {
         CPC_TRY(infonce_deferred_start(st));
         CPC_CHECK_HIP(hipStreamWaitEvent(st, side->late, 0));
@@ -1660,6 +1669,14 @@ extern "C" int cpc_infonce_backward_cw(const float *c, const float *z, const flo
 }
 
 extern "C" int cpc_infonce_join(cpc_stream_t stream) { return cpc::infonce_join(static_cast<hipStream_t>(stream)); }
+extern "C" int cpc_side_stream(cpc_stream_t caller, cpc_stream_t *out)
+{
+    CPC_REQUIRE(out != nullptr, "cpc_side_stream: null output");
+    hipStream_t st = nullptr;
+    CPC_TRY(cpc::side_stream_peek(static_cast<hipStream_t>(caller), &st));
+    *out = st;
+    return CPC_OK;
+}
 
 extern "C" int cpc_infonce_forward_pred(const float *const *pred, const float *z, const int32_t *ext_idx, const float *weights,
                                         float *losses, float *acc, void *saved, void *scratch, int b, int t, int k, int dim_enc,

@@ -6,8 +6,11 @@
 // The generator state is kept in torch's bookkeeping form (left / next) so that it can be seeded from,
 // and written back to, torch.get_rng_state() -- the criterion then consumes the SAME stream the
 // reference would.  Whole 624-word blocks are twisted and tempered in bulk.
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -23,8 +26,22 @@ struct cpc_mt19937 {
     int left;   // torch: twist when --left == 0
     int next;
     std::vector<uint32_t> tmp;
-    std::thread worker;        // at most one asynchronous sample in flight (cpc_negidx_sample_host_async)
+    // ONE worker thread per generator, started by the first asynchronous call and parked on a condition variable between jobs
+    // (until round 5 every call started a thread and -- for the device forms -- created and destroyed a HIP stream: the stream's
+    // hardware queue was then whatever the runtime's least-used one was at that moment, in a process with a process group the
+    // training stream's own; profiles/r06_process_group_queues.md).  At most one job in flight; every other entry point waits.
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool busy = false, quit = false;
     int worker_status = 0;
+    // device forms: a stream of the worker's own (created apart from the training stream's hardware queue) and the event that
+    // marks "step i + 1's words / indices are on the device"
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    int stream_device = -1;
+    bool device_pending = false;      // `done` has been recorded and nobody has waited for it yet
 };
 
 namespace {
@@ -77,16 +94,86 @@ extern "C" cpc_mt19937 *cpc_mt_create(uint32_t seed)
     return g;
 }
 
+// (cpc_stream_create_apart lives in the device half of the library; a host-only build of this file -- the sanitizer test -- links without it)
+extern "C" int cpc_stream_create_apart(const cpc_stream_t *avoid, int n_avoid, cpc_stream_t *out) __attribute__((weak));
+
+namespace {
+void worker_loop(cpc_mt19937 *g)
+{
+    std::unique_lock<std::mutex> lk(g->mu);
+    for (;;) {
+        g->cv.wait(lk, [g] { return g->quit || (g->busy && g->job); });
+        if (g->quit) return;
+        std::function<int()> job = std::move(g->job);
+        g->job = nullptr;
+        lk.unlock();
+        const int st = job();
+        lk.lock();
+        g->worker_status = st;
+        g->busy = false;
+        g->cv.notify_all();
+    }
+}
+
+// wait for the job in flight (if any); returns its status once
+int join_job(cpc_mt19937 *g)
+{
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return !g->busy; });
+    const int st = g->worker_status;
+    g->worker_status = 0;
+    return st;
+}
+
+void submit(cpc_mt19937 *g, std::function<int()> job)
+{
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return !g->busy; });
+    if (!g->worker.joinable()) g->worker = std::thread(worker_loop, g);
+    g->job = std::move(job);
+    g->busy = true;
+    g->cv.notify_all();
+}
+
+// the worker's stream and event on `device` (worker thread only)
+hipError_t worker_stream(cpc_mt19937 *g, int device, cpc_stream_t caller_stream)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess || (g->stream != nullptr && g->stream_device == device)) return e;
+    if (g->stream != nullptr) { (void)hipStreamDestroy(g->stream); g->stream = nullptr; }
+    if (g->done != nullptr) { (void)hipEventDestroy(g->done); g->done = nullptr; }
+    if (cpc_stream_create_apart != nullptr) {
+        cpc_stream_t st = nullptr;
+        if (cpc_stream_create_apart(&caller_stream, 1, &st) != CPC_OK) return hipErrorUnknown;
+        g->stream = static_cast<hipStream_t>(st);
+    } else {
+        e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
+    g->stream_device = device;
+    return e;
+}
+}  // namespace
+
 extern "C" void cpc_mt_destroy(cpc_mt19937 *g)
 {
-    if (g != nullptr && g->worker.joinable()) g->worker.join();
+    if (g == nullptr) return;
+    (void)join_job(g);
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->quit = true;
+        g->cv.notify_all();
+    }
+    if (g->worker.joinable()) g->worker.join();
+    if (g->stream != nullptr) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    if (g->done != nullptr) (void)hipEventDestroy(g->done);
     delete g;
 }
 
 extern "C" int cpc_mt_seed(cpc_mt19937 *g, uint32_t seed)
 {
     if (g == nullptr) { cpc::set_error("cpc_mt_seed: null generator"); return CPC_ERR_INVALID; }
-    if (g->worker.joinable()) g->worker.join();
+    (void)join_job(g);
     g->mt[0] = seed;
     for (int i = 1; i < N; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
     g->left = 1;
@@ -179,9 +266,27 @@ int check_args(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, co
 extern "C" int cpc_negidx_wait(cpc_mt19937 *g)
 {
     if (g == nullptr) { cpc::set_error("cpc_negidx_wait: null generator"); return CPC_ERR_INVALID; }
-    if (g->worker.joinable()) g->worker.join();
-    const int st = g->worker_status;
-    g->worker_status = 0;
+    const int st = join_job(g);
+    if (g->device_pending) {          // host-blocking form: the device has the words when this returns
+        g->device_pending = false;
+        if (hipEventSynchronize(g->done) != hipSuccess && st == CPC_OK) { cpc::set_error("cpc_negidx_wait: event wait failed"); return CPC_ERR_HIP; }
+    }
+    return st;
+}
+
+// The same hand-over WITHOUT blocking the host on the device: waits for the worker's host part (the draw and the enqueue of
+// copy + expansion), then makes `stream` wait for the event behind them.
+extern "C" int cpc_negidx_wait_on(cpc_mt19937 *g, cpc_stream_t stream)
+{
+    if (g == nullptr) { cpc::set_error("cpc_negidx_wait_on: null generator"); return CPC_ERR_INVALID; }
+    const int st = join_job(g);
+    if (g->device_pending) {
+        g->device_pending = false;
+        if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), g->done, 0) != hipSuccess && st == CPC_OK) {
+            cpc::set_error("cpc_negidx_wait_on: hipStreamWaitEvent failed");
+            return CPC_ERR_HIP;
+        }
+    }
     return st;
 }
 
@@ -208,28 +313,7 @@ extern "C" int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t
 {
     if (g == nullptr || raw_host == nullptr) { cpc::set_error("cpc_mt_draw_host_async: null argument"); return CPC_ERR_INVALID; }
     cpc_negidx_wait(g);
-    g->worker = std::thread([=] { draw(g, raw_host, n); g->worker_status = CPC_OK; });
-    return CPC_OK;
-}
-
-// Draw on the worker thread, then upload from the (pinned) staging buffer on a stream of the worker's own, so the
-// host-to-device copy (8 bytes per negative) overlaps whatever the training stream is doing; the words are on the
-// device when cpc_negidx_wait returns.
-extern "C" int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device)
-{
-    if (g == nullptr || raw_host == nullptr || raw_dev == nullptr) { cpc::set_error("cpc_mt_draw_device_async: null argument"); return CPC_ERR_INVALID; }
-    cpc_negidx_wait(g);
-    g->worker = std::thread([=] {
-        draw(g, raw_host, n);
-        hipStream_t st = nullptr;
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMemcpyAsync(raw_dev, raw_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (st != nullptr) (void)hipStreamDestroy(st);
-        if (e != hipSuccess) cpc::set_error("cpc_mt_draw_device_async: %s", hipGetErrorString(e));
-        g->worker_status = e == hipSuccess ? CPC_OK : CPC_ERR_HIP;
-    });
+    submit(g, [=] { draw(g, raw_host, n); return (int)CPC_OK; });
     return CPC_OK;
 }
 
@@ -237,10 +321,35 @@ extern "C" int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint
 extern "C" int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
                                  cpc_stream_t stream) __attribute__((weak));
 
+// draw on the worker thread, upload from the (pinned) staging buffer on the worker's stream and -- ext_dev != nullptr -- expand
+// there too; `done` is recorded behind it: cpc_negidx_wait (host) / cpc_negidx_wait_on (a stream) hand the result over
+static int device_job(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, size_t n, int device,
+                      int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream, const char *who)
+{
+    draw(g, raw_host, n);
+    hipError_t e = worker_stream(g, device, caller_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(raw_dev, raw_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, g->stream);
+    int rc = CPC_OK;
+    if (e == hipSuccess && ext_dev != nullptr) rc = cpc_negidx_expand(raw_dev, ext_dev, batch, seq_len, window, n_neg, g->stream);
+    if (e == hipSuccess) e = hipEventRecord(g->done, g->stream);
+    if (e == hipSuccess) g->device_pending = true;
+    if (e != hipSuccess) cpc::set_error("%s: %s", who, hipGetErrorString(e));
+    return e != hipSuccess ? (int)CPC_ERR_HIP : rc;
+}
+
+extern "C" int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device,
+                                        cpc_stream_t caller_stream)
+{
+    if (g == nullptr || raw_host == nullptr || raw_dev == nullptr) { cpc::set_error("cpc_mt_draw_device_async: null argument"); return CPC_ERR_INVALID; }
+    cpc_negidx_wait(g);
+    submit(g, [=] { return device_job(g, raw_host, raw_dev, nullptr, n, device, 0, 0, 0, 0, caller_stream, "cpc_mt_draw_device_async"); });
+    return CPC_OK;
+}
+
 // The same, and the worker also EXPANDS the words into extIdx on its stream (cpc_negidx_expand): step i + 1's index tensor is
 // complete on the device before step i has ended, and nothing of the sampler is left on the training stream.
 extern "C" int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
-                                               int batch, int seq_len, int window, int n_neg)
+                                               int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream)
 {
     if (g == nullptr || raw_host == nullptr || raw_dev == nullptr || ext_dev == nullptr || batch < 1 || seq_len < 2 || window < 1 || n_neg < 1) {
         cpc::set_error("cpc_mt_draw_expand_device_async: bad argument");
@@ -249,23 +358,12 @@ extern "C" int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_hos
     if (cpc_negidx_expand == nullptr) { cpc::set_error("cpc_mt_draw_expand_device_async: built without the device kernels"); return CPC_ERR_HIP; }
     const size_t n = 2 * (size_t)batch * n_neg * window;
     cpc_negidx_wait(g);
-    g->worker = std::thread([=] {
-        draw(g, raw_host, n);
-        hipStream_t st = nullptr;
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMemcpyAsync(raw_dev, raw_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-        int rc = CPC_OK;
-        if (e == hipSuccess) rc = cpc_negidx_expand(raw_dev, ext_dev, batch, seq_len, window, n_neg, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (st != nullptr) (void)hipStreamDestroy(st);
-        if (e != hipSuccess) cpc::set_error("cpc_mt_draw_expand_device_async: %s", hipGetErrorString(e));
-        g->worker_status = e != hipSuccess ? CPC_ERR_HIP : rc;
-    });
+    submit(g, [=] { return device_job(g, raw_host, raw_dev, ext_dev, n, device, batch, seq_len, window, n_neg, caller_stream,
+                                      "cpc_mt_draw_expand_device_async"); });
     return CPC_OK;
 }
 
-// Same as cpc_negidx_sample_host but on a worker thread: returns at once, ext_idx_host is valid after
+// Same as cpc_negidx_sample_host but on the worker thread: returns at once, ext_idx_host is valid after
 // cpc_negidx_wait(g).  Lets the host draw step i+1's indices while the GPU is busy with step i.
 extern "C" int cpc_negidx_sample_host_async(cpc_mt19937 *g, int batch, int seq_len, int window, int n_neg, int time_major,
                                             int32_t *ext_idx_host)
@@ -273,6 +371,6 @@ extern "C" int cpc_negidx_sample_host_async(cpc_mt19937 *g, int batch, int seq_l
     const int st = check_args(g, batch, seq_len, window, n_neg, ext_idx_host);
     if (st != CPC_OK) return st;
     cpc_negidx_wait(g);
-    g->worker = std::thread([=] { g->worker_status = sample_impl(g, batch, seq_len, window, n_neg, time_major, ext_idx_host, nullptr, nullptr); });
+    submit(g, [=] { return sample_impl(g, batch, seq_len, window, n_neg, time_major, ext_idx_host, nullptr, nullptr); });
     return CPC_OK;
 }

@@ -400,9 +400,105 @@ __global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n
     if (bad) coop_report(err, COOP_ERR_NONFINITE_GRAD);
 }
 
+// ---------------------------------------------------------------- streams that run BESIDE a given stream
+// A HIP stream is served by one of a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default, per priority); the runtime hands a new
+// stream the least-used queue AT THAT MOMENT, and two streams on one queue run one after the other -- whatever their events say.
+// Which queue a stream of this library's got used to be an accident of creation order: in a process with a process group
+// (torch's stream pools, RCCL's stream) the side stream could land on the training stream's own queue, and the ~1.1 ms of
+// deferred work per step then ran IN FRONT of the backward pass instead of beside it (5.86 against 4.9 ms per step, round 5's
+// unexplained record; profiles/r06_process_group_queues.md).  A stream made here is TESTED: a kernel that spins for 200 us on
+// each stream to avoid, a one-wave kernel on the candidate -- if the candidate's finishes while the spin is still running the two
+// are on different queues.  Candidates that fail are kept alive (they hold their queue's use count) until one passes.
+// Sharing a queue serialises ANY two streams (measured pair by pair: profiles/r06_process_group_queues.md).
+__global__ void queue_probe_spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();                 // 100 MHz, constant
+    for (int i = 0; i < (1 << 20) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void queue_probe_tag_kernel() {}
+
+static std::mutex g_streams_mu;
+static std::vector<std::pair<int, hipStream_t>> g_apart;       // (device, stream) of every stream made by stream_create_apart
+static std::atomic<long> g_apart_fail{0};
+
+// 1: kernels of `b` run beside kernels of `a`; 0: behind them (same hardware queue, or a blocking stream beside the null stream)
+static int streams_overlap_locked(hipStream_t a, hipStream_t b, int *overlap)
+{
+    hipEvent_t spun = nullptr, tagged = nullptr;
+    CPC_CHECK_HIP(hipEventCreateWithFlags(&spun, hipEventDisableTiming));
+    CPC_CHECK_HIP(hipEventCreateWithFlags(&tagged, hipEventDisableTiming));
+    hipLaunchKernelGGL(queue_probe_spin_kernel, dim3(1), dim3(64), 0, a, 20000LL);
+    hipError_t e = hipEventRecord(spun, a);
+    if (e == hipSuccess) { hipLaunchKernelGGL(queue_probe_tag_kernel, dim3(1), dim3(64), 0, b); e = hipEventRecord(tagged, b); }
+    if (e == hipSuccess) e = hipEventSynchronize(tagged);
+    if (e == hipSuccess) {
+        const hipError_t q = hipEventQuery(spun);
+        *overlap = q == hipErrorNotReady ? 1 : 0;
+        if (q != hipErrorNotReady && q != hipSuccess) e = q;
+    }
+    (void)hipGetLastError();                               // (hipErrorNotReady is not an error)
+    if (e == hipSuccess) e = hipEventSynchronize(spun);
+    (void)hipEventDestroy(spun);
+    (void)hipEventDestroy(tagged);
+    CPC_CHECK_HIP(e);
+    return CPC_OK;
+}
+
+int stream_create_apart(const hipStream_t *avoid, int n_avoid, hipStream_t *out)
+{
+    int dev = 0;
+    CPC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    // (only the streams the caller names: with four hardware queues the library's three streams -- side, sampler, data-parallel
+    //  helper -- can each sit apart from the training stream, not all four from each other; nothing of theirs needs that)
+    std::vector<hipStream_t> others(avoid, avoid + n_avoid);
+    std::vector<hipStream_t> rejected;
+    hipStream_t cand = nullptr;
+    bool ok = false;
+    for (int attempt = 0; attempt < 12 && !ok; ++attempt) {
+        CPC_CHECK_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+        ok = true;
+        for (hipStream_t o : others) {
+            int overlap = 0;
+            CPC_TRY(streams_overlap_locked(o, cand, &overlap));
+            if (!overlap) { ok = false; break; }
+        }
+        if (!ok) rejected.push_back(cand);
+    }
+    if (!ok) {                       // (a saturated device can fail every test: the last candidate serves, and the count says so)
+        g_apart_fail.fetch_add(1, std::memory_order_relaxed);
+        rejected.pop_back();
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    g_apart.emplace_back(dev, cand);
+    *out = cand;
+    return CPC_OK;
+}
+
 }  // namespace cpc
 
-extern "C" int cpc_version(void) { return 105; }     // 105: round 5 (cpc_encoder_forward2 / backward2, cpc_coop_set_policy, cpc_side_tail_wait, ...)
+extern "C" int cpc_stream_create_apart(const cpc_stream_t *avoid, int n_avoid, cpc_stream_t *out)
+{
+    CPC_REQUIRE(out != nullptr && n_avoid >= 0 && (n_avoid == 0 || avoid != nullptr), "cpc_stream_create_apart: bad arguments");
+    std::vector<hipStream_t> av(n_avoid);
+    for (int i = 0; i < n_avoid; ++i) av[i] = static_cast<hipStream_t>(avoid[i]);
+    hipStream_t st = nullptr;
+    CPC_TRY(cpc::stream_create_apart(av.data(), n_avoid, &st));
+    *out = st;
+    return CPC_OK;
+}
+
+extern "C" int cpc_streams_overlap(cpc_stream_t a, cpc_stream_t b)
+{
+    std::lock_guard<std::mutex> lk(cpc::g_streams_mu);
+    int overlap = 0;
+    const int rc = cpc::streams_overlap_locked(static_cast<hipStream_t>(a), static_cast<hipStream_t>(b), &overlap);
+    return rc != CPC_OK ? rc : overlap;
+}
+
+extern "C" long cpc_stream_apart_failures(void) { return cpc::g_apart_fail.load(std::memory_order_relaxed); }
+
+extern "C" int cpc_version(void) { return 106; }     // 106: round 6 (cpc_stream_create_apart, cpc_negidx_wait_on, ...); 105: round 5 (cpc_encoder_forward2 / backward2, cpc_coop_set_policy, cpc_side_tail_wait, ...)
 
 extern "C" int cpc_prof_enable(int on)
 {

@@ -352,7 +352,14 @@ class DataParallelContext:
                 # backward pass / in reduce_and_step().
                 device = self.opt.flat_grad.device
                 if self._helper is None:
-                    self._helper = torch.cuda.Stream(device)
+                    # (a stream of the library's making: on a hardware queue that is neither the compute stream's nor the side
+                    #  stream's -- a pool stream that happened to share the compute stream's queue would park the wait for the side
+                    #  stream IN FRONT of the encoder's backward; cpc2_hip.h, cpc_stream_create_apart)
+                    import ctypes
+                    raw = ctypes.c_void_p()
+                    avoid = (ctypes.c_void_p * 1)(torch.cuda.current_stream(device).cuda_stream)
+                    check(_lib.load().cpc_stream_create_apart(avoid, 1, ctypes.byref(raw)), "stream_create_apart")
+                    self._helper = torch.cuda.ExternalStream(raw.value, device=device)
                 self._helper.wait_stream(torch.cuda.current_stream(device))
                 with torch.cuda.stream(self._helper):
                     check(_lib.load().cpc_side_tail_wait(stream_ptr(device)), "side_tail_wait")
@@ -371,8 +378,9 @@ class DataParallelContext:
                 t0 = self._span()
                 for lo, hi in self.late:
                     self._all_reduce(lo, hi)
-                for work in self._pending:
-                    work.wait()
+                with _lib.host_wait("collective_wait"):
+                    for work in self._pending:
+                        work.wait()
                 if t0 is not None:
                     self._spans.append((t0, self._span()))
                 if self.trace is not None:

@@ -60,6 +60,20 @@ const char *cpc_last_error(void);
  * elements, so the parameters are intact), the following ones do not depend on co-residency.  CPC_COOP_FAULT=1 in the environment
  * (tests) makes one member withhold one publish so that its group times out. */
 int cpc_async_error_check(cpc_stream_t stream);
+
+/* Streams that run BESIDE a given stream.  A HIP stream is served by one of a few hardware queues (4 by default per priority) that
+ * the runtime assigns by use count at creation, and two streams on one queue run one after the other.  cpc_stream_create_apart
+ * returns a non-blocking stream of default priority whose kernels were OBSERVED to run beside those of every avoid[i] (the
+ * caller's stream(s); NULL = the null stream is a valid entry): a 200 us spin kernel on the one, a one-wave kernel on the
+ * candidate, who finishes first.  (With four queues at most three streams can be apart from a given one AND from each other.)  Blocks the host until avoid[i] has
+ * drained (once).  The library's own side stream and the sampler's worker stream are made this way; cpc2_amd.train's
+ * data-parallel helper stream too.  cpc_streams_overlap(a, b): the same test on two given streams, 1 = beside, 0 = behind, < 0
+ * error.  cpc_stream_apart_failures: streams handed out although every candidate failed the test (a saturated device). */
+int cpc_stream_create_apart(const cpc_stream_t *avoid, int n_avoid, cpc_stream_t *out);
+int cpc_streams_overlap(cpc_stream_t a, cpc_stream_t b);
+long cpc_stream_apart_failures(void);
+/* the library's side stream on the current device (created on first use, apart from `caller`), for diagnostics */
+int cpc_side_stream(cpc_stream_t caller, cpc_stream_t *out);
 /* Cooperative recurrent launches (the GRU / LSTM kernels at hidden 256 / 512 that need every workgroup resident at once)
  * issued by this process so far.  The data-parallel glue (train.py:523-527's role) checks with it that a gradient all-reduce
  * is never issued between a step's forward and backward recurrent launches. */
@@ -323,12 +337,16 @@ int cpc_mt_draw_host(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
 int cpc_mt_draw_host_async(cpc_mt19937 *g, uint32_t *raw_host, size_t n);
 /* ... and uploaded by the worker on its own stream (raw_host pinned): raw_dev holds the words once
  * cpc_negidx_wait returns, so no copy sits on the training stream. */
-int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device);
-/* ... and expanded there too (cpc_negidx_expand on the worker's stream): ext_dev [batch * window * n_neg] is complete once
- * cpc_negidx_wait returns -- the two torch.randint calls AND the index arithmetic of criterion.py:247-266 for step i + 1, done
- * while step i runs. */
+int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, size_t n, int device,
+                             cpc_stream_t caller_stream);
+/* ... and expanded there too (cpc_negidx_expand on the worker's stream): the two torch.randint calls AND the index arithmetic of
+ * criterion.py:247-266 for step i + 1, done while step i runs.  The worker is ONE thread per generator with ONE stream, made on its
+ * first device job apart from `caller_stream`'s hardware queue (cpc_stream_create_apart); an event is recorded behind the job.
+ * ext_dev [batch * window * n_neg] may be read by the host's device work after cpc_negidx_wait (blocks the host until the device
+ * has it) or, without blocking the host on the device, by everything enqueued on `stream` after cpc_negidx_wait_on(g, stream). */
 int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
-                                    int batch, int seq_len, int window, int n_neg);
+                                    int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream);
+int cpc_negidx_wait_on(cpc_mt19937 *g, cpc_stream_t stream);
 int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
                       cpc_stream_t stream);
 

@@ -26,15 +26,20 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
     plain = _bench({})
     dist = _bench({"CPC_BENCH_FORCE_DIST": "1"})
     assert dist["comm"]["process_group"] == "nccl" and plain["comm"]["process_group"] is None
+    # Round 5 recorded 5.86 against 4.9 ms per step here once, every kernel at its usual time (profiles/r05_bench_nccl1.json), and
+    # this test re-measured before failing.  The cause (profiles/r06_process_group_queues.md): the library's side stream shared
+    # the training stream's HARDWARE QUEUE -- assigned by use count at creation, crowded by the process group's streams -- so the
+    # deferred backward work (1.1 ms per step) ran in front of the backward pass instead of beside it.  The library's streams are
+    # now made on queues that were observed to run beside the caller's, and the line says so: no second measurement.
+    for rec in (plain, dist):
+        host = rec["host"]
+        assert host["side_stream_runs_beside_training_stream"] is True, host
+        assert host["streams_handed_out_untested"] == 0, host
+        assert host["steps_over_2x_median"] == [], host          # no one-off stall inside the timed region
+        assert host["step_ms_max"] < 1.15 * host["step_ms_median"], host
     ratio = dist["ms_per_step"] / plain["ms_per_step"]
-    if ratio >= 1.2:
-        # one 16-step run on a box that has just come up can be off by itself (seen once: 6.31 against 5.23 ms, then 5.17 against
-        # 5.09 on the next box); the defect this test exists for does not go away on a second measurement
-        plain = _bench({})
-        dist = _bench({"CPC_BENCH_FORCE_DIST": "1"})
-        ratio = dist["ms_per_step"] / plain["ms_per_step"]
-    # measured 1.02-1.03 (hooks + two collectives of one rank); the defect this guards against measured 1.45
-    assert ratio < 1.2, f"process-group mode {dist['ms_per_step']} ms per step against {plain['ms_per_step']} plain"
+    # measured 1.01-1.03 (hooks + two collectives of one rank)
+    assert ratio < 1.1, f"process-group mode {dist['ms_per_step']} ms per step against {plain['ms_per_step']} plain"
     # the fields an 8-GPU run will be read by (there is no multi-GPU node to measure a scaling curve on): what the exchange holds
     # the compute stream for per step -- with one rank the wire costs nothing, so this is the floor of the collectives themselves
     comm = dist["comm"]
@@ -42,3 +47,16 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
     assert comm["exposed_ms_per_step"] is not None and 0 <= comm["exposed_ms_per_step"] < 0.2, comm
     assert comm["rank_ms_per_step_min"] <= comm["rank_ms_per_step_max"] <= dist["ms_per_step"] * 1.01
     assert plain["comm"]["exposed_ms_per_step"] is None
+    # what a step costs the host: far below the step itself, so that eight ranks on one host do not starve their GPUs
+    for rec in (plain, dist):
+        assert rec["host"]["busy_ms_per_step"] < 0.6 * rec["ms_per_step"], rec["host"]
+
+
+def test_a_rank_on_two_cores_keeps_its_gpu_fed():
+    """Eight ranks share one host: a rank gets a couple of cores.  Pinned to two (process-wide, before any GPU call) the step
+    costs what it costs on sixteen."""
+    free = _bench({"CPC_BENCH_FORCE_DIST": "1"})
+    two = _bench({"CPC_BENCH_FORCE_DIST": "1", "CPC_BENCH_PIN_CORES": "2"})
+    assert two["host"]["pinned"] and two["host"]["cores"] == 2
+    assert two["ms_per_step"] < 1.05 * free["ms_per_step"], (two["ms_per_step"], free["ms_per_step"], two["host"])
+    assert two["host"]["busy_ms_per_step"] < 0.6 * two["ms_per_step"], two["host"]

@@ -2736,3 +2736,28 @@ def test_full_batch_launch_geometry_vs_oracle_on_four_windows(name, hidden, laye
         worst = max(worst, rel_err(p.grad, ref))
         assert_close(p.grad, ref, 2e-4, f"grad {pname}")
     print(f"{name}: four-window gradients at N = {n}: worst {worst:.2e} of scale")
+
+
+def test_library_streams_run_beside_the_training_stream():
+    """A HIP stream is served by one of a few hardware queues, assigned by use count when it is created; two streams on one queue
+    run one after the other.  In a process crowded with streams (a process group's pools) the library's side stream used to land,
+    now and then, on the training stream's queue (round 5's +1 ms per step).  cpc_stream_create_apart tests its candidates: here
+    in a process that first creates forty streams, against the current stream, and the test itself is shown to tell a shared
+    queue from a separate one."""
+    lib = _lib.load()
+    crowd = [torch.cuda.Stream(DEV) for _ in range(40)]
+    cur = _lib.stream_ptr(torch.device(DEV))
+    verdicts = [lib.cpc_streams_overlap(cur, ctypes.c_void_p(s.cuda_stream)) for s in crowd[:16]]
+    assert all(v in (0, 1) for v in verdicts), verdicts
+    assert 0 in verdicts and 1 in verdicts, f"sixteen plain streams over the default hardware queues: {verdicts}"
+    for _ in range(6):                                       # (more than there are queues: each is apart from the CALLER's)
+        raw = ctypes.c_void_p()
+        avoid = (ctypes.c_void_p * 1)(cur.value)
+        _lib.check(lib.cpc_stream_create_apart(avoid, 1, ctypes.byref(raw)), "stream_create_apart")
+        assert lib.cpc_streams_overlap(cur, raw) == 1
+    side = ctypes.c_void_p()
+    _lib.check(lib.cpc_side_stream(cur, ctypes.byref(side)), "side_stream")
+    assert lib.cpc_streams_overlap(cur, side) == 1
+    assert lib.cpc_stream_apart_failures() == 0
+    torch.cuda.synchronize()
+    del crowd
