@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 
 # Eight hardware queues per priority instead of the runtime's four (read when HIP initialises, i.e. at the first GPU call): the
 # library places its own streams on queues it has TESTED to run beside the training stream's, but RCCL's stream is torch's to pick,
-# and with four queues it shares the training stream's one time in four (profiles/r06_process_group_queues.md).  No effect on the
-# one-GPU step (profiles/r06_ab_hw_queues_8.txt).
+# and with four queues it shares the training stream's one time in four (profiles/r06_process_group_queues.md).  One RCCL rank:
+# 4.87-4.98 against 4.94-5.03 ms per step, six alternating pairs (profiles/r06_ab_hw_queues_dist.txt); no effect without a process group.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # CPC_BENCH_PIN_CORES=n: run this process (and every thread it starts: the sampler's worker, RCCL's proxy and watchdog) on the first
@@ -259,6 +259,86 @@ def cpu_baseline(cfg, seconds_budget):
             "by_batch": {"b8": r8, "b16": r16}}
 
 
+class ClockSampler:
+    """What the GPU box itself was doing while the timed region ran, sampled from a thread (sysfs, ~50 Hz): this GPU's shader-clock
+    level and power, and how many OTHER GPUs of the host were busy (the box is one GPU of a shared 8-GPU host).  A run in which every
+    kernel is slower (seen in round 6: 6.68 against 4.9 ms per step, the latency-bound kernels hit hardest, every stream on its own
+    queue, `training_stream_held_by_side_stream` normal) is then told apart from one in which the step's own schedule went wrong."""
+
+    def __init__(self, device, period=0.02):
+        import glob
+        import threading
+        self.own, self.others = None, []
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:                                         # noqa: BLE001
+            want = None
+        for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if not os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                continue
+            if want is not None and os.path.basename(os.path.realpath(c)) == want:
+                self.own = c
+            else:
+                self.others.append(c)
+        self.power = None
+        if self.own is not None:
+            import glob as g2
+            hits = g2.glob(os.path.join(self.own, "hwmon", "hwmon*", "power1_average")) + g2.glob(os.path.join(self.own, "hwmon", "hwmon*", "power1_input"))
+            self.power = hits[0] if hits else None
+        self.sclk, self.watts, self.busy_others = [], [], []
+        self.period, self._stop = period, threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.own is not None else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except OSError:
+            return ""
+
+    def _run(self):
+        while not self._stop.is_set():
+            for ln in self._read(os.path.join(self.own, "pp_dpm_sclk")).splitlines():
+                if ln.rstrip().endswith("*"):
+                    digits = "".join(ch for ch in ln.split(":")[-1] if ch.isdigit())
+                    if digits:
+                        self.sclk.append(int(digits))
+            if self.power is not None:
+                txt = self._read(self.power).strip()
+                if txt.isdigit():
+                    self.watts.append(int(txt) / 1e6)
+            n = 0
+            for c in self.others:
+                txt = self._read(os.path.join(c, "gpu_busy_percent")).strip()
+                n += 1 if (txt.isdigit() and int(txt) >= 20) else 0
+            self.busy_others.append(n)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._thread is not None:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+        return False
+
+    def record(self):
+        if self.own is None or not self.sclk:
+            return None
+        v = sorted(self.sclk)
+        rec = {"card": self.own.split("/")[4], "samples": len(v), "sclk_level_mhz_min": v[0], "sclk_level_mhz_median": v[len(v) // 2],
+               "sclk_level_mhz_max": v[-1], "other_gpus_of_the_host": len(self.others),
+               "other_gpus_busy_max": max(self.busy_others) if self.busy_others else None}
+        if self.watts:
+            w = sorted(self.watts)
+            rec.update(power_w_min=round(w[0]), power_w_median=round(w[len(w) // 2]), power_w_max=round(w[-1]))
+        return rec
+
+
 def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_seconds):
     """Build CONFIGS[cfg_name], run `warmup` untimed and `steps` timed steps (barrier + synchronize on both sides, MAX over
     ranks) and return the result record (rank 0: the dict that is printed; other ranks: None)."""
@@ -317,16 +397,18 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     _lib.HOST_WAITS.clear()
     enqueue_s = 0.0
     cpu0, thr0 = time.process_time(), time.thread_time()
-    marks[0].record()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ta = time.perf_counter()
-        losses = step()
-        enqueue_s += time.perf_counter() - ta
-        marks[i + 1].record()
-    t_enqueued = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    own_elapsed = time.perf_counter() - t0                  # this rank's own clock (before the closing barrier)
+    clocks = ClockSampler(device)
+    with clocks:
+        marks[0].record()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ta = time.perf_counter()
+            losses = step()
+            enqueue_s += time.perf_counter() - ta
+            marks[i + 1].record()
+        t_enqueued = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0              # this rank's own clock (before the closing barrier)
     cpu_s, thr_s = time.process_time() - cpu0, time.thread_time() - thr0
     waits = dict(_lib.HOST_WAITS)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
@@ -346,6 +428,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         # per step on the compute stream (events): a one-off stall reads here, not as a slower average
         "step_ms_median": round(med, 3), "step_ms_min": round(min(step_ms), 3), "step_ms_max": round(step_ms[worst], 3),
         "step_ms_max_index": worst, "steps_over_2x_median": [i for i in range(steps) if step_ms[i] > 2 * med],
+        "gpu_clock": clocks.record(),
     }
     if use_dist:
         dist.barrier()
@@ -375,7 +458,11 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                                  "avg_launch_us": round(1e3 * tot.value / cnt.value, 2)}
 
     if prof:
-        read_classes((roof,), steps)                       # measured over the timed region
+        read_classes((roof, "side_wait"), steps)           # measured over the timed region
+        if "side_wait" in kernels:
+            # not a kernel: the time the training stream stood still at its joins with the library's side stream (events around the
+            # waits).  ~0.1 ms when the deferred work runs BESIDE the backward pass; its whole length (~1 ms) when it does not
+            host_rec["training_stream_held_by_side_stream_ms_per_step"] = kernels.pop("side_wait")["ms_per_step"]
         # the other classes: a few extra steps after the clock has stopped (timing every class costs ~0.1 ms per step)
         extra = 5
         lib.cpc_prof_enable(1)
@@ -457,6 +544,11 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     cur = _lib.stream_ptr(device)
     if lib.cpc_side_stream(cur, ctypes.byref(side)) == 0:
         host_rec["side_stream_runs_beside_training_stream"] = lib.cpc_streams_overlap(cur, side) == 1
+    wst = ctypes.c_void_p()
+    if lib.cpc_negidx_stream(crit.sampler._h, ctypes.byref(wst)) == 0 and wst.value:
+        host_rec["sampler_stream_runs_beside_training_stream"] = lib.cpc_streams_overlap(cur, wst) == 1
+    if getattr(dp, "_helper", None) is not None:
+        host_rec["exchange_helper_stream_runs_beside_training_stream"] = lib.cpc_streams_overlap(cur, ctypes.c_void_p(dp._helper.cuda_stream)) == 1
     host_rec["streams_handed_out_untested"] = int(lib.cpc_stream_apart_failures())
     out["host"] = host_rec
     out["_gradient_bytes"] = 4 * opt.flat_grad.numel()

@@ -62,7 +62,9 @@ struct Carver {
 
 // ---- optional in-situ kernel timing (see cpc_prof_* in cpc2_hip.h) ----
 enum ProfSlot { PROF_GEMM_NT = 0, PROF_GEMM_TN, PROF_NCE_FWD, PROF_NCE_BWD, PROF_GRU_FWD, PROF_GRU_BWD, PROF_CONV0_FWD,
-                PROF_CONV0_BWD, PROF_PLANES_NT, PROF_PLANES_TN, PROF_SLOTS };
+                PROF_CONV0_BWD, PROF_PLANES_NT, PROF_PLANES_TN,
+                PROF_SIDE_WAIT,      // a stream held at a join with the library's side stream (events around the wait: idle time, not a kernel)
+                PROF_SLOTS };
 class ProfScope {
 public:
     // attached = true: the scope records nothing itself -- the ONE kernel launched inside takes start() / stop() as the events

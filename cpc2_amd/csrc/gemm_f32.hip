@@ -19,6 +19,7 @@
 #include <atomic>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace cpc {
 
@@ -496,13 +497,37 @@ template <int MI, int NJ, int DBG = 0> __global__ __launch_bounds__(256, NJ == 4
     else nt_epilogue<MI, NJ>(p, acc, m0, m_end, n0, wm, wn, r32, h);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS image of one 16-k stage of the pipelined kernels (gemm_tn_x6p_kernel; the NT twin is tools/experiments/gemm_nt_x6p_kernel.inc):
+// three planes, each [2 halves of the 16 k][rows][16 bytes]: lane (r32, h)'s fragment (8 consecutive k) is chunk r32 of half h --
+// the 32 lanes of a half read 512 contiguous bytes (every 16-lane group of a ds_read_b128 its own 16 bank quads); the loader's
+// stores stay conflict free because the second half starts 128 bytes off a multiple of 256.
+template <int ROWS> __device__ __forceinline__ int x6p_off(int row, int half) { return half * (ROWS * 16 + 128) + row * 16; }
+template <int ROWS> constexpr int x6p_plane() { return 2 * ROWS * 16 + 128; }
+
+
 __global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k);
 
+// A/B switch: CPC_GEMM_X6_OLD=1 selects the two-barrier TN kernel and the K-split rule of rounds 1-5
+static bool x6_pipelined()
+{
+    static const bool old_kernels = getenv("CPC_GEMM_X6_OLD") != nullptr;
+    return !old_kernels;
+}
+
 // few tiles but a long K (e.g. dC = dP . W, K = 12 H): K is split over blockIdx.y
+// (Round 6, tools/x6_sweep.py: below K = 2048 a split costs more than the idle CUs it fills -- 7424 x 256 x 768: 34 us whole
+//  against 44 in four parts; 8192 x 256 x 256: 13.5 against 27 in two; 7424 x 512 x 1536: 83 against 88 -- above it the parts stay
+//  >= 512 k long.  CPC_GEMM_X6_OLD=1 keeps the rule of rounds 1-5 for A/B runs.)
 static int nt_splits(long blocks, int K)
 {
-    if (blocks >= 2 * 256 || K < 8 * BK) return 1;
-    return (int)std::max<long>(1, std::min<long>(cdiv(3 * 256, blocks), K / (4 * BK)));
+    if (!x6_pipelined()) {
+        if (blocks >= 2 * 256 || K < 8 * BK) return 1;
+        return (int)std::max<long>(1, std::min<long>(cdiv(3 * 256, blocks), K / (4 * BK)));
+    }
+    if (blocks >= 2 * 256 || K < 2048) return 1;
+    return (int)std::max<long>(1, std::min<long>(cdiv(3 * 256, blocks), K / 512));
 }
 
 size_t gemm_nt_scratch_bytes(long M, int N, int K)
@@ -555,12 +580,17 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
         static const bool wide_always = getenv("CPC_GEMM_WIDE_ALWAYS") != nullptr;        // A/B switch
         nj = (N == 256 || wide >= narrow || wide_always) ? 4 : 2;
     } else if (a.aligned && m_tiles(128) * cdiv(N, BN) < 2 * 256) mi = 1;
+    // (tile / split sweeps of tools/x6_sweep.py: CPC_GEMM_TILE="mi,nj", CPC_GEMM_SPLITS=n)
+    static const char *tile_env = getenv("CPC_GEMM_TILE"), *splits_env = getenv("CPC_GEMM_SPLITS");
+    if (tile_env != nullptr && split_kernels) {
+        if (sscanf(tile_env, "%d,%d", &mi, &nj) != 2 || !((mi == 1 && nj == 2) || (mi == 2 && (nj == 2 || nj == 4)))) { mi = 2; nj = 2; }
+    }
     const long blocks = m_tiles(64 * mi) * cdiv(N, 64 * nj);
     CPC_REQUIRE(blocks <= 2147483647L, "gemm_nt: grid too large (%ld blocks)", blocks);
     // few tiles but a long K (e.g. dC = dP . W, K = 12 H): split K over blockIdx.y, partial products are
     // atomically added into a zeroed C (dense, unmapped outputs only)
     int splits = 1;
-    if (a.aligned && !map.enabled && ldc == N && map.epi == EPI_NONE) splits = nt_splits(blocks, K);
+    if (a.aligned && !map.enabled && ldc == N && map.epi == EPI_NONE) splits = splits_env != nullptr ? std::max(1, atoi(splits_env)) : nt_splits(blocks, K);
     a.kchunk = (int)(cdiv(cdiv(K, splits), BK) * BK);
     splits = (int)cdiv(K, a.kchunk);
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
@@ -581,6 +611,9 @@ int gemm_nt(const float *A, long lda, const float *B, long ldb, float *C, long l
                 "gemm_nt: a fused elementwise epilogue needs a dense output (M=%ld N=%d K=%d ldc=%ld)", M, N, K, ldc);
     const bool epi_pass = map.epi != EPI_NONE && !(a.vec_out != 0 && split_kernels);     // (only the staged store does it in place)
     dim3 grid((unsigned)blocks, (unsigned)splits);
+    static const bool log_shapes = getenv("CPC_GEMM_LOG") != nullptr;        // tools/x6_shapes.py: one line per launch
+    if (log_shapes) fprintf(stderr, "cpc_gemm nt M=%ld N=%d K=%d lda=%ld ldb=%ld ldc=%ld tile=%dx%d grid=%ld splits=%d map=%d epi=%d kernel=%s\n", M, N, K, lda,
+                            ldb, ldc, 64 * mi, 64 * nj, blocks, splits, map.enabled, map.epi, split_kernels ? "x6" : "f32");
     ProfScope prof(PROF_GEMM_NT, st);
     if (!a.aligned) hipLaunchKernelGGL((gemm_nt_kernel<false, 2>), grid, dim3(256), 0, st, a);
     else if (native && mi == 1) hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), grid, dim3(256), 0, st, a);
@@ -853,6 +886,151 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_x6_kernel(GemmTNArgs p)
         }
 }
 
+// The TN product as a SOFTWARE PIPELINE (round 6).  gemm_tn_x6_kernel stores a step of 32 rows into LDS, waits at a barrier,
+// multiplies, waits again.  Here a stage is 16 reduction rows (one MFMA's depth), LDS holds TWO stages and every wave splits and
+// stores stage s + 1 while the matrix pipe works through the MFMAs it has issued for stage s (sched_group_barrier interleaves
+// them: no branch inside a stage, clamped stage numbers instead); raw operands arrive two stages ahead in two register sets; ONE
+// barrier per stage.  5-9 % faster than the two-barrier kernel on the large weight-gradient products (predictor 3072 x 256 over
+// 7424 rows: 83 against 91 us; CPC-large 6144 x 512: 287 against 305), equal on the small ones (profiles/r06_x6_sweep.md).
+// The loader transposes while it splits: waves 0, 1 stage A, waves 2, 3 stage B; a thread takes an 8 (r) x 2 (columns) micro tile
+// (eight 8-byte loads; a wave's load covers 256 contiguous bytes of two rows) and writes, per column, its 8 consecutive r as one
+// 16-byte chunk per plane.
+__global__ __launch_bounds__(256, 3) void gemm_tn_x6p_kernel(GemmTNArgs p)
+{
+    constexpr int PL = x6p_plane<BM>();                    // bytes per plane of one stage (BM == BN)
+    constexpr int STAGE = 6 * PL;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned tiles = gridDim.x * gridDim.y, j = b >> 3, tile = j % tiles;
+        bz = (int)((j / tiles) * 8 + (b & 7));
+        by = (int)(tile / gridDim.x);
+        bx = (int)(tile % gridDim.x);
+    }
+    const int i0 = by * BM;
+    const int j0 = bx * BN;
+    const long rbeg = (long)bz * p.chunk;
+    long rend = rbeg + p.chunk;
+    if (rend > p.R) rend = p.R;
+
+    const bool isA = tid < 128;                                // wave uniform
+    const int u = tid & 127;
+    const int rg = u & 1, cg = u >> 1;
+    const long ld = isA ? p.lda : p.ldb;
+    const int ncols = isA ? p.M : p.N;
+    const int col = min((isA ? i0 : j0) + 2 * cg, ncols - 2);  // clamped columns only feed outputs never stored
+    const float *src = (isA ? p.A : p.B) + col;
+    const int plane_off = isA ? 0 : 3 * PL;
+    float2 rv[2][8];                                           // two register sets: stage s lives in set s & 1
+
+    const int nk = rbeg < rend ? (int)((rend - rbeg + 15) / 16) : 0;
+    auto load_stage = [&](int st, auto SET, auto KT) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        constexpr bool kt = decltype(KT)::value;
+        const long r0 = rbeg + (long)min(st, nk - 1) * 16 + 8 * rg;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            if (!kt) rv[set][d] = *reinterpret_cast<const float2 *>(src + (r0 + d) * ld);
+            else {
+                const float2 v = *reinterpret_cast<const float2 *>(src + min(r0 + d, rend - 1) * ld);
+                rv[set][d] = r0 + d < rend ? v : make_float2(0.f, 0.f);     // rows beyond the range contribute zero
+            }
+        }
+    };
+    auto store_stage = [&](auto SET, char *buf) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        const float2 *r = rv[set];
+        split8_store(make_float4(r[0].x, r[1].x, r[2].x, r[3].x), make_float4(r[4].x, r[5].x, r[6].x, r[7].x), buf + plane_off, PL,
+                     x6p_off<BM>(2 * cg, rg));
+        split8_store(make_float4(r[0].y, r[1].y, r[2].y, r[3].y), make_float4(r[4].y, r[5].y, r[6].y, r[7].y), buf + plane_off, PL,
+                     x6p_off<BM>(2 * cg + 1, rg));
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto stage = [&](int st, auto PAR, auto KT) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value;
+        const char *As = lds + par * STAGE, *Bs = As + 3 * PL;
+        bf16x8_t fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fa[i][t] = *reinterpret_cast<const bf16x8_t *>(As + t * PL + x6p_off<BM>(wm * 64 + i * 32 + r32, h));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fb[j][t] = *reinterpret_cast<const bf16x8_t *>(Bs + t * PL + x6p_off<BM>(wn * 64 + j * 32 + r32, h));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+            }
+        store_stage(std::integral_constant<int, par ^ 1>{}, lds + (par ^ 1) * STAGE);
+        load_stage(st + 3, std::integral_constant<int, par ^ 1>{}, KT);
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+            if (g % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+            if (g % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+        }
+        __syncthreads();
+    };
+    auto run = [&](auto KT) __attribute__((always_inline)) {
+        load_stage(0, I0{}, KT);
+        load_stage(1, I1{}, KT);
+        store_stage(I0{}, lds);
+        load_stage(2, I0{}, KT);
+        __syncthreads();
+        int st = 0;
+        for (; st + 1 < nk; st += 2) {
+            stage(st, I0{}, KT);
+            stage(st + 1, I1{}, KT);
+        }
+        if (st < nk) stage(st, I0{}, KT);
+    };
+    if (nk > 0) {
+        if ((rend - rbeg) % 16 != 0) run(std::true_type{}); else run(std::false_type{});
+    }
+
+    // slab[z][i][j]: i = i0 + wm*64 + it*32 + (e&3) + 8*(e>>2) + 4h ; j = j0 + wn*64 + jt*32 + r32
+    float *slab = p.slab + (long)bz * p.M * p.N;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm * 64 + it * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i >= p.M) continue;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j = j0 + wn * 64 + jt * 32 + r32;
+                if (j < p.N) slab[(long)i * p.N + j] = acc[it][jt][e];
+            }
+        }
+}
+
 // out = sum over slabs; optional Conv1d weight re-layout (column jj*cin+ci -> [ci][jj])
 __global__ void gemm_tn_reduce_kernel(const float *slab, int S, int M, int N, float *C, long ldc, int conv_cin, int conv_k)
 {
@@ -906,6 +1084,8 @@ static int tn_splits(int M, int N, long R, long *chunk_out)
 {
     const long tiles = cdiv(M, BM) * cdiv(N, BN);
     long S = 768 / tiles;                     // one full wave of 3 workgroups per CU (256 CUs)
+    static const char *splits_env = getenv("CPC_GEMM_TN_SPLITS");     // (tools/x6_sweep.py)
+    if (splits_env != nullptr) S = std::max(1, atoi(splits_env));
     const long max_s = cdiv(R, 4 * BK);      // at least 128 rows per split
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
@@ -944,9 +1124,13 @@ int gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long l
     dim3 grid((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM), (unsigned)S);
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
     a.xcd_remap = (!no_remap && S % 8 == 0 && grid.x * grid.y > 1) ? 1 : 0;
+    static const bool log_shapes = getenv("CPC_GEMM_LOG") != nullptr;
+    if (log_shapes) fprintf(stderr, "cpc_gemm tn M=%d N=%d R=%ld lda=%ld ldb=%ld ldc=%ld tile=128x128 grid=%ld splits=%d chunk=%ld kernel=%s\n", M, N, R, lda, ldb,
+                            ldc, cdiv(N, BN) * cdiv(M, BM), S, chunk, a.aligned ? "x6" : "f32");
     ProfScope prof(PROF_GEMM_TN, st);
     const bool native = g_gemm_mode.load() == 1;
-    if (a.aligned && !native) hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, dim3(256), 0, st, a);
+    if (a.aligned && !native && x6_pipelined()) hipLaunchKernelGGL(gemm_tn_x6p_kernel, grid, dim3(256), 0, st, a);
+    else if (a.aligned && !native) hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, dim3(256), 0, st, a);
     else if (a.aligned) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
     CPC_CHECK_LAUNCH("gemm_tn_kernel");

@@ -1517,6 +1517,7 @@ int side_tail_join(hipStream_t st)
     NceSide *side = nullptr;
     CPC_TRY(nce_side(&side, st));
     if (side->tail_pending) {
+        ProfScope held(PROF_SIDE_WAIT, st);          // (bench.py: how long `st` stands still here)
         CPC_CHECK_HIP(hipStreamWaitEvent(st, side->tail, 0));
         side->tail_pending = false;
     }
@@ -1548,7 +1549,10 @@ static int infonce_join(hipStream_t st)
     CPC_TRY(nce_side(&side, st));
     if (side->pending.load()) {
         CPC_TRY(infonce_deferred_start(st));
-        CPC_CHECK_HIP(hipStreamWaitEvent(st, side->late, 0));
+        {
+            ProfScope held(PROF_SIDE_WAIT, st);
+            CPC_CHECK_HIP(hipStreamWaitEvent(st, side->late, 0));
+        }
         side->pending.store(false);
     }
     return CPC_OK;

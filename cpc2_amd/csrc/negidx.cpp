@@ -274,6 +274,15 @@ extern "C" int cpc_negidx_wait(cpc_mt19937 *g)
     return st;
 }
 
+// the worker's stream (NULL before its first device job), for diagnostics
+extern "C" int cpc_negidx_stream(cpc_mt19937 *g, cpc_stream_t *out)
+{
+    if (g == nullptr || out == nullptr) { cpc::set_error("cpc_negidx_stream: null argument"); return CPC_ERR_INVALID; }
+    (void)join_job(g);
+    *out = g->stream;
+    return CPC_OK;
+}
+
 // The same hand-over WITHOUT blocking the host on the device: waits for the worker's host part (the draw and the enqueue of
 // copy + expansion), then makes `stream` wait for the event behind them.
 extern "C" int cpc_negidx_wait_on(cpc_mt19937 *g, cpc_stream_t stream)

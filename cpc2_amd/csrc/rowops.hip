@@ -31,12 +31,12 @@ struct ProfRec { int slot; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static const char *kProfNames[PROF_SLOTS] = {"gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd", "gru_fwd", "gru_bwd",
-                                             "conv0_fwd", "conv0_bwd", "gemm_planes_nt", "gemm_planes_tn"};
+                                             "conv0_fwd", "conv0_bwd", "gemm_planes_nt", "gemm_planes_tn", "side_wait"};
 
 ProfScope::ProfScope(int slot, hipStream_t st, bool attached) : attached_(attached), slot_(slot), st_(st), active_(false)
 {
     const int on = g_prof_on.load(std::memory_order_relaxed);
-    if (on == 0 || (on == 2 && slot != PROF_PLANES_NT) || (on == 3 && slot != PROF_GEMM_NT)) return;
+    if (on == 0 || (on == 2 && slot != PROF_PLANES_NT && slot != PROF_SIDE_WAIT) || (on == 3 && slot != PROF_GEMM_NT && slot != PROF_SIDE_WAIT)) return;
     if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) return;
     active_ = attached_ ? true : hipEventRecord(a_, st_) == hipSuccess;
 }

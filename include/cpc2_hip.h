@@ -347,6 +347,7 @@ int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_d
 int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
                                     int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream);
 int cpc_negidx_wait_on(cpc_mt19937 *g, cpc_stream_t stream);
+int cpc_negidx_stream(cpc_mt19937 *g, cpc_stream_t *out);      /* the worker's stream (NULL before its first device job) */
 int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,
                       cpc_stream_t stream);
 
