@@ -73,6 +73,10 @@ CONFIGS = {
     # the reference's own dataflow: CPCModel.forward on all 2b windows (the context network also on the b windows whose context
     # train.py:102 drops) -- what the headline was measured on up to round 4; identical results (tests/test_gpu_parity.py)
     "small_strict": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", strict=True),
+    # the REAL loop around the same step (dataset.py:300-325,366-408 -> train.py:95-134): WAV files on disk -> findAllSeqs ->
+    # AudioBatchData (flat audio resident in HBM) -> getDataLoader(64, "samespeaker", randomOffset) -> cpc2_amd.train.trainStep
+    # (its own logging at the reference's default logging_step = 1000), one epoch of >= 200 steps: measure_feeder()
+    "small_feeder": dict(hidden=256, layers=1, npred=12, nneg=128, ar="GRU", feeder=True),
 }
 GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
 CONV = ((10, 5, 3), (8, 4, 2), (4, 2, 1), (4, 2, 1), (4, 2, 1))
@@ -563,6 +567,123 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     return out
 
 
+def write_synthetic_corpus(root, n_windows, n_speakers=16, files_per_speaker=8, seed=7):
+    """16-bit mono 16 kHz WAV files of gaussian noise at speech-like RMS, `n_speakers` directories: a little more than
+    n_windows * 20480 samples in all (librispeech-like layout: speaker / file)."""
+    import numpy as np
+    import struct
+    rs = np.random.RandomState(seed)
+    n_files = n_speakers * files_per_speaker
+    per_file = (n_windows * WINDOW) // n_files + WINDOW + 1
+    for spk in range(n_speakers):
+        d = os.path.join(root, f"spk{spk:03d}")
+        os.makedirs(d, exist_ok=True)
+        for i in range(files_per_speaker):
+            pcm = np.clip(rs.standard_normal(per_file) * (0.05 * 32768.0), -32768, 32767).astype("<i2").tobytes()
+            with open(os.path.join(d, f"utt{i:03d}.wav"), "wb") as fh:
+                fh.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+                         + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    return n_files * per_file
+
+
+def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate):
+    """One epoch of cpc2_amd.train.trainStep fed by the window feeder from files on disk; returns the record (rank 0) or None."""
+    import random
+    import shutil
+    import tempfile
+    from cpc2_amd import _lib
+    from cpc2_amd.dataset import AudioBatchData, findAllSeqs
+    from cpc2_amd.train import DataParallelContext, backward, cpcStep, trainStep
+    cfg = CONFIGS[cfg_name]
+    lib = _lib.load()
+    steps_wanted = max(200, args.steps * 10)
+    model, crit, opt = build(cfg, device)
+    dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()), timing=False)
+    crit.seed(1234 + rank)
+    crit.sampler.prefetch = True
+    tmp = tempfile.mkdtemp(prefix="cpc_feeder_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t_a = time.perf_counter()
+        total = write_synthetic_corpus(tmp, steps_wanted * args.batch, seed=7 + rank)
+        t_b = time.perf_counter()
+        random.seed(11 + rank)
+        seqs, speakers = findAllSeqs(tmp, extension=".wav")
+        data = AudioBatchData(tmp, WINDOW, seqs, None, len(speakers), device=device)
+        t_c = time.perf_counter()
+        log(f"{cfg_name}: {total / 16000.0 / 3600.0:.2f} h of synthetic audio in {len(seqs)} files written in {t_b - t_a:.1f} s, loaded to the device in {t_c - t_b:.1f} s")
+        loader = data.getDataLoader(args.batch, "samespeaker", True)
+        # warm-up on the feeder's own windows (arena growth, first-use costs)
+        it = iter(loader)
+        for _ in range(5):
+            seq, label = next(it)
+            tot, _l, _a = cpcStep(seq[:, 0], seq[:, 1], label, model, crit, dp=dp)
+            backward(tot)
+            dp.reduce_and_step()
+            opt.zero_grad()
+        del it
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        loader = data.getDataLoader(args.batch, "samespeaker", True)
+        n_batches = len(loader)
+        _lib.HOST_WAITS.clear()
+        cpu0, thr0 = time.process_time(), time.thread_time()
+        clocks = ClockSampler(device)
+        import contextlib
+        import io
+        printed = io.StringIO()
+        with clocks, contextlib.redirect_stdout(printed):
+            t0 = time.perf_counter()
+            seen = [0]
+
+            def counted(it):                          # (the same-speaker sampler ends every speaker with a partial batch)
+                for item in it:
+                    seen[0] += int(item[0].size(0))
+                    yield item
+            logs = trainStep(counted(loader), model, crit, opt, None, 1000, dp=dp)          # logging_step: the reference's default
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        cpu_s, thr_s = time.process_time() - cpu0, time.thread_time() - thr0
+        waits = dict(_lib.HOST_WAITS)
+        if use_dist:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax[0].item())
+        iters, windows = int(logs["iter"]), seen[0]
+        if use_dist:
+            wsum = torch.tensor([windows], dtype=torch.float64, device=device)
+            dist.all_reduce(wsum)
+            windows = int(wsum[0].item())
+        _lib.check(lib.cpc_async_error_check(_lib.stream_ptr(device)), "async error check")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if rank != 0:
+        return None
+    ms = 1e3 * elapsed / iters
+    return {
+        "metric": "audio-seconds/sec CPC training (1.28 s @16 kHz, 128 neg)",
+        "value": round(windows * SECONDS_PER_WINDOW / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world,
+        "steps": iters, "warmup": 5, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic audio FILES (16-bit WAV, written to a temporary directory) through the window feeder",
+        "config": {"workload": f"CPC-{cfg_name}: the reference's loop around the headline step -- findAllSeqs -> AudioBatchData (flat audio in "
+                               f"HBM) -> getDataLoader({args.batch}, 'samespeaker', randomOffset=True) -> cpc2_amd.train.trainStep (logging_step "
+                               f"1000: train.py:596), one epoch of {iters} steps of {args.batch} windows; dataset.py:300-325,366-408, train.py:95-134",
+                   "windows_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                   "final_losses": [round(float(v), 4) for v in logs["locLoss_train"]],
+                   "windows": windows, "mean_batch": round(windows / max(1, iters * world), 2), "epoch_batches_announced": n_batches},
+        # audio-seconds per second against the headline's (windows already resident, every batch full) in the same run
+        "vs_resident_synthetic": None if not resident_rate else round(windows * SECONDS_PER_WINDOW / elapsed / resident_rate, 4),
+        "host": {"cores": PINNED_CORES if PINNED_CORES is not None else host_cores(), "pinned": PINNED_CORES is not None,
+                 "loop_ms_per_step": round(1e3 * t_host / iters, 3),          # wall time of trainStep's loop per step (waits included)
+                 "blocked_ms_per_step": {k: round(1e3 * v / iters, 3) for k, v in sorted(waits.items())},
+                 "busy_ms_per_step": round(1e3 * (t_host - sum(waits.values())) / iters, 3),
+                 "thread_cpu_ms_per_step": round(1e3 * thr_s / iters, 3), "process_cpu_ms_per_step": round(1e3 * cpu_s / iters, 3),
+                 "host_done_before_device_ms": round(1e3 * (elapsed - t_host), 3), "gpu_clock": clocks.record(),
+                 "corpus_s": round(t_b - t_a, 1), "load_s": round(t_c - t_b, 1)},
+    }
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -661,7 +782,10 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
 
-    out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
+    if CONFIGS[args.config].get("feeder"):
+        out = measure_feeder(args, args.config, device, rank, world, use_dist, None)
+    else:
+        out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
     if out is not None:
         comm = {"world": world, "process_group": backend if use_dist else None}
         if use_dist and backend == "nccl":
@@ -679,14 +803,17 @@ def main():
     also = args.also
     if also is None:
         # (N > 1: the line still carries BASELINE configs[4] -- CPC-large is DEFINED as the 8-GPU data-parallel config)
-        also = ("large,transformer,small_strict,small_3term,small_dedup" if world == 1 else "large") \
+        also = ("large,transformer,small_strict,small_feeder,recipe,small_3term,small_dedup" if world == 1 else "large") \
             if (args.config == "small" and not args.no_prof) else ""
     others = []
     for name in [n for n in also.split(",") if n]:
         # (an extra configuration must never cost the headline its line: a failure is recorded in its place.  Every rank runs the
         #  same code on the same shapes, so an exception is raised on every rank alike and no collective is left half-entered)
         try:
-            rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
+            if CONFIGS[name].get("feeder"):
+                rec = measure_feeder(args, name, device, rank, world, use_dist, out["value"] if (out and args.config == "small") else None)
+            else:
+                rec = measure(args, name, device, rank, world, use_dist, max(5, args.steps // 2), 3, 0.0)
         except Exception as exc:                                   # noqa: BLE001
             log(f"{name}: FAILED: {exc!r}")
             rec = {"config": {"workload": f"CPC-{name}"}, "error": repr(exc)[:400]} if rank == 0 else None

@@ -1502,6 +1502,18 @@ def test_feeder_windows_on_device_match_host_slices():
     random.seed(3)
     batches = list(dev_data.getDataLoader(8, "uniform", True))
     assert len(batches) >= 5 and all(s.is_cuda and s.shape == (8, 2, 1, 20480) for s, _ in batches)
+    # the device loader (a pack's offsets uploaded once, speaker labels looked up on the device) yields what the host loader
+    # yields, batch for batch -- windows AND labels, ragged last batches of a speaker included (dataset.py:300-330)
+    for kind in ("samespeaker", "samesequence", "temporalsamespeaker", "sequential"):
+        torch.manual_seed(5)
+        random.seed(5)
+        on_dev = list(dev_data.getDataLoader(8, kind, True))
+        torch.manual_seed(5)
+        random.seed(5)
+        on_cpu = list(cpu_data.getDataLoader(8, kind, True))
+        assert len(on_dev) == len(on_cpu) > 0, kind
+        for (sd, ld), (sc, lc) in zip(on_dev, on_cpu):
+            assert torch.equal(sd.cpu(), sc) and torch.equal(ld.cpu(), lc), kind
 
 
 def _small_model(hidden=64):
