@@ -98,9 +98,14 @@ def grad_home(t):
     home = getattr(t, "_cpc_grad_home", None)
     if home is None or not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         return None
+    # ONE consumer per home: a second function that takes the same tagged tensor would write the same memory, and autograd would
+    # then add the buffer to itself (twice the last gradient, no error).  The first forward that honours the home claims it.
+    if getattr(t, "_cpc_grad_home_claimed", False):
+        return None
     full_shape, _slot, start = home
     if tuple(t.shape[1:]) != tuple(full_shape[1:]) or start + t.shape[0] > full_shape[0]:
         return None
+    t._cpc_grad_home_claimed = True
     return home
 
 

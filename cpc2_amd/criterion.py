@@ -37,6 +37,7 @@ class NegativeSampler:
         self._prefetched = None
         self._last = None             # (key, slot) of the previous device-side call: its buffers' release event is recorded by the next one
         self.prefetch = False         # opt-in: draw step i+1's words during step i (private stream, fixed shapes)
+        self.alias_ring = False       # opt-in with prefetch: sample() returns one of RING persistent buffers instead of a copy of it
 
     def __del__(self):
         try:
@@ -122,7 +123,10 @@ class NegativeSampler:
             with _lib.host_wait("sampler_worker"):
                 check(self._lib.cpc_negidx_wait_on(self._h, _lib.stream_ptr(device)), "negidx_wait_on")
             if self._prefetched[2] == shape:
-                ext = self._ext_ring[key][slot]
+                # (a COPY of the ring buffer, 3.8 MB at the benchmark shape: the worker rewrites the buffer RING - 1 calls later, and
+                #  a caller may keep the indices -- saved for a backward that runs late, logged, compared -- for longer than that;
+                #  `alias_ring = True` hands out the buffer itself to a caller that consumes it before the next RING - 1 samples)
+                ext = self._ext_ring[key][slot] if self.alias_ring else self._ext_ring[key][slot].clone()
             else:                              # (the same number of words for another shape: the words are right, the expansion is not)
                 ext = torch.empty(n, dtype=torch.int32, device=device)
                 check(self._lib.cpc_negidx_expand(ptr(dev_ring[slot]), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),

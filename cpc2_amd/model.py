@@ -503,7 +503,10 @@ class CPCModel(nn.Module):
         return features
 
     def forward(self, batchData, label):
-        if hasattr(self.gEncoder, "forward_channel_last"):
+        # (an encoder with forward hooks -- feature taps, profilers -- is CALLED, so that they fire; its channel-first output is
+        #  then permuted as the reference does, model.py:382)
+        hooked = bool(self.gEncoder._forward_hooks or self.gEncoder._forward_pre_hooks)
+        if hasattr(self.gEncoder, "forward_channel_last") and not hooked:
             encodedData = self.gEncoder.forward_channel_last(batchData)      # [N, T, H], contiguous
         else:
             encodedData = self.gEncoder(batchData).permute(0, 2, 1)

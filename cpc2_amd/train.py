@@ -424,6 +424,11 @@ def _context_windows_only(cpcModel):
         return False
     if not hasattr(cpcModel.gEncoder, "forward_channel_last"):
         return False
+    # this form calls gEncoder.forward_channel_last and gAR directly: forward (pre-)hooks registered on the model or its encoder
+    # (feature taps, profilers) would silently stop firing -- with hooks the reference's own call is kept
+    for m in (cpcModel, cpcModel.gEncoder):
+        if m._forward_hooks or m._forward_pre_hooks:
+            return False
     ar = cpcModel.gAR
     if isinstance(ar, CPCAR):
         return not ar.keepHidden and ar.hidden is None

@@ -2773,3 +2773,63 @@ def test_library_streams_run_beside_the_training_stream():
     assert lib.cpc_stream_apart_failures() == 0
     torch.cuda.synchronize()
     del crowd
+
+
+def test_prefetched_indices_outlive_the_staging_ring():
+    """With `prefetch` the sampler's worker rewrites one of RING persistent device buffers RING - 1 calls after it was filled.
+    What sample() hands out is a copy: indices kept across more than 2 * RING later calls (saved for a late backward, logged) still
+    equal the host sampler's -- and with `alias_ring` (the opt-in) they demonstrably do not."""
+    b, t_len, k, nn = 4, 64, 12, 32
+    ref, dev, alias = (cpc2_amd.criterion.NegativeSampler() for _ in range(3))
+    for smp in (ref, dev, alias):
+        smp.seed(9)
+    dev.prefetch = alias.prefetch = True
+    alias.alias_ring = True
+    n = 2 * cpc2_amd.criterion.NegativeSampler.RING + 3
+    want = [ref.sample_host(b, t_len, t_len - k, nn, time_major=True).clone() for _ in range(n)]
+    kept = [dev.sample(b, t_len, t_len - k, nn, torch.device(DEV)) for _ in range(n)]
+    kept_alias = [alias.sample(b, t_len, t_len - k, nn, torch.device(DEV)) for _ in range(n)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(g.cpu(), w) for g, w in zip(kept, want))
+    assert torch.equal(kept_alias[-1].cpu(), want[-1])
+    assert not all(torch.equal(g.cpu(), w) for g, w in zip(kept_alias, want)), "the ring was expected to have wrapped"
+
+
+def test_a_gradient_home_serves_one_consumer():
+    """split_windows tags its parts with a fixed place in the encoder output's gradient buffer; the first function that consumes a
+    part writes there in place.  A SECOND consumer of the same part (a subclass that runs two recurrent nets on x) must get a buffer
+    of its own -- both writing the home would make autograd add the buffer to itself."""
+    from cpc2_amd.criterion import split_windows
+    hidden, n, t_len = 256, 6, 32
+    torch.manual_seed(2)
+    ar1 = cpc2_amd.CPCAR(hidden, hidden, False, 1).to(DEV)
+    ar2 = cpc2_amd.CPCAR(hidden, hidden, False, 1).to(DEV)
+    x = torch.randn(n, t_len, hidden, device=DEV)
+    gout = torch.randn(n // 2, t_len, hidden, device=DEV)
+
+    def run(tagged):
+        xin = x.clone().requires_grad_(True)
+        first = split_windows(xin, n // 2)[0] if tagged else xin[:n // 2]
+        out = ar1(first) + 2.0 * ar2(first)
+        (out * gout).sum().backward()
+        return xin.grad.clone()
+    plain, tagged = run(False), run(True)
+    assert float(plain[n // 2:].abs().max()) == 0.0 and float(tagged[n // 2:].abs().max()) == 0.0
+    assert_close(tagged[:n // 2], plain[:n // 2], 2e-6, "gradient of a part with two consumers")
+
+
+def test_forward_hooks_keep_the_reference_call():
+    """cpcStep's default form calls the encoder and the context network directly; a forward hook on the model or the encoder would then
+    never fire.  With a hook registered the step goes through CPCModel.__call__ (the reference's own call) -- same losses."""
+    model, crit = _step_model(256, 1, "GRU", 32)
+    x = synth.audio_windows(4, 20480, 31).to(DEV)
+    label = torch.zeros(4, dtype=torch.long, device=DEV)
+    crit.seed(3)
+    _tot, base, _ = cpcStep(x, x, label, model, crit)
+    fired = []
+    handle = model.gEncoder.register_forward_hook(lambda mod, inp, out: fired.append(tuple(out.shape)))
+    crit.seed(3)
+    _tot, hooked, _ = cpcStep(x, x, label, model, crit)
+    handle.remove()
+    assert fired == [(8, 256, 128)], fired
+    assert_close(hooked, base, 1e-6, "losses with a forward hook on the encoder")
