@@ -407,6 +407,27 @@ __device__ __forceinline__ float4 norm_in4(const NormArgs &a, long m, int H, int
     return acc;
 }
 
+// (sample n, row r inside it) of signal row `base + off`, R rows per sample.  `base` is the same for the whole workgroup (a function
+// of blockIdx and loop counters): ITS division is one scalar-unit sequence per tile; the lanes add their small offset and carry.
+// Rounds 1-5 wrote `row / R` per row and lane: a 64-bit division by a run-time value is ~70 VALU instructions -- a third of
+// conv0_fwd_pl_kernel's vector work (87 M of them per launch, the kernel's time at four cycles each: profiles/r06_a_kernel_counters.txt).
+struct RowBase { long n; int r; };
+__device__ __forceinline__ RowBase row_base(long base, int R)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)base >> 32));
+    const long b = (long)(((unsigned long long)hi << 32) | lo);
+    RowBase q;
+    q.n = b / R;
+    q.r = (int)(b - q.n * R);
+    return q;
+}
+__device__ __forceinline__ void row_at(const RowBase &q, int off, int R, long &n, int &r)
+{
+    n = q.n;
+    r = q.r + off;
+    while (r >= R) { r -= R; ++n; }          // (off is a few rows: at most one trip unless the samples are shorter than a tile)
+}
+
 template <int H> __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs a)
 {
     using Cfg = RowCfg<H>;
@@ -426,8 +447,10 @@ template <int H> __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs
     for (long base = (long)blockIdx.x * 4 * RPW; base < total; base += stride) {
         const long row = base + wave * RPW + gi;          // row of Y
         const bool in_range = row < total;
-        const int n = in_range ? (int)(row / a.Rnext) : 0;
-        const int t = in_range ? (int)(row - (long)n * a.Rnext) - a.halo : -1;
+        long nl; int rr;
+        row_at(row_base(base, a.Rnext), wave * RPW + gi, a.Rnext, nl, rr);
+        const int n = in_range ? (int)nl : 0;
+        const int t = in_range ? rr - a.halo : -1;
         const bool valid = in_range && t >= 0 && t < a.Lout;
         const long m = (long)n * a.Rv + (valid ? t : 0);
         float4 x4[VPL];
@@ -490,8 +513,10 @@ template <int H> __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs
     for (long base = (long)blockIdx.x * 4 * RPW; base < total; base += stride) {
         const long row = base + wave * RPW + gi;
         const bool in_range = row < total;
-        const int n = in_range ? (int)(row / a.Rv) : 0;
-        const int t = in_range ? (int)(row - (long)n * a.Rv) - 1 : -1;
+        long nl; int rr;
+        row_at(row_base(base, a.Rv), wave * RPW + gi, a.Rv, nl, rr);
+        const int n = in_range ? (int)nl : 0;
+        const int t = in_range ? rr - 1 : -1;
         const bool valid = in_range && n < a.N && t >= 0 && t < a.Lout;
         const long m = (long)n * a.Rv + (valid ? t : 0);
         const float rstd = valid ? a.rstd[m] : 0.f;
@@ -628,15 +653,16 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
 
     // three samples per thread and group (64 rows x 10 taps = 640 = 2.5 x 256), requested together
     auto fetch = [&](long grp, float (&v)[3]) {
+        const RowBase fq = row_base(grp * 64, a.R0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int i = threadIdx.x + 256 * q;
             v[q] = 0.f;
             if (i < 64 * C0_K && grp < n_groups) {
                 const int slot = i / C0_K, j = i - slot * C0_K;
-                const long row = grp * 64 + slot;
-                const long n = row / a.R0;
-                const int t = (int)(row - n * a.R0) - a.halo;
+                long n; int rr;
+                row_at(fq, slot, a.R0, n, rr);
+                const int t = rr - a.halo;
                 const int pos = C0_S * t - C0_P + j;
                 if (n < a.N && t >= 0 && t < a.L1 && pos >= 0 && pos < a.L0) v[q] = conv0_window(a, n)[pos];
             }
@@ -658,6 +684,7 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
         }
     for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const long G0 = grp * 64;
+    const RowBase gq = row_base(G0, a.R0);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         if (threadIdx.x + 256 * q < 64 * C0_K) xs[threadIdx.x + 256 * q] = xnext[q];
@@ -667,9 +694,9 @@ template <int H> __global__ __launch_bounds__(256) void conv0_fwd_pl_kernel(Conv
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int r16 = pass * 4 + wave, slot = sub * 16 + r16;
-            const long row = G0 + slot;
-            const long n = row / a.R0;
-            const int t = (int)(row - n * a.R0) - a.halo;
+            long n; int rr;
+            row_at(gq, slot, a.R0, n, rr);
+            const int t = rr - a.halo;
             const bool valid = n < a.N && t >= 0 && t < a.L1;
             float xr[C0_K];
 #pragma unroll
@@ -757,15 +784,16 @@ template <int H> __global__ __launch_bounds__(256) void norm_fwd_pl_kernel(NormA
             bet[v][e] = a.beta[(v * G + gl) * 4 + e];
         }
     for (long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const RowBase tq = row_base(tl * 16, a.Rnext);
         // the four rows of this wave are requested together: a row is a load -> use chain
         float4 x4[4][VPL];
         long mrow[4];
         bool ok[4];
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-            const long row = tl * 16 + pass * 4 + wave;
-            const long n = row / a.Rnext;
-            const int t = (int)(row - n * a.Rnext) - a.halo;
+            long n; int rr;
+            row_at(tq, pass * 4 + wave, a.Rnext, n, rr);
+            const int t = rr - a.halo;
             ok[pass] = n < a.N && t >= 0 && t < a.Lout;
             mrow[pass] = n * a.Rv + (ok[pass] ? t : 0);
 #pragma unroll
@@ -825,14 +853,15 @@ template <int H> __global__ __launch_bounds__(256) void norm_bwd_pl_kernel(NormA
             dg[v][e] = dbe[v][e] = dbi[v][e] = 0.f;
         }
     for (long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const RowBase tq = row_base(tl * 16, a.Rv);
         float4 x4[4][VPL], g4[4][VPL];
         float rs[4];
         bool ok[4];
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-            const long row = tl * 16 + pass * 4 + wave;
-            const long n = row / a.Rv;
-            const int t = (int)(row - n * a.Rv) - 1;
+            long n; int rr;
+            row_at(tq, pass * 4 + wave, a.Rv, n, rr);
+            const int t = rr - 1;
             ok[pass] = n < a.N && t >= 0 && t < a.Lout;
             const long m = n * a.Rv + (ok[pass] ? t : 0);
             rs[pass] = ok[pass] ? a.rstd[m] : 0.f;

@@ -239,6 +239,7 @@ template <int DBG, bool TN, int TERMS = 6, bool NORM = false, bool PAIR = false>
         ks0 = 0;
         rbeg = (long)bz * p.rchunk;
         slab_z = bz;
+        if (rbeg >= p.R) return;                                        // (a slab slot past the last slab: the grid's z is padded to a multiple of 8)
         nst = (int)((min(p.R, rbeg + p.rchunk) - rbeg) / PT_BK);        // even, >= 2
         // wave w fills the 32 columns (two chunks) 32 w .. 32 w + 31 of both tiles; lane -> (4-row group, chunk, row, half)
         const int rowp = 4 * (lane >> 4) + ((lane >> 1) & 3), ch = (lane >> 3) & 1, half = lane & 1;
@@ -874,20 +875,31 @@ __global__ void planes_tn_reduce_kernel(const float *slab, int S, int M, int N, 
     }
 }
 
-static int tn_planes_splits(int M, int N, long R, long *chunk_out)
+// slabs of `chunk` reduction rows: as many as give every CU one workgroup in ONE round.  *slots_out = the grid's z: the slab count
+// padded to a multiple of 8, so that all tiles of a slab share an XCD (gemm_planes_kernel, xcd_remap) whatever the count -- the
+// padding slots' workgroups leave at once.  (Rounds 2-5 looked for a chunk whose slab count WAS a multiple of 8: conv3's weight
+// gradient then ran as 4 x 40 = 160 workgroups of 52 stages on 256 CUs, conv4's as 192 of 22, conv2's as 224 of 74; now 244 of
+// 34, 232 of 18, 252 of 66.  CPC_PLANES_TN_OLD_SPLITS=1 keeps the old rule for A/B runs.)
+static int tn_planes_splits(int M, int N, long R, long *chunk_out, int *slots_out = nullptr)
 {
     const long tiles = (long)(M / PT_BM) * (N / PT_BN);
     const long Rp = cdiv(R, 32) * 32;
     long S = std::max<long>(1, (256 + tiles / 2) / tiles);            // one workgroup per CU, one round
     S = std::min(S, std::max<long>(1, Rp / 128));
     long chunk = cdiv(cdiv(Rp, S), 32) * 32;
-    // a slab count that is a multiple of 8 lets all tiles of a slab share an XCD (gemm_planes_kernel, xcd_remap): look for
-    // one among slightly larger chunks
-    if (S >= 8 && tiles > 1)
-        for (long c = chunk; c <= chunk + 32 * 16; c += 32)
-            if (cdiv(Rp, c) % 8 == 0) { chunk = c; break; }
+    static const bool old_rule = getenv("CPC_PLANES_TN_OLD_SPLITS") != nullptr;
+    if (old_rule) {
+        if (S >= 8 && tiles > 1)
+            for (long c = chunk; c <= chunk + 32 * 16; c += 32)
+                if (cdiv(Rp, c) % 8 == 0) { chunk = c; break; }
+        *chunk_out = chunk;
+        if (slots_out != nullptr) *slots_out = (int)cdiv(Rp, chunk);
+        return (int)cdiv(Rp, chunk);
+    }
+    const long slabs = cdiv(Rp, chunk);
     *chunk_out = chunk;
-    return (int)cdiv(Rp, chunk);
+    if (slots_out != nullptr) *slots_out = (int)((slabs >= 8 && tiles > 1) ? cdiv(slabs, 8) * 8 : slabs);
+    return (int)slabs;
 }
 
 bool gemm_tn_planes_ok(int M, int N, long R) { return M % PT_BM == 0 && N % PT_BN == 0 && R >= 64; }
@@ -910,7 +922,8 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     };
     CPC_REQUIRE(!bad(A) && !bad(B), "gemm_tn_planes: bad operand");
     long chunk;
-    const int S = tn_planes_splits(M, N, R, &chunk);
+    int slots = 0;
+    const int S = tn_planes_splits(M, N, R, &chunk, &slots);
     if ((size_t)S * M * N * sizeof(float) > scratch_bytes) {
         set_error("gemm_tn_planes: scratch too small (%zu < %zu)", scratch_bytes, (size_t)S * M * N * sizeof(float));
         return CPC_ERR_WORKSPACE;
@@ -923,10 +936,10 @@ int gemm_tn_planes(const PlanesTNOperand &A, const PlanesTNOperand &B, float *C,
     a.M = M; a.N = N; a.K = 0; a.slabs = static_cast<float *>(scratch);
     a.dbg = 0;
     static const bool no_remap = getenv("CPC_GEMM_NO_XCD") != nullptr;
-    a.xcd_remap = (!no_remap && S % 8 == 0 && (M / PT_BM) * (N / PT_BN) > 1) ? 1 : 0;
+    a.xcd_remap = (!no_remap && slots % 8 == 0 && (M / PT_BM) * (N / PT_BN) > 1) ? 1 : 0;
     {
         ProfScope prof(PROF_PLANES_TN, st);
-        const dim3 grid((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)S);
+        const dim3 grid((unsigned)(N / PT_BN), (unsigned)(M / PT_BM), (unsigned)slots);
         const int rc = gemm_mode() == 2 ? launch_planes<0, true, 3, false, false>(grid, a, st) : launch_planes<0, true, 6, false, false>(grid, a, st);
         if (rc != CPC_OK) return rc;
     }
