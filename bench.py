@@ -263,16 +263,16 @@ def cpu_baseline(cfg, seconds_budget):
             "by_batch": {"b8": r8, "b16": r16}}
 
 
-class ClockSampler:
-    """What the GPU box itself was doing while the timed region ran, sampled from a thread (sysfs, ~50 Hz): this GPU's shader-clock
-    level and power, and how many OTHER GPUs of the host were busy (the box is one GPU of a shared 8-GPU host).  A run in which every
-    kernel is slower (seen in round 6: 6.68 against 4.9 ms per step, the latency-bound kernels hit hardest, every stream on its own
-    queue, `training_stream_held_by_side_stream` normal) is then told apart from one in which the step's own schedule went wrong."""
+class GpuBoxSnapshot:
+    """What the GPU box itself was doing: this GPU's shader-clock level and power and how many OTHER GPUs of the host were busy (the
+    box is one GPU of a shared 8-GPU host), ONE read of sysfs taken OUTSIDE the timed region while a few extra steps are queued on
+    the device.  (Read from a thread inside the timed region -- the first form, at 50 Hz and then once -- it was the disturbance:
+    every read is a request to the GPU's power controller; a rank pinned to two cores went from 4.9 to 20 ms per step, and a single
+    read cost the region 20 ms of wall time and once a 23 ms step: profiles/r06_process_group_queues.md, section 5.)"""
 
-    def __init__(self, device, period=0.02):
+    def __init__(self, device):
         import glob
-        import threading
-        self.own, self.others = None, []
+        self.own, self.others, self.power = None, [], None
         try:
             pr = torch.cuda.get_device_properties(device)
             want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
@@ -285,14 +285,9 @@ class ClockSampler:
                 self.own = c
             else:
                 self.others.append(c)
-        self.power = None
         if self.own is not None:
-            import glob as g2
-            hits = g2.glob(os.path.join(self.own, "hwmon", "hwmon*", "power1_average")) + g2.glob(os.path.join(self.own, "hwmon", "hwmon*", "power1_input"))
+            hits = glob.glob(os.path.join(self.own, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(self.own, "hwmon", "hwmon*", "power1_input"))
             self.power = hits[0] if hits else None
-        self.sclk, self.watts, self.busy_others = [], [], []
-        self.period, self._stop = period, threading.Event()
-        self._thread = threading.Thread(target=self._run, daemon=True) if self.own is not None else None
 
     @staticmethod
     def _read(path):
@@ -301,45 +296,24 @@ class ClockSampler:
         except OSError:
             return ""
 
-    def _run(self):
-        while not self._stop.is_set():
-            for ln in self._read(os.path.join(self.own, "pp_dpm_sclk")).splitlines():
-                if ln.rstrip().endswith("*"):
-                    digits = "".join(ch for ch in ln.split(":")[-1] if ch.isdigit())
-                    if digits:
-                        self.sclk.append(int(digits))
-            if self.power is not None:
-                txt = self._read(self.power).strip()
-                if txt.isdigit():
-                    self.watts.append(int(txt) / 1e6)
-            n = 0
-            for c in self.others:
-                txt = self._read(os.path.join(c, "gpu_busy_percent")).strip()
-                n += 1 if (txt.isdigit() and int(txt) >= 20) else 0
-            self.busy_others.append(n)
-            self._stop.wait(self.period)
-
-    def __enter__(self):
-        if self._thread is not None:
-            self._thread.start()
-        return self
-
-    def __exit__(self, *exc):
-        self._stop.set()
-        if self._thread is not None:
-            self._thread.join()
-        return False
-
-    def record(self):
-        if self.own is None or not self.sclk:
+    def take(self):
+        if self.own is None:
             return None
-        v = sorted(self.sclk)
-        rec = {"card": self.own.split("/")[4], "samples": len(v), "sclk_level_mhz_min": v[0], "sclk_level_mhz_median": v[len(v) // 2],
-               "sclk_level_mhz_max": v[-1], "other_gpus_of_the_host": len(self.others),
-               "other_gpus_busy_max": max(self.busy_others) if self.busy_others else None}
-        if self.watts:
-            w = sorted(self.watts)
-            rec.update(power_w_min=round(w[0]), power_w_median=round(w[len(w) // 2]), power_w_max=round(w[-1]))
+        rec = {"card": self.own.split("/")[4], "taken": "during extra steps after the timed region", "other_gpus_of_the_host": len(self.others)}
+        for ln in self._read(os.path.join(self.own, "pp_dpm_sclk")).splitlines():
+            if ln.rstrip().endswith("*"):
+                digits = "".join(ch for ch in ln.split(":")[-1] if ch.isdigit())
+                if digits:
+                    rec["sclk_level_mhz"] = int(digits)
+        if self.power is not None:
+            txt = self._read(self.power).strip()
+            if txt.isdigit():
+                rec["power_w"] = round(int(txt) / 1e6)
+        busy = 0
+        for c in self.others:
+            txt = self._read(os.path.join(c, "gpu_busy_percent")).strip()
+            busy += 1 if (txt.isdigit() and int(txt) >= 20) else 0
+        rec["other_gpus_busy"] = busy
         return rec
 
 
@@ -366,7 +340,11 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     # N > 1: the criterion / context-network gradient slices are all-reduced under the encoder's backward (train.py)
     dp = DataParallelContext(opt, early_params=list(crit.parameters()) + list(model.gAR.parameters()),
                              overlap=not os.environ.get("CPC_BENCH_NO_OVERLAP"), timing=True)
-    crit.seed(1234 + rank)                                  # per-rank negative stream
+    if os.environ.get("CPC_BENCH_FOLLOW_TORCH"):
+        # the module's default: the negatives come from torch's global CPU generator, as the reference's torch.randint calls do
+        torch.manual_seed(1234 + rank)
+    else:
+        crit.seed(1234 + rank)                              # per-rank negative stream
     crit.sampler.prefetch = True                            # host draws step i+1's MT19937 words during step i
     g = torch.Generator().manual_seed(1000 + rank)          # per-rank shard of the synthetic utterances
     x = (0.05 * torch.randn(args.batch, 1, WINDOW, generator=g)).to(device)
@@ -401,18 +379,16 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
     _lib.HOST_WAITS.clear()
     enqueue_s = 0.0
     cpu0, thr0 = time.process_time(), time.thread_time()
-    clocks = ClockSampler(device)
-    with clocks:
-        marks[0].record()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            ta = time.perf_counter()
-            losses = step()
-            enqueue_s += time.perf_counter() - ta
-            marks[i + 1].record()
-        t_enqueued = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        own_elapsed = time.perf_counter() - t0              # this rank's own clock (before the closing barrier)
+    marks[0].record()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ta = time.perf_counter()
+        losses = step()
+        enqueue_s += time.perf_counter() - ta
+        marks[i + 1].record()
+    t_enqueued = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0                  # this rank's own clock (before the closing barrier)
     cpu_s, thr_s = time.process_time() - cpu0, time.thread_time() - thr0
     waits = dict(_lib.HOST_WAITS)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
@@ -432,7 +408,6 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         # per step on the compute stream (events): a one-off stall reads here, not as a slower average
         "step_ms_median": round(med, 3), "step_ms_min": round(min(step_ms), 3), "step_ms_max": round(step_ms[worst], 3),
         "step_ms_max_index": worst, "steps_over_2x_median": [i for i in range(steps) if step_ms[i] > 2 * med],
-        "gpu_clock": clocks.record(),
     }
     if use_dist:
         dist.barrier()
@@ -472,6 +447,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         lib.cpc_prof_enable(1)
         for _ in range(extra):
             step()
+        host_rec["gpu_box"] = GpuBoxSnapshot(device).take()     # (the device is busy with the extra steps; the clock has stopped)
         torch.cuda.synchronize()
         lib.cpc_prof_enable(0)
         tot, cnt = ctypes.c_double(0), ctypes.c_long(0)
@@ -628,11 +604,10 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
         n_batches = len(loader)
         _lib.HOST_WAITS.clear()
         cpu0, thr0 = time.process_time(), time.thread_time()
-        clocks = ClockSampler(device)
         import contextlib
         import io
         printed = io.StringIO()
-        with clocks, contextlib.redirect_stdout(printed):
+        with contextlib.redirect_stdout(printed):
             t0 = time.perf_counter()
             seen = [0]
 
@@ -679,7 +654,7 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
                  "blocked_ms_per_step": {k: round(1e3 * v / iters, 3) for k, v in sorted(waits.items())},
                  "busy_ms_per_step": round(1e3 * (t_host - sum(waits.values())) / iters, 3),
                  "thread_cpu_ms_per_step": round(1e3 * thr_s / iters, 3), "process_cpu_ms_per_step": round(1e3 * cpu_s / iters, 3),
-                 "host_done_before_device_ms": round(1e3 * (elapsed - t_host), 3), "gpu_clock": clocks.record(),
+                 "host_done_before_device_ms": round(1e3 * (elapsed - t_host), 3),
                  "corpus_s": round(t_b - t_a, 1), "load_s": round(t_c - t_b, 1)},
     }
 

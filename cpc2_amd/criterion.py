@@ -35,8 +35,13 @@ class NegativeSampler:
         self.follow_torch = True      # consume torch's global CPU generator (reference semantics)
         self._ring, self._dev_ring, self._ext_ring, self._events, self._slot = {}, {}, {}, {}, 0
         self._prefetched = None
+        self._prefetch_state = None   # generator state in front of the draw that is in flight (see sample())
+        self._torch_seen = None       # follow_torch: torch's generator state as this sampler last left it
         self._last = None             # (key, slot) of the previous device-side call: its buffers' release event is recorded by the next one
-        self.prefetch = False         # opt-in: draw step i+1's words during step i (private stream, fixed shapes)
+        # draw the next call's words during this step, on a worker thread with a stream of its own.  On by default since round 6: a
+        # draw ahead that turns out not to fit (another size, a host-side call, torch's generator used by someone else) is undone,
+        # so the index sequence is the reference's either way (tests: test_prefetch_*); False = everything at call time
+        self.prefetch = True
         self.alias_ring = False       # opt-in with prefetch: sample() returns one of RING persistent buffers instead of a copy of it
 
     def __del__(self):
@@ -72,11 +77,28 @@ class NegativeSampler:
         st[16:24].view(np.uint64)[0] = nxt.value
         st[24:24 + 624 * 8].view(np.uint64)[:] = mt.astype(np.uint64)
         torch.set_rng_state(torch.from_numpy(st))
+        self._torch_seen = st[8:24 + 624 * 8].copy()      # what torch's generator holds after this sampler's draw
+
+    def _torch_unchanged(self):
+        """Has nobody drawn from torch's global CPU generator since this sampler left it (a draw ahead is only valid then)?"""
+        if self._torch_seen is None:
+            return False
+        return np.array_equal(torch.get_rng_state().numpy()[8:24 + 624 * 8], self._torch_seen)
+
+    def _cancel_prefetch(self):
+        """Undo a draw ahead that will not be used: the private generator goes back to where it stood before it (with follow_torch
+        the next draw starts from torch's state anyway)."""
+        if self._prefetched is not None:
+            check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")
+            mt, left, nxt = self._prefetch_state
+            check(self._lib.cpc_mt_set_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), left, nxt), "mt_set_state")
+            self._prefetched = None
 
     def sample_host(self, batch, seq_len, window, n_neg, out=None, want_parts=False, time_major=False):
         """int32 extIdx on the host (criterion.py:247-266): [batch, n_neg, window] in the reference's
         order, or the same values as [batch, window, n_neg] with time_major (the kernels' layout)."""
         n = batch * n_neg * window
+        self._cancel_prefetch()
         if out is None:
             out = torch.empty(n, dtype=torch.int32)
         bidx = torch.empty(n, dtype=torch.int64) if want_parts else None
@@ -90,8 +112,8 @@ class NegativeSampler:
 
     def sample(self, batch, seq_len, window, n_neg, device, time_major=True):
         """Device int32 extIdx.  time_major (the fused kernels' layout): the host only draws the raw MT19937
-        words into a pinned buffer (on a worker thread, one step ahead, when the stream is private), the
-        device does the integer arithmetic (cpc_negidx_expand).  Otherwise: full host path, reference order."""
+        words into a pinned buffer (with `prefetch`: on a worker thread, one call ahead), the device does the
+        integer arithmetic (cpc_negidx_expand).  Otherwise: full host path, reference order."""
         n = batch * n_neg * window
         if not time_major:
             host = self.sample_host(batch, seq_len, window, n_neg)
@@ -102,8 +124,7 @@ class NegativeSampler:
             self._ring[key] = [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
             self._dev_ring[key] = [torch.empty(2 * n, dtype=torch.int32, device=device) for _ in range(self.RING)]
             self._ext_ring[key] = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(self.RING)]
-            self._events[key] = [None] * self.RING
-            self._prefetched = None
+            self._events[key] = [None] * self.RING     # (a draw in flight for another size is rewound below)
         ring, dev_ring, events = self._ring[key], self._dev_ring[key], self._events[key]
         # The buffers of the PREVIOUS call's slot are free again once everything enqueued since -- that call's expansion and the
         # criterion kernels that read its index tensor -- has run: marked here, one call later, on the stream those kernels are on.
@@ -115,7 +136,10 @@ class NegativeSampler:
         self._slot += 1
         host = ring[slot]
         shape = (batch, seq_len, window, n_neg)
-        if self._prefetched is not None and self._prefetched[:2] == (key, slot):
+        use_ahead = self._prefetched is not None and self._prefetched[:2] == (key, slot)
+        if use_ahead and self.follow_torch and not self._torch_unchanged():
+            use_ahead = False              # someone else drew from torch's generator meanwhile: ITS state decides what comes next
+        if use_ahead:
             # drawn, uploaded AND expanded (on the worker's own stream) while the GPU was busy with the previous step: the index
             # tensor is one of RING buffers, valid until RING - 1 further calls (prefetch is the caller's opt-in)
             # (waits for the worker's HOST part -- the draw, the enqueue of copy + expansion on its stream -- and orders the
@@ -131,7 +155,14 @@ class NegativeSampler:
                 ext = torch.empty(n, dtype=torch.int32, device=device)
                 check(self._lib.cpc_negidx_expand(ptr(dev_ring[slot]), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
                       "negidx_expand")
+            if self.follow_torch:              # torch's generator moves on by what the reference's two randint calls consume
+                self._push_torch_state(torch.get_rng_state().numpy())
         else:
+            # words drawn ahead for a call that is not this one (another batch size: the same-speaker sampler ends every speaker
+            # with a partial batch; or torch's generator was used in between): the generator goes back to where it stood before
+            # that draw, so that this call consumes exactly the words the reference's two torch.randint calls would
+            # (criterion.py:247-256)
+            self._cancel_prefetch()
             if events[slot] is not None:
                 with _lib.host_wait("sampler_buffer_event"):
                     events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
@@ -146,14 +177,20 @@ class NegativeSampler:
                   "negidx_expand")
         self._last = (key, slot)
         self._prefetched = None
-        if self.prefetch and not self.follow_torch:
-            # private stream: draw the NEXT step's words now, on the library's worker thread (the caller promises
-            # that the next call has the same shape -- the words are consumed from the stream either way)
+        if self.prefetch:
+            # draw the NEXT call's words now, on the library's worker thread, for a call of the same shape.  A call of another size, a
+            # host-side call, or -- when the words come from torch's global generator (follow_torch) -- anyone else's use of that
+            # generator in between undoes the draw (above), so the sequence is the reference's whatever happens
             nslot = self._slot % self.RING
             if events[nslot] is not None:
                 with _lib.host_wait("sampler_buffer_event"):
                     events[nslot].synchronize()
             dev_index = device.index if device.index is not None else torch.cuda.current_device()
+            # (where the generator stands before the draw ahead: a next call of another size rewinds to it)
+            mt = np.empty(624, dtype=np.uint32)
+            left, nxt = ctypes.c_int(0), ctypes.c_int(0)
+            check(self._lib.cpc_mt_get_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), ctypes.byref(left), ctypes.byref(nxt)), "mt_get_state")
+            self._prefetch_state = (mt, left.value, nxt.value)
             check(self._lib.cpc_mt_draw_expand_device_async(self._h, ptr(ring[nslot]), ptr(dev_ring[nslot]), ptr(self._ext_ring[key][nslot]),
                                                             dev_index, batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
                   "mt_draw_expand_device_async")

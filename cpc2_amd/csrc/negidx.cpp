@@ -125,6 +125,13 @@ int join_job(cpc_mt19937 *g)
     return st;
 }
 
+// wait for the job in flight without taking its status (the next cpc_negidx_wait still reports it)
+void wait_idle(cpc_mt19937 *g)
+{
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return !g->busy; });
+}
+
 void submit(cpc_mt19937 *g, std::function<int()> job)
 {
     std::unique_lock<std::mutex> lk(g->mu);
@@ -184,6 +191,7 @@ extern "C" int cpc_mt_seed(cpc_mt19937 *g, uint32_t seed)
 extern "C" int cpc_mt_get_state(const cpc_mt19937 *g, uint32_t *mt624, int *left, int *next)
 {
     if (g == nullptr || mt624 == nullptr) { cpc::set_error("cpc_mt_get_state: null argument"); return CPC_ERR_INVALID; }
+    wait_idle(const_cast<cpc_mt19937 *>(g));               // (a draw in flight owns the generator until it is done)
     std::memcpy(mt624, g->mt, sizeof(g->mt));
     if (left) *left = g->left;
     if (next) *next = g->next;
@@ -196,6 +204,7 @@ extern "C" int cpc_mt_set_state(cpc_mt19937 *g, const uint32_t *mt624, int left,
         cpc::set_error("cpc_mt_set_state: invalid state (left=%d next=%d)", left, next);
         return CPC_ERR_INVALID;
     }
+    wait_idle(g);
     std::memcpy(g->mt, mt624, sizeof(g->mt));
     g->left = left;
     g->next = next;

@@ -2833,3 +2833,46 @@ def test_forward_hooks_keep_the_reference_call():
     handle.remove()
     assert fired == [(8, 256, 128)], fired
     assert_close(hooked, base, 1e-6, "losses with a forward hook on the encoder")
+
+
+def test_prefetch_with_changing_batch_sizes_is_bit_exact():
+    """The same-speaker sampler ends every speaker with a partial batch: the call after a draw ahead then has another size.  The
+    generator is rewound to where it stood before that draw, so the sequence of index tensors equals the host sampler's (= the
+    reference's torch.randint calls, golden g1) whatever the sizes do."""
+    t_len, k, nn = 64, 12, 32
+    sizes = [8, 8, 5, 8, 8, 8, 3, 3, 8, 8, 8, 8, 8, 7, 8]
+    ref, dev = cpc2_amd.criterion.NegativeSampler(), cpc2_amd.criterion.NegativeSampler()
+    ref.seed(21)
+    dev.seed(21)
+    dev.prefetch = True
+    for i, b in enumerate(sizes):
+        want = ref.sample_host(b, t_len, t_len - k, nn, time_major=True)
+        got = dev.sample(b, t_len, t_len - k, nn, torch.device(DEV))
+        assert torch.equal(got.cpu(), want), (i, b)
+
+
+def test_prefetch_under_torchs_global_generator_is_bit_exact():
+    """The module's default takes the negatives from torch's global CPU generator (the reference's torch.randint calls).  With
+    `prefetch` the next call's words are drawn ahead from the state the sampler left in torch -- valid only while nobody else
+    uses that generator: a torch.rand in between, a host-side call or another batch size undo the draw.  Index tensors AND the
+    generator's state after every call equal the plain path's."""
+    t_len, k, nn = 64, 12, 32
+    plan = [(8, None), (8, None), (8, "rand"), (5, None), (8, None), (8, "host"), (8, None), (8, None)]
+    results = []
+    for prefetch in (False, True):
+        smp = cpc2_amd.criterion.NegativeSampler()
+        smp.prefetch = prefetch
+        torch.manual_seed(77)
+        seen = []
+        for b, between in plan:
+            got = smp.sample(b, t_len, t_len - k, nn, torch.device(DEV)).cpu()
+            seen.append((got, torch.get_rng_state().clone()))
+            if between == "rand":
+                torch.rand(3)                                   # someone else consumes torch's stream
+            elif between == "host":
+                seen.append((smp.sample_host(b, t_len, t_len - k, nn, time_major=True).clone(), torch.get_rng_state().clone()))
+        results.append(seen)
+    assert len(results[0]) == len(results[1])
+    for i, ((a, sa), (c, sc)) in enumerate(zip(*results)):
+        assert torch.equal(a, c), f"call {i}: indices differ with prefetch"
+        assert torch.equal(sa, sc), f"call {i}: torch's generator state differs with prefetch"
