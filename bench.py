@@ -300,11 +300,12 @@ class GpuBoxSnapshot:
         if self.own is None:
             return None
         rec = {"card": self.own.split("/")[4], "taken": "during extra steps after the timed region", "other_gpus_of_the_host": len(self.others)}
-        for ln in self._read(os.path.join(self.own, "pp_dpm_sclk")).splitlines():
-            if ln.rstrip().endswith("*"):
-                digits = "".join(ch for ch in ln.split(":")[-1] if ch.isdigit())
-                if digits:
-                    rec["sclk_level_mhz"] = int(digits)
+        for name in ("sclk", "mclk", "fclk", "socclk"):
+            for ln in self._read(os.path.join(self.own, "pp_dpm_" + name)).splitlines():
+                if ln.rstrip().endswith("*"):
+                    digits = "".join(ch for ch in ln.split(":")[-1] if ch.isdigit())
+                    if digits:
+                        rec[name + "_level_mhz"] = int(digits)
         if self.power is not None:
             txt = self._read(self.power).strip()
             if txt.isdigit():
@@ -587,33 +588,41 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
         data = AudioBatchData(tmp, WINDOW, seqs, None, len(speakers), device=device)
         t_c = time.perf_counter()
         log(f"{cfg_name}: {total / 16000.0 / 3600.0:.2f} h of synthetic audio in {len(seqs)} files written in {t_b - t_a:.1f} s, loaded to the device in {t_c - t_b:.1f} s")
-        loader = data.getDataLoader(args.batch, "samespeaker", True)
-        # warm-up on the feeder's own windows (arena growth, first-use costs)
-        it = iter(loader)
-        for _ in range(5):
-            seq, label = next(it)
-            tot, _l, _a = cpcStep(seq[:, 0], seq[:, 1], label, model, crit, dp=dp)
-            backward(tot)
-            dp.reduce_and_step()
-            opt.zero_grad()
-        del it
-        torch.cuda.synchronize()
+        # warm-up = whole epochs, timed apart: the same-speaker sampler ends every speaker with a partial batch whose size changes with
+        # the epoch's random offset, and every new batch size has first-use costs (pinned staging rings, gradient buffers, kernel
+        # variants the runtime loads at their first launch: ~12 ms each under a kernel trace) that a one-second epoch would otherwise
+        # be charged with and a training run is not.  Measured (tools/feeder_epochs.py): 5.52 / 5.13 / 4.63 / 4.69 / 4.68 ms per step
+        # for epochs 0 .. 4.
+        import contextlib
+        import io
+        warm_ms = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for _ in range(3):
+                t_w = time.perf_counter()
+                first_logs = trainStep(data.getDataLoader(args.batch, "samespeaker", True), model, crit, opt, None, 1000, dp=dp)
+                torch.cuda.synchronize()
+                warm_ms.append(round(1e3 * (time.perf_counter() - t_w) / max(1, int(first_logs["iter"])), 3))
         if use_dist:
             dist.barrier()
         loader = data.getDataLoader(args.batch, "samespeaker", True)
         n_batches = len(loader)
         _lib.HOST_WAITS.clear()
         cpu0, thr0 = time.process_time(), time.thread_time()
-        import contextlib
-        import io
         printed = io.StringIO()
         with contextlib.redirect_stdout(printed):
             t0 = time.perf_counter()
             seen = [0]
+            sizes, marks, box = [], [], []
 
             def counted(it):                          # (the same-speaker sampler ends every speaker with a partial batch)
                 for item in it:
-                    seen[0] += int(item[0].size(0))
+                    if len(marks) == n_batches - 2:     # (near the end of the epoch, two steps still queued on the device)
+                        box.append(GpuBoxSnapshot(device).take())
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()                       # on the training stream, in front of this iteration's work
+                    marks.append(ev)
+                    sizes.append(int(item[0].size(0)))
+                    seen[0] += sizes[-1]
                     yield item
             logs = trainStep(counted(loader), model, crit, opt, None, 1000, dp=dp)          # logging_step: the reference's default
             t_host = time.perf_counter() - t0
@@ -621,6 +630,15 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
             elapsed = time.perf_counter() - t0
         cpu_s, thr_s = time.process_time() - cpu0, time.thread_time() - thr0
         waits = dict(_lib.HOST_WAITS)
+        # per iteration on the device (event to event): full batches, batches of another size than their predecessor, outliers
+        dev_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+        full = sorted(d for d, b in zip(dev_ms, sizes) if b == args.batch)
+        changed = [d for i, d in enumerate(dev_ms) if i > 0 and sizes[i] != sizes[i - 1]]
+        med_full = full[len(full) // 2] if full else None
+        step_rec = {"full_batch_median_ms": None if med_full is None else round(med_full, 3),
+                    "size_changes": len(changed), "after_size_change_mean_ms": round(sum(changed) / len(changed), 3) if changed else None,
+                    "over_1p5x_full_median": sum(1 for d in dev_ms if med_full and d > 1.5 * med_full),
+                    "ms_in_those": round(sum(d for d in dev_ms if med_full and d > 1.5 * med_full), 1)}
         if use_dist:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -639,11 +657,11 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
     return {
         "metric": "audio-seconds/sec CPC training (1.28 s @16 kHz, 128 neg)",
         "value": round(windows * SECONDS_PER_WINDOW / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world,
-        "steps": iters, "warmup": 5, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "steps": iters, "warmup": 3 * int(first_logs["iter"]), "ms_per_step": round(ms, 3), "warmup_epochs_ms_per_step": warm_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic audio FILES (16-bit WAV, written to a temporary directory) through the window feeder",
         "config": {"workload": f"CPC-{cfg_name}: the reference's loop around the headline step -- findAllSeqs -> AudioBatchData (flat audio in "
                                f"HBM) -> getDataLoader({args.batch}, 'samespeaker', randomOffset=True) -> cpc2_amd.train.trainStep (logging_step "
-                               f"1000: train.py:596), one epoch of {iters} steps of {args.batch} windows; dataset.py:300-325,366-408, train.py:95-134",
+                               f"1000: train.py:596), the FOURTH epoch of {iters} steps of up to {args.batch} windows (the first three, with every batch size's first-use costs, are `warmup_epochs_ms_per_step`); dataset.py:300-325,366-408, train.py:95-134",
                    "windows_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                    "final_losses": [round(float(v), 4) for v in logs["locLoss_train"]],
                    "windows": windows, "mean_batch": round(windows / max(1, iters * world), 2), "epoch_batches_announced": n_batches},
@@ -654,7 +672,7 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
                  "blocked_ms_per_step": {k: round(1e3 * v / iters, 3) for k, v in sorted(waits.items())},
                  "busy_ms_per_step": round(1e3 * (t_host - sum(waits.values())) / iters, 3),
                  "thread_cpu_ms_per_step": round(1e3 * thr_s / iters, 3), "process_cpu_ms_per_step": round(1e3 * cpu_s / iters, 3),
-                 "host_done_before_device_ms": round(1e3 * (elapsed - t_host), 3),
+                 "host_done_before_device_ms": round(1e3 * (elapsed - t_host), 3), "device_steps": step_rec, "gpu_box": box[0] if box else None,
                  "corpus_s": round(t_b - t_a, 1), "load_s": round(t_c - t_b, 1)},
     }
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "cpc_mt_draw_host_async": (c_int, [c_ptr, c_ptr, c_size_t]),
     "cpc_mt_draw_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_size_t, c_int, c_ptr]),
     "cpc_mt_draw_expand_device_async": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
+    "cpc_mt_redraw_expand_device_async": (c_int, [c_ptr, c_ptr, c_int, c_int, c_size_t, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_negidx_wait_on": (c_int, [c_ptr, c_ptr]),
     "cpc_negidx_stream": (c_int, [c_ptr, c_ptr]),
     "cpc_stream_create_apart": (c_int, [c_ptr, c_int, c_ptr]),

@@ -25,7 +25,7 @@ from ._lib import check, f32c, grad_buffers, ptr, require_gpu, scratch, stream_p
 class NegativeSampler:
     """Host MT19937 sampler (cpc_negidx_sample_host) + pinned staging ring for the H2D copy."""
 
-    RING = 4
+    RING = int(os.environ.get("CPC_SAMPLER_RING", "4"))
 
     def __init__(self):
         self._lib = _lib.load()
@@ -37,6 +37,9 @@ class NegativeSampler:
         self._prefetched = None
         self._prefetch_state = None   # generator state in front of the draw that is in flight (see sample())
         self._torch_seen = None       # follow_torch: torch's generator state as this sampler last left it
+        self._prefetch_skip = 0       # words the draw in flight dropped first (consumed by a smaller call from the draw before it)
+        self._ahead_shape = None      # (n, device, shape) the draws ahead are made for: the largest call seen
+        self._ahead_misses = 0        # calls in a row that were not the one drawn for
         self._last = None             # (key, slot) of the previous device-side call: its buffers' release event is recorded by the next one
         # draw the next call's words during this step, on a worker thread with a stream of its own.  On by default since round 6: a
         # draw ahead that turns out not to fit (another size, a host-side call, torch's generator used by someone else) is undone,
@@ -92,6 +95,9 @@ class NegativeSampler:
             check(self._lib.cpc_negidx_wait(self._h), "negidx_wait")
             mt, left, nxt = self._prefetch_state
             check(self._lib.cpc_mt_set_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), left, nxt), "mt_set_state")
+            if self._prefetch_skip:            # (the draw had first put the generator behind words an earlier call consumed)
+                skipped = torch.empty(self._prefetch_skip, dtype=torch.int32)
+                check(self._lib.cpc_mt_draw_host(self._h, ptr(skipped), self._prefetch_skip), "mt_draw_host")
             self._prefetched = None
 
     def sample_host(self, batch, seq_len, window, n_neg, out=None, want_parts=False, time_major=False):
@@ -110,59 +116,90 @@ class NegativeSampler:
             self._push_torch_state(st)
         return (out, bidx, sidx) if want_parts else out
 
+    def _rings(self, key, n, device):
+        if key not in self._ring:
+            self._ring[key] = [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+            self._dev_ring[key] = [torch.empty(2 * n, dtype=torch.int32, device=device) for _ in range(self.RING)]
+            self._ext_ring[key] = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(self.RING)]
+            self._events[key] = [None] * self.RING
+        return self._ring[key], self._dev_ring[key], self._events[key]
+
     def sample(self, batch, seq_len, window, n_neg, device, time_major=True):
         """Device int32 extIdx.  time_major (the fused kernels' layout): the host only draws the raw MT19937
         words into a pinned buffer (with `prefetch`: on a worker thread, one call ahead), the device does the
-        integer arithmetic (cpc_negidx_expand).  Otherwise: full host path, reference order."""
+        integer arithmetic (cpc_negidx_expand).  Otherwise: full host path, reference order.
+
+        A draw ahead is made for the LARGEST call seen so far (the full batch).  The stream of words is one sequence whatever it is
+        cut into -- a call of n negatives consumes its first 2 n -- so what follows a draw ahead of 2 n' words is one of:
+          * the call it was made for: indices already expanded by the worker, nothing on the caller's stream but a wait;
+          * a SMALLER call (the same-speaker sampler ends every speaker with a partial batch): its 2 n words are a prefix of the
+            words already on the device; one expansion kernel, and the generator is put behind those 2 n words by the worker in
+            front of its next draw (private stream only);
+          * anything else (a larger call, a host-side call, torch's generator used in between with follow_torch): the draw is undone
+            and the call draws for itself.
+        Either way the index sequence is the reference's (tests: test_prefetch_*)."""
         n = batch * n_neg * window
         if not time_major:
             host = self.sample_host(batch, seq_len, window, n_neg)
             return host.to(device)
         device = torch.device(device)
         key = (n, str(device))
-        if key not in self._ring:
-            self._ring[key] = [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
-            self._dev_ring[key] = [torch.empty(2 * n, dtype=torch.int32, device=device) for _ in range(self.RING)]
-            self._ext_ring[key] = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(self.RING)]
-            self._events[key] = [None] * self.RING     # (a draw in flight for another size is rewound below)
-        ring, dev_ring, events = self._ring[key], self._dev_ring[key], self._events[key]
+        ring, dev_ring, events = self._rings(key, n, device)
         # The buffers of the PREVIOUS call's slot are free again once everything enqueued since -- that call's expansion and the
         # criterion kernels that read its index tensor -- has run: marked here, one call later, on the stream those kernels are on.
         if self._last is not None and self._last[0] in self._events:
             ev = torch.cuda.Event(blocking=True)       # (a host that has to wait for it sleeps instead of spinning on a core)
             ev.record(torch.cuda.current_stream(device))
             self._events[self._last[0]][self._last[1]] = ev
-        slot = self._slot % self.RING
-        self._slot += 1
-        host = ring[slot]
         shape = (batch, seq_len, window, n_neg)
-        use_ahead = self._prefetched is not None and self._prefetched[:2] == (key, slot)
-        if use_ahead and self.follow_torch and not self._torch_unchanged():
-            use_ahead = False              # someone else drew from torch's generator meanwhile: ITS state decides what comes next
-        if use_ahead:
-            # drawn, uploaded AND expanded (on the worker's own stream) while the GPU was busy with the previous step: the index
-            # tensor is one of RING buffers, valid until RING - 1 further calls (prefetch is the caller's opt-in)
+        ahead = self._prefetched                        # (key, slot, shape) of the draw in flight, or None
+        if ahead is not None and self.follow_torch and not self._torch_unchanged():
+            self._cancel_prefetch()                     # someone else drew from torch's generator meanwhile: ITS state decides
+            ahead = None
+        fixup = None                                    # (state, words consumed): where the generator has to be put before the next draw
+        used = None                                     # (key, slot) whose buffers this call's kernels read
+        if ahead is not None and ahead[0] == key:
+            # the call the draw was made for: drawn, uploaded AND expanded (on the worker's own stream) while the GPU was busy
             # (waits for the worker's HOST part -- the draw, the enqueue of copy + expansion on its stream -- and orders the
             #  training stream behind the event recorded there: the host is not held up by the device)
+            akey, aslot, ashape = ahead
             with _lib.host_wait("sampler_worker"):
                 check(self._lib.cpc_negidx_wait_on(self._h, _lib.stream_ptr(device)), "negidx_wait_on")
-            if self._prefetched[2] == shape:
+            if ashape == shape:
                 # (a COPY of the ring buffer, 3.8 MB at the benchmark shape: the worker rewrites the buffer RING - 1 calls later, and
                 #  a caller may keep the indices -- saved for a backward that runs late, logged, compared -- for longer than that;
                 #  `alias_ring = True` hands out the buffer itself to a caller that consumes it before the next RING - 1 samples)
-                ext = self._ext_ring[key][slot] if self.alias_ring else self._ext_ring[key][slot].clone()
+                ext = self._ext_ring[akey][aslot] if self.alias_ring else self._ext_ring[akey][aslot].clone()
             else:                              # (the same number of words for another shape: the words are right, the expansion is not)
                 ext = torch.empty(n, dtype=torch.int32, device=device)
-                check(self._lib.cpc_negidx_expand(ptr(dev_ring[slot]), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
+                check(self._lib.cpc_negidx_expand(ptr(self._dev_ring[akey][aslot]), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
                       "negidx_expand")
+            used = (akey, aslot)
+            self._ahead_misses = 0
             if self.follow_torch:              # torch's generator moves on by what the reference's two randint calls consume
                 self._push_torch_state(torch.get_rng_state().numpy())
+        elif (ahead is not None and not self.follow_torch and n < ahead[0][0] and ahead[0][1] == key[1]
+              and self._prefetch_skip + 2 * n <= 2 * ahead[0][0] and self._ahead_misses < 8):
+            # a smaller call: its words are the first 2 n of those already on the device
+            akey, aslot, _ashape = ahead
+            with _lib.host_wait("sampler_worker"):
+                check(self._lib.cpc_negidx_wait_on(self._h, _lib.stream_ptr(device)), "negidx_wait_on")
+            ext = torch.empty(n, dtype=torch.int32, device=device)
+            check(self._lib.cpc_negidx_expand(ptr(self._dev_ring[akey][aslot]), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
+                  "negidx_expand")
+            used = (akey, aslot)
+            # (behind the words consumed since the state the draw in flight started from: a run of smaller calls adds up -- and is
+            #  bounded above: past one draw's worth, or after eight calls in a row that were not the one drawn for, the draws ahead
+            #  follow the calls' new size instead)
+            fixup = (self._prefetch_state, self._prefetch_skip + 2 * n)
+            self._ahead_misses += 1
         else:
-            # words drawn ahead for a call that is not this one (another batch size: the same-speaker sampler ends every speaker
-            # with a partial batch; or torch's generator was used in between): the generator goes back to where it stood before
-            # that draw, so that this call consumes exactly the words the reference's two torch.randint calls would
-            # (criterion.py:247-256)
+            # words drawn ahead for a call that cannot use them: the generator goes back to where it stood before that draw, so
+            # that this call consumes exactly the words the reference's two torch.randint calls would (criterion.py:247-256)
             self._cancel_prefetch()
+            slot = self._slot % self.RING
+            self._slot += 1
+            host = ring[slot]
             if events[slot] is not None:
                 with _lib.host_wait("sampler_buffer_event"):
                     events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
@@ -175,26 +212,50 @@ class NegativeSampler:
             ext = torch.empty(n, dtype=torch.int32, device=device)
             check(self._lib.cpc_negidx_expand(ptr(raw), ptr(ext), batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
                   "negidx_expand")
-        self._last = (key, slot)
+            used = (key, slot)
+        self._last = used
         self._prefetched = None
         if self.prefetch:
-            # draw the NEXT call's words now, on the library's worker thread, for a call of the same shape.  A call of another size, a
-            # host-side call, or -- when the words come from torch's global generator (follow_torch) -- anyone else's use of that
-            # generator in between undoes the draw (above), so the sequence is the reference's whatever happens
-            nslot = self._slot % self.RING
-            if events[nslot] is not None:
+            # draw the NEXT call's words now, on the library's worker thread, for the largest call seen so far
+            if self._ahead_shape is None or self._ahead_shape[1] != str(device) or n > self._ahead_shape[0] or self._ahead_misses >= 8:
+                self._ahead_shape = (n, str(device), shape)
+                self._ahead_misses = 0
+            an, _adev, ashape = self._ahead_shape
+            akey = (an, str(device))
+            aring, adev_ring, aevents = self._rings(akey, an, device)
+            aslot = self._slot % self.RING
+            self._slot += 1
+            if aevents[aslot] is not None:
                 with _lib.host_wait("sampler_buffer_event"):
-                    events[nslot].synchronize()
+                    aevents[aslot].synchronize()
             dev_index = device.index if device.index is not None else torch.cuda.current_device()
-            # (where the generator stands before the draw ahead: a next call of another size rewinds to it)
-            mt = np.empty(624, dtype=np.uint32)
-            left, nxt = ctypes.c_int(0), ctypes.c_int(0)
-            check(self._lib.cpc_mt_get_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), ctypes.byref(left), ctypes.byref(nxt)), "mt_get_state")
-            self._prefetch_state = (mt, left.value, nxt.value)
-            check(self._lib.cpc_mt_draw_expand_device_async(self._h, ptr(ring[nslot]), ptr(dev_ring[nslot]), ptr(self._ext_ring[key][nslot]),
-                                                            dev_index, batch, seq_len, window, n_neg, _lib.stream_ptr(device)),
-                  "mt_draw_expand_device_async")
-            self._prefetched = (key, nslot, shape)
+            ab, at, aw, ann = ashape
+            if fixup is not None:
+                (mt, left, nxt), consumed = fixup
+                # (the state this draw will start from, for a rewind by the NEXT call, is not known on the host: it is the state
+                #  behind the consumed words, which the worker produces -- a next call that cannot use the draw rewinds to the old
+                #  state and draws those words again)
+                self._prefetch_state = (mt, left, nxt)
+                self._prefetch_skip = consumed
+                check(self._lib.cpc_mt_redraw_expand_device_async(self._h, mt.ctypes.data_as(ctypes.c_void_p), left, nxt, consumed, ptr(aring[aslot]),
+                                                                  ptr(adev_ring[aslot]), ptr(self._ext_ring[akey][aslot]), dev_index, ab, at, aw, ann,
+                                                                  _lib.stream_ptr(device)), "mt_redraw_expand_device_async")
+            else:
+                # (where the generator stands before the draw ahead: a next call that cannot use it rewinds to it)
+                mt = np.empty(624, dtype=np.uint32)
+                left, nxt = ctypes.c_int(0), ctypes.c_int(0)
+                check(self._lib.cpc_mt_get_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), ctypes.byref(left), ctypes.byref(nxt)), "mt_get_state")
+                self._prefetch_state = (mt, left.value, nxt.value)
+                self._prefetch_skip = 0
+                check(self._lib.cpc_mt_draw_expand_device_async(self._h, ptr(aring[aslot]), ptr(adev_ring[aslot]), ptr(self._ext_ring[akey][aslot]),
+                                                                dev_index, ab, at, aw, ann, _lib.stream_ptr(device)), "mt_draw_expand_device_async")
+            self._prefetched = (akey, aslot, ashape)
+        elif fixup is not None:
+            # (prefetch was switched off in between: put the generator behind the consumed words here)
+            (mt, left, nxt), consumed = fixup
+            check(self._lib.cpc_mt_set_state(self._h, mt.ctypes.data_as(ctypes.c_void_p), left, nxt), "mt_set_state")
+            scratch_words = torch.empty(consumed, dtype=torch.int32)
+            check(self._lib.cpc_mt_draw_host(self._h, ptr(scratch_words), consumed), "mt_draw_host")
         return ext
 
 

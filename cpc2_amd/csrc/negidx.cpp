@@ -6,6 +6,7 @@
 // The generator state is kept in torch's bookkeeping form (left / next) so that it can be seeded from,
 // and written back to, torch.get_rng_state() -- the criterion then consumes the SAME stream the
 // reference would.  Whole 624-word blocks are twisted and tempered in bulk.
+#include <algorithm>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -378,6 +379,39 @@ extern "C" int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_hos
     cpc_negidx_wait(g);
     submit(g, [=] { return device_job(g, raw_host, raw_dev, ext_dev, n, device, batch, seq_len, window, n_neg, caller_stream,
                                       "cpc_mt_draw_expand_device_async"); });
+    return CPC_OK;
+}
+
+// The same draw ahead, preceded ON THE WORKER by a repositioning of the generator: state (mt624, left, next) is restored and
+// `skip_words` outputs are generated and dropped.  For a draw ahead whose words were used only in part (the call that followed was
+// smaller: its 2 n words are a PREFIX of the 2 n' drawn, the stream being one sequence whatever it is cut into): the generator
+// has to stand behind the words that WERE consumed before the next draw, and the caller does not wait for that.
+extern "C" int cpc_mt_redraw_expand_device_async(cpc_mt19937 *g, const uint32_t *restore_mt624, int restore_left, int restore_next,
+                                                 size_t skip_words, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
+                                                 int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream)
+{
+    if (g == nullptr || restore_mt624 == nullptr || raw_host == nullptr || raw_dev == nullptr || ext_dev == nullptr || batch < 1 || seq_len < 2 ||
+        window < 1 || n_neg < 1 || restore_left < 1 || restore_left > N || restore_next < 0 || restore_next > N ||
+        (restore_left > 1 && restore_next + restore_left - 1 != N)) {
+        cpc::set_error("cpc_mt_redraw_expand_device_async: bad argument");
+        return CPC_ERR_INVALID;
+    }
+    if (cpc_negidx_expand == nullptr) { cpc::set_error("cpc_mt_redraw_expand_device_async: built without the device kernels"); return CPC_ERR_HIP; }
+    const size_t n = 2 * (size_t)batch * n_neg * window;
+    std::vector<uint32_t> st(restore_mt624, restore_mt624 + N);
+    cpc_negidx_wait(g);
+    submit(g, [=] {
+        std::memcpy(g->mt, st.data(), sizeof(g->mt));
+        g->left = restore_left;
+        g->next = restore_next;
+        g->tmp.resize(4096);
+        for (size_t done = 0; done < skip_words;) {
+            const size_t take = std::min<size_t>(4096, skip_words - done);
+            draw(g, g->tmp.data(), take);
+            done += take;
+        }
+        return device_job(g, raw_host, raw_dev, ext_dev, n, device, batch, seq_len, window, n_neg, caller_stream, "cpc_mt_redraw_expand_device_async");
+    });
     return CPC_OK;
 }
 

@@ -346,6 +346,13 @@ int cpc_mt_draw_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_d
  * has it) or, without blocking the host on the device, by everything enqueued on `stream` after cpc_negidx_wait_on(g, stream). */
 int cpc_mt_draw_expand_device_async(cpc_mt19937 *g, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
                                     int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream);
+/* ... preceded on the worker by a repositioning of the generator: the state (mt624, left, next) is restored and skip_words outputs
+ * are generated and dropped.  For a draw ahead of which a SMALLER call used only a prefix (its 2 n words are the first 2 n of the
+ * stream whatever it is cut into): the generator has to stand behind the consumed words before the next draw, and the caller does
+ * not wait for that. */
+int cpc_mt_redraw_expand_device_async(cpc_mt19937 *g, const uint32_t *restore_mt624, int restore_left, int restore_next,
+                                      size_t skip_words, uint32_t *raw_host, uint32_t *raw_dev, int32_t *ext_dev, int device,
+                                      int batch, int seq_len, int window, int n_neg, cpc_stream_t caller_stream);
 int cpc_negidx_wait_on(cpc_mt19937 *g, cpc_stream_t stream);
 int cpc_negidx_stream(cpc_mt19937 *g, cpc_stream_t *out);      /* the worker's stream (NULL before its first device job) */
 int cpc_negidx_expand(const uint32_t *raw, int32_t *ext_idx, int batch, int seq_len, int window, int n_neg,

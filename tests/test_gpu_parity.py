@@ -2840,12 +2840,21 @@ def test_prefetch_with_changing_batch_sizes_is_bit_exact():
     generator is rewound to where it stood before that draw, so the sequence of index tensors equals the host sampler's (= the
     reference's torch.randint calls, golden g1) whatever the sizes do."""
     t_len, k, nn = 64, 12, 32
-    sizes = [8, 8, 5, 8, 8, 8, 3, 3, 8, 8, 8, 8, 8, 7, 8]
+    # smaller calls after a draw ahead for the full batch (a prefix of its words), runs of them, a LARGER call (the draw is undone),
+    # a host-side call in between, prefetch switched off behind a smaller call
+    sizes = [8, 8, 5, 8, 8, 8, 3, 3, 8, 8, 12, 12, 5, 12, 8, 7, 8, "host", 8, 5, "off", 8, 8, "on"] + [2] * 12 + [12, 2, 2, 12]
     ref, dev = cpc2_amd.criterion.NegativeSampler(), cpc2_amd.criterion.NegativeSampler()
+    ref.prefetch = False
     ref.seed(21)
     dev.seed(21)
     dev.prefetch = True
     for i, b in enumerate(sizes):
+        if b == "host":
+            assert torch.equal(dev.sample_host(6, t_len, t_len - k, nn, time_major=True), ref.sample_host(6, t_len, t_len - k, nn, time_major=True))
+            continue
+        if b in ("off", "on"):
+            dev.prefetch = b == "on"
+            continue
         want = ref.sample_host(b, t_len, t_len - k, nn, time_major=True)
         got = dev.sample(b, t_len, t_len - k, nn, torch.device(DEV))
         assert torch.equal(got.cpu(), want), (i, b)
