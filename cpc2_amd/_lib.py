@@ -89,6 +89,7 @@ SIGNATURES = {
     "cpc_stream_create_apart": (c_int, [c_ptr, c_int, c_ptr]),
     "cpc_streams_overlap": (c_int, [c_ptr, c_ptr]),
     "cpc_stream_apart_failures": (c_long, []),
+    "cpc_stream_spin": (c_int, [c_ptr, c_long]),
     "cpc_side_stream": (c_int, [c_ptr, c_ptr]),
     "cpc_negidx_expand": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "cpc_infonce_saved_bytes": (c_size_t, [c_int] * 6),

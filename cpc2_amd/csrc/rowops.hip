@@ -413,7 +413,7 @@ __global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n
 __global__ void queue_probe_spin_kernel(long long ticks)
 {
     const long long t0 = wall_clock64();                 // 100 MHz, constant
-    for (int i = 0; i < (1 << 20) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+    for (int i = 0; i < (1 << 24) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
 }
 __global__ void queue_probe_tag_kernel() {}
 
@@ -494,6 +494,16 @@ extern "C" int cpc_streams_overlap(cpc_stream_t a, cpc_stream_t b)
     int overlap = 0;
     const int rc = cpc::streams_overlap_locked(static_cast<hipStream_t>(a), static_cast<hipStream_t>(b), &overlap);
     return rc != CPC_OK ? rc : overlap;
+}
+
+// a kernel that keeps one wave of `stream` busy for `ticks` of the 100 MHz clock (diagnostics: bench.py tests whether RCCL's stream,
+// which it cannot name, runs beside the training stream)
+extern "C" int cpc_stream_spin(cpc_stream_t stream, long ticks)
+{
+    CPC_REQUIRE(ticks > 0 && ticks <= 100000000L, "cpc_stream_spin: ticks out of range");
+    hipLaunchKernelGGL(cpc::queue_probe_spin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)ticks);
+    CPC_CHECK_LAUNCH("queue_probe_spin_kernel");
+    return CPC_OK;
 }
 
 extern "C" long cpc_stream_apart_failures(void) { return cpc::g_apart_fail.load(std::memory_order_relaxed); }

@@ -72,6 +72,7 @@ int cpc_async_error_check(cpc_stream_t stream);
 int cpc_stream_create_apart(const cpc_stream_t *avoid, int n_avoid, cpc_stream_t *out);
 int cpc_streams_overlap(cpc_stream_t a, cpc_stream_t b);
 long cpc_stream_apart_failures(void);
+int cpc_stream_spin(cpc_stream_t stream, long ticks);      /* one wave of `stream` busy for `ticks` of the 100 MHz clock (diagnostics) */
 /* the library's side stream on the current device (created on first use, apart from `caller`), for diagnostics */
 int cpc_side_stream(cpc_stream_t caller, cpc_stream_t *out);
 /* Cooperative recurrent launches (the GRU / LSTM kernels at hidden 256 / 512 that need every workgroup resident at once)
