@@ -22,6 +22,15 @@ from ._lib import check, f32c, grad_buffers, ptr, require_gpu, scratch, stream_p
 
 
 # --------------------------------------------------------------------------- index sampler
+def _sleep_until(event):
+    """Wait for a device event WITHOUT spinning on a core: this is where the training thread stands still while it is its two steps
+    ahead of the device (2.4-2.8 ms of every 4.8 ms step), and hipEventSynchronize -- blocking-sync flag or not -- burns that time
+    as CPU time (bench.py: host.thread_cpu_ms_per_step 4.1 against 1.4 of work); eight ranks share one host."""
+    import time
+    while not event.query():
+        time.sleep(0.0001)
+
+
 class NegativeSampler:
     """Host MT19937 sampler (cpc_negidx_sample_host) + pinned staging ring for the H2D copy."""
 
@@ -148,7 +157,7 @@ class NegativeSampler:
         # The buffers of the PREVIOUS call's slot are free again once everything enqueued since -- that call's expansion and the
         # criterion kernels that read its index tensor -- has run: marked here, one call later, on the stream those kernels are on.
         if self._last is not None and self._last[0] in self._events:
-            ev = torch.cuda.Event(blocking=True)       # (a host that has to wait for it sleeps instead of spinning on a core)
+            ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
             self._events[self._last[0]][self._last[1]] = ev
         shape = (batch, seq_len, window, n_neg)
@@ -202,7 +211,7 @@ class NegativeSampler:
             host = ring[slot]
             if events[slot] is not None:
                 with _lib.host_wait("sampler_buffer_event"):
-                    events[slot].synchronize()     # the kernel that last read this slot's buffers has finished
+                    _sleep_until(events[slot])     # the kernel that last read this slot's buffers has finished
             st = self._pull_torch_state() if self.follow_torch else None
             check(self._lib.cpc_mt_draw_host(self._h, ptr(host), 2 * n), "mt_draw_host")
             if st is not None:
@@ -227,7 +236,7 @@ class NegativeSampler:
             self._slot += 1
             if aevents[aslot] is not None:
                 with _lib.host_wait("sampler_buffer_event"):
-                    aevents[aslot].synchronize()
+                    _sleep_until(aevents[aslot])
             dev_index = device.index if device.index is not None else torch.cuda.current_device()
             ab, at, aw, ann = ashape
             if fixup is not None:
