@@ -24,7 +24,9 @@ def _bench(env_extra):
     keep = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(keep, exist_ok=True)
-        tag = "_".join(f"{k[4:].lower()}{v}" for k, v in sorted(env_extra.items())) or "plain"
+        tag = "_".join(f"{k[4:].lower()}{v}" for k, v in sorted(env_extra.items()) if k != "CPC_BENCH_NOTE") or "plain"
+        if "CPC_BENCH_NOTE" in env_extra:
+            tag += "_warming"
         with open(os.path.join(keep, f"test_bench_gpu_{tag}.jsonl"), "a") as fh:
             fh.write(line + "\n")
     except OSError:
@@ -33,6 +35,10 @@ def _bench(env_extra):
 
 
 def test_one_rank_process_group_step_costs_about_a_plain_step():
+    # This module is the first thing that runs on a fresh box: the first bench process pages everything in (torch, the 42 MB of
+    # code objects, kernels loaded at their first launch) and has been seen at 23 ms per step with single steps of 90 ms, the
+    # host descheduled for 17 ms per step (thread CPU 1.0 ms).  One discarded run first; its line is kept with the others.
+    _bench({"CPC_BENCH_NOTE": "cache warming run of tests/test_bench_gpu.py (discarded)"})
     plain = _bench({})
     dist = _bench({"CPC_BENCH_FORCE_DIST": "1"})
     assert dist["comm"]["process_group"] == "nccl" and plain["comm"]["process_group"] is None
@@ -61,8 +67,9 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
     assert comm["rank_ms_per_step_min"] <= comm["rank_ms_per_step_max"] <= dist["ms_per_step"] * 1.01
     assert plain["comm"]["exposed_ms_per_step"] is None
     # what a step costs the host: far below the step itself, so that eight ranks on one host do not starve their GPUs
+    # (CPU time of the training thread: wall time inside step() also counts whatever descheduled the thread on a shared host)
     for rec in (plain, dist):
-        assert rec["host"]["busy_ms_per_step"] < 0.6 * rec["ms_per_step"], rec["host"]
+        assert rec["host"]["thread_cpu_ms_per_step"] < 0.6 * rec["host"]["step_ms_median"], rec["host"]
 
 
 def test_a_rank_on_two_cores_keeps_its_gpu_fed():
@@ -72,4 +79,4 @@ def test_a_rank_on_two_cores_keeps_its_gpu_fed():
     two = _bench({"CPC_BENCH_FORCE_DIST": "1", "CPC_BENCH_PIN_CORES": "2"})
     assert two["host"]["pinned"] and two["host"]["cores"] == 2
     assert two["host"]["step_ms_median"] < 1.05 * free["host"]["step_ms_median"], (two["host"], free["host"])
-    assert two["host"]["busy_ms_per_step"] < 0.6 * two["ms_per_step"], two["host"]
+    assert two["host"]["thread_cpu_ms_per_step"] < 0.6 * two["host"]["step_ms_median"], two["host"]
