@@ -559,8 +559,6 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
                     if dp.early else 4 * opt.flat_grad.numel(),
                     "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
                     "rank_ms_per_step_min": round(rank_ms[0], 3), "rank_ms_per_step_max": round(rank_ms[1], 3)}
-    if cpu_seconds > 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(cfg, cpu_seconds)
     del model, crit, opt, dp, x
     torch.cuda.empty_cache()
     return out
@@ -797,10 +795,18 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
 
+    # The CPU leg FIRST (rank 0 of a one-GPU run): ~20 s of host work on the oracle's step.  The GPU legs then start on a box that has
+    # paged its libraries in and finished starting up -- the first process on a fresh box has been seen at 23 ms per step with the host
+    # descheduled for 17 of them (tests/test_bench_gpu.py) -- and the timed region never shares the host with the CPU leg.
+    cpu_rec = None
+    if args.cpu_seconds > 0 and world == 1 and not CONFIGS[args.config].get("feeder"):
+        cpu_rec = cpu_baseline(CONFIGS[args.config], args.cpu_seconds)
     if CONFIGS[args.config].get("feeder"):
         out = measure_feeder(args, args.config, device, rank, world, use_dist, None)
     else:
         out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
+    if out is not None and cpu_rec is not None:
+        out["cpu_baseline"] = cpu_rec
     if out is not None:
         comm = {"world": world, "process_group": backend if use_dist else None}
         if use_dist and backend == "nccl":
