@@ -46,6 +46,7 @@ SIGNATURES = {
     "cpc_encoder_forward2": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_ptr]),
     "cpc_encoder_backward2": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_float, c_int, c_ptr]),
     "cpc_coop_launches": (c_long, []),
+    "cpc_coop_comm_buffers": (c_int, []),
     "cpc_coop_set_policy": (c_int, [c_int]),
     "cpc_recurrent_backward_calls": (c_long, []),
     "cpc_encoder_saved_layout": (c_int, [c_int, c_int, c_int, c_int, c_ptr]),

@@ -73,15 +73,41 @@ int *coop_error_word()
     return g_err_dev;
 }
 // ---- granule memory of the cooperative recurrent kernels (coop.h)
-struct CoopComm { gu64_t *p = nullptr; size_t bytes = 0; unsigned next = 0; };
+struct CoopComm { gu64_t *p = nullptr; size_t bytes = 0; unsigned next = 0; unsigned long used = 0; };
+constexpr size_t COOP_COMM_STREAMS = 8;     // buffers kept: one per (device, stream) that launched a recurrent kernel lately
+static std::mutex g_coop_comm_mu;
+static std::map<std::pair<int, hipStream_t>, CoopComm> g_coop_comm;
+int coop_comm_buffers()
+{
+    std::lock_guard<std::mutex> lk(g_coop_comm_mu);
+    return (int)g_coop_comm.size();
+}
 int coop_comm_acquire(size_t bytes, int T, hipStream_t st, gu64_t **comm, unsigned *epoch0)
 {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, CoopComm> bufs;
+    std::mutex &mu = g_coop_comm_mu;
+    std::map<std::pair<int, hipStream_t>, CoopComm> &bufs = g_coop_comm;
     int dev = 0;
     CPC_CHECK_HIP(hipGetDevice(&dev));
+    static unsigned long tick = 0;
     std::lock_guard<std::mutex> lk(mu);
-    CoopComm &c = bufs[std::make_pair(dev, st)];
+    const auto key = std::make_pair(dev, st);
+    if (bufs.find(key) == bufs.end() && bufs.size() >= COOP_COMM_STREAMS) {
+        // a process that keeps making streams (a stream per request, say) would otherwise keep a buffer for each of them for good:
+        // the one unused for longest goes (hipFree waits for the device: nothing still polls it)
+        auto old = bufs.begin();
+        for (auto it = bufs.begin(); it != bufs.end(); ++it)
+            if (it->second.used < old->second.used) old = it;
+        if (old->second.p != nullptr) {
+            int cur = dev;
+            if (old->first.first != cur) CPC_CHECK_HIP(hipSetDevice(old->first.first));
+            const hipError_t fe = hipFree(old->second.p);
+            if (old->first.first != cur) CPC_CHECK_HIP(hipSetDevice(cur));
+            CPC_CHECK_HIP(fe);
+        }
+        bufs.erase(old);
+    }
+    CoopComm &c = bufs[key];
+    c.used = ++tick;
     if (c.bytes < bytes) {
         // (rare: the first launch on this stream, or a larger shape.  hipFree waits for the device, so nothing still polls the old one)
         if (c.p != nullptr) CPC_CHECK_HIP(hipFree(c.p));
@@ -604,6 +630,7 @@ extern "C" int cpc_async_error_check(cpc_stream_t stream)
 // Cooperative recurrent launches (GRU / LSTM kernels that need every workgroup resident) issued by this process so far: the
 // data-parallel glue asserts its collectives are ordered behind them (cpc2_amd/train.py, DataParallelContext.attach)
 extern "C" long cpc_coop_launches(void) { return cpc::coop_launches(); }
+extern "C" int cpc_coop_comm_buffers(void) { return cpc::coop_comm_buffers(); }
 extern "C" long cpc_recurrent_backward_calls(void) { return cpc::g_rec_bwd_calls.load(std::memory_order_relaxed); }
 extern "C" int cpc_coop_set_policy(int policy)
 {

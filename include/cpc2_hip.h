@@ -79,6 +79,9 @@ int cpc_side_stream(cpc_stream_t caller, cpc_stream_t *out);
  * issued by this process so far.  The data-parallel glue (train.py:523-527's role) checks with it that a gradient all-reduce
  * is never issued between a step's forward and backward recurrent launches. */
 long cpc_coop_launches(void);
+/* Granule buffers the cooperative kernels' launches hold right now: one per (device, stream) that launched one lately, at most
+ * eight -- the one unused for longest is freed when a ninth stream comes (diagnostics / tests). */
+int cpc_coop_comm_buffers(void);
 /* Calls of the recurrent backward entry points (cpc_gru_backward*, cpc_lstm_backward*, cpc_rnn_backward; cooperative or streaming
  * kernels alike) by this process so far: what "the recurrent backward of this step has been issued" is decided by. */
 long cpc_recurrent_backward_calls(void);

@@ -2626,6 +2626,31 @@ def test_cooperative_granule_epochs_across_launches_and_the_wrap(monkeypatch, mo
     _lib.check(lib.cpc_async_error_check(_lib.stream_ptr(torch.device(DEV))), "async error check")
 
 
+def test_granule_buffers_of_abandoned_streams_are_given_back():
+    """A recurrent launch takes its granule buffer by (device, stream); a process that makes a stream per request used to keep one
+    buffer per stream it ever launched from (round-5 advice).  Thirty streams in a row: the results stay those of the first launch,
+    bit for bit (a stream that comes back after its buffer was given away starts a fresh, zeroed one), and the library never holds
+    more than eight buffers."""
+    lib = _lib.load()
+    ar = cpc2_amd.CPCAR(256, 256, False, 1).to(DEV)
+    x = synth.features((8, 9, 256), 77).to(DEV)
+    with torch.no_grad():
+        ref = ar(x).clone()
+    torch.cuda.synchronize()
+    handles = set()
+    for _sweep in range(2):
+        for _i in range(30):
+            side = torch.cuda.Stream(torch.device(DEV))
+            handles.add(side.cuda_stream)
+            side.wait_stream(torch.cuda.current_stream(torch.device(DEV)))
+            with torch.cuda.stream(side), torch.no_grad():
+                out = ar(x)
+            side.synchronize()
+            assert torch.equal(out, ref)
+            assert 1 <= lib.cpc_coop_comm_buffers() <= 8
+    assert len(handles) > 8                                            # (more distinct streams than buffers: some were given away)
+
+
 def test_adam_leaves_non_finite_gradient_elements_alone_and_reports_them():
     """A NaN / inf gradient element (what a timed-out cooperative kernel leaves behind, on every rank after the all-reduce)
     must not reach the weights: parameter and moments of that element stay, the others step, and the asynchronous error
