@@ -34,6 +34,27 @@ def _bench(env_extra):
     return json.loads(line)
 
 
+def _same_box_conditions(a, b, what):
+    """The two runs are separate processes on one GPU of a shared host.  Neither mode can change how long a KERNEL takes (same
+    kernels, same streams), so kernel time per step that differs by more than 4 % between them means the box changed under the
+    measurement (seen twice in ~60 runs: every kernel 7-37 % slower for a whole run, `profiles/r06_process_group_queues.md` section 5)
+    and a step-time comparison of the two says nothing about the library.  The structural assertions (stream placement, hold
+    times, host CPU time) do not depend on this and are always made."""
+    ka, kb = a["host"]["timed_kernel_classes_ms_per_step"], b["host"]["timed_kernel_classes_ms_per_step"]
+    if abs(ka / kb - 1.0) <= 0.04:
+        return True
+    import warnings
+    msg = (f"{what}: kernel time per step differs between the runs ({ka:.3f} against {kb:.3f} ms) -- the box changed under the "
+           f"measurement; step times not compared ({a['host']['step_ms_median']:.3f} against {b['host']['step_ms_median']:.3f} ms)")
+    warnings.warn(msg)
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "test_bench_gpu_not_compared.txt"), "a") as fh:
+            fh.write(msg + "\n")
+    except OSError:
+        pass
+    return False
+
+
 def test_one_rank_process_group_step_costs_about_a_plain_step():
     # This module is the first thing that runs on a fresh box: the first bench process pages everything in (torch, the 42 MB of
     # code objects, kernels loaded at their first launch) and has been seen at 23 ms per step with single steps of 90 ms, the
@@ -57,8 +78,13 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
     # The box is one GPU of a shared host: a step of the 16 now and then takes 2-3 ms longer (recorded: `step_ms_max`,
     # `step_ms_max_index`, `gpu_clock.other_gpus_busy_max`), and that is not what this test is about -- the modes are compared on the
     # MEDIAN step; measured 1.01-1.03 (hooks + two collectives of one rank)
-    ratio = dist["host"]["step_ms_median"] / plain["host"]["step_ms_median"]
-    assert ratio < 1.1, f"process-group mode {dist['host']} against plain {plain['host']}"
+    if _same_box_conditions(dist, plain, "one RCCL rank against no process group"):
+        ratio = dist["host"]["step_ms_median"] / plain["host"]["step_ms_median"]
+        assert ratio < 1.1, f"process-group mode {dist['host']} against plain {plain['host']}"
+        # ... and on what a step takes BEYOND its kernels (gaps on the training stream: what a queue collision or a starved host
+        # adds while every kernel keeps its time -- round 5's 5.86 ms run had +1 ms of it); measured 0.05-0.15 ms for the hooks
+        beyond = [r["host"]["step_ms_median"] - r["host"]["timed_kernel_classes_ms_per_step"] for r in (dist, plain)]
+        assert beyond[0] - beyond[1] < 0.35, (beyond, dist["host"], plain["host"])
     # the fields an 8-GPU run will be read by (there is no multi-GPU node to measure a scaling curve on): what the exchange holds
     # the compute stream for per step -- with one rank the wire costs nothing, so this is the floor of the collectives themselves
     comm = dist["comm"]
@@ -78,5 +104,6 @@ def test_a_rank_on_two_cores_keeps_its_gpu_fed():
     free = _bench({"CPC_BENCH_FORCE_DIST": "1"})
     two = _bench({"CPC_BENCH_FORCE_DIST": "1", "CPC_BENCH_PIN_CORES": "2"})
     assert two["host"]["pinned"] and two["host"]["cores"] == 2
-    assert two["host"]["step_ms_median"] < 1.05 * free["host"]["step_ms_median"], (two["host"], free["host"])
+    if _same_box_conditions(two, free, "two cores against sixteen"):
+        assert two["host"]["step_ms_median"] < 1.05 * free["host"]["step_ms_median"], (two["host"], free["host"])
     assert two["host"]["thread_cpu_ms_per_step"] < 0.6 * two["host"]["step_ms_median"], two["host"]
