@@ -1027,7 +1027,7 @@ struct GruLayout {
     float *gates[8], *hn[8], *hall[8], *outl[8];
     size_t saved_bytes;
     // scratch
-    float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn, *tn2;
+    float *gi, *dgi, *dgh, *dxa, *dxb, *wt_l[8], *cs, *tn, *tn2;
     float *dgi_l[8], *dgh_l[8];            // layers 1..: gate gradients of their own (deferred tail: the side stream still reads them)
     size_t tn2_bytes;
     float4 *wpack;
@@ -1057,7 +1057,7 @@ static int gru_layout(GruLayout &g, int N, int T, int Din, int H, int layers, vo
     g.dgh = sc.take<float>((size_t)N * (T + 1) * 3 * H);
     g.dxa = sc.take<float>((size_t)N * T * dmax);
     g.dxb = sc.take<float>((size_t)N * T * dmax);
-    g.wt = sc.take<float>((size_t)3 * H * dmax);
+    for (int l = 0; l < layers; ++l) g.wt_l[l] = sc.take<float>((size_t)3 * H * dmax);        // W_ih^T of every layer (backward)
     g.wpack = sc.take<float4>((size_t)3 * H * H / 4);
     g.cs = sc.take<float>(colsum_rows_scratch_bytes(3 * H) / sizeof(float));
     // granules of the cooperative kernels: backward [groups][2][G][NB][H], groups*NB < N + 8 windows, G <= 16
@@ -1154,8 +1154,13 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
     const int hp = std::max(64, (int)cdiv(H, 64) * 64);
     const int kq = std::max(1, std::min(1024 / hp, H / 4));
     const float *dcur = dout;
+    // W_ih^T of every layer that has an input gradient, in front of the first recurrent kernel: the transposes depend on the weights
+    // only, and a small kernel queued BEHIND a recurrent kernel starts while the deferred criterion sum / the weight-gradient
+    // products hold the chip on the side stream -- seen at 212 us (3 MB) on the critical path of CPC-large, 5 us alone
+    for (int l = layers - 1; l >= 0; --l)
+        if (l > 0 || dx != nullptr) CPC_TRY(transpose2d(prm[4 * l], g.wt_l[l], 3 * H, (l == 0) ? Din : H, st));
     for (int l = layers - 1; l >= 0; --l) {
-        const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1];
+        const float *w_hh = prm[4 * l + 1];
         const float *xin = (l == 0) ? x : g.outl[l - 1];
         const int din = (l == 0) ? Din : H;
         GruArgs a{};
@@ -1214,11 +1219,10 @@ static int gru_backward(const float *x, const float *const *prm, const float *do
         // dX = dGI . W_ih
         float *dxl = (l == 0) ? dx : ((l % 2) ? g.dxa : g.dxb);
         if (dxl != nullptr) {
-            CPC_TRY(transpose2d(w_ih, g.wt, 3 * H, din, st));                      // [din][3H]
             RowMap none{};
             if (tail) { none.splitk_scratch = g.tn2; none.splitk_bytes = g.tn2_bytes; }        // (g.tn is the side stream's now)
             else { none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes; }
-            CPC_TRY(gemm_nt(dgi, 3L * H, g.wt, 3L * H, dxl, din, nullptr, (long)N * T, din, 3 * H, none, st));
+            CPC_TRY(gemm_nt(dgi, 3L * H, g.wt_l[l], 3L * H, dxl, din, nullptr, (long)N * T, din, 3 * H, none, st));
         }
         dcur = dxl;
     }

@@ -554,7 +554,7 @@ struct LstmLayout {
     float *gates[8], *hall[8], *call[8], *outl[8];
     size_t saved_bytes;
     // scratch
-    float *gi, *dgi, *dgh, *dxa, *dxb, *wt, *cs, *tn, *tn2;
+    float *gi, *dgi, *dgh, *dxa, *dxb, *wt_l[8], *cs, *tn, *tn2;
     float *dgi_l[8], *dgh_l[8];            // layers 1..: gate gradients of their own (deferred tail: the side stream still reads them)
     size_t tn2_bytes;
     float4 *wpack;
@@ -585,7 +585,7 @@ int lstm_layout(LstmLayout &g, int G, int N, int T, int Din, int H, int layers, 
     g.dgh = sc.take<float>((size_t)N * (T + 1) * G * H);
     g.dxa = sc.take<float>((size_t)N * T * dmax);
     g.dxb = sc.take<float>((size_t)N * T * dmax);
-    g.wt = sc.take<float>((size_t)G * H * dmax);
+    for (int l = 0; l < layers; ++l) g.wt_l[l] = sc.take<float>((size_t)G * H * dmax);        // W_ih^T of every layer (backward)
     g.wpack = sc.take<float4>((size_t)G * H * H / 4);
     g.cs = sc.take<float>(colsum_rows_scratch_bytes(G * H) / sizeof(float));
     g.comm_bytes = G == 4 ? coop_comm_bytes(H, N) : 256;
@@ -686,8 +686,13 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
     int hp, kq;
     lstm_threads(H, G, hp, kq);
     const float *dcur = dout;
+    // W_ih^T of every layer that has an input gradient, in front of the first recurrent kernel: the transposes depend on the weights
+    // only, and a small kernel queued BEHIND a recurrent kernel starts while the deferred criterion sum / the weight-gradient
+    // products hold the chip on the side stream -- seen at 212 us (3 MB) on the critical path of CPC-large, 5 us alone
+    for (int l = layers - 1; l >= 0; --l)
+        if (l > 0 || dx != nullptr) CPC_TRY(transpose2d(prm[4 * l], g.wt_l[l], G * H, (l == 0) ? Din : H, st));
     for (int l = layers - 1; l >= 0; --l) {
-        const float *w_ih = prm[4 * l], *w_hh = prm[4 * l + 1];
+        const float *w_hh = prm[4 * l + 1];
         const float *xin = (l == 0) ? x : g.outl[l - 1];
         const int din = (l == 0) ? Din : H;
         LstmArgs a{};
@@ -736,11 +741,10 @@ static int lstm_backward(const float *x, const float *const *prm, const float *d
         // dX = dG . W_ih
         float *dxl = (l == 0) ? dx : ((l % 2) ? g.dxa : g.dxb);
         if (dxl != nullptr) {
-            CPC_TRY(transpose2d(w_ih, g.wt, GH, din, st));                         // [din][G*H]
             RowMap none{};
             if (tail) { none.splitk_scratch = g.tn2; none.splitk_bytes = g.tn2_bytes; }        // (g.tn is the side stream's now)
             else { none.splitk_scratch = g.tn; none.splitk_bytes = g.tn_bytes; }
-            CPC_TRY(gemm_nt(dgi, GH, g.wt, GH, dxl, din, nullptr, (long)N * T, din, GH, none, st));
+            CPC_TRY(gemm_nt(dgi, GH, g.wt_l[l], GH, dxl, din, nullptr, (long)N * T, din, GH, none, st));
         }
         dcur = dxl;
     }
