@@ -455,6 +455,30 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         lib.cpc_prof_read(roof.encode(), ctypes.byref(tot), ctypes.byref(cnt))   # discard: already taken from the timed region
         read_classes(tuple(c for c in ("gemm_planes_nt", "gemm_planes_tn", "gemm_nt", "gemm_tn", "infonce_fwd", "infonce_bwd",
                                        "gru_fwd", "gru_bwd", "conv0_fwd", "conv0_bwd") if c != roof), extra)
+    cur = _lib.stream_ptr(device)
+    if use_dist and dp.active:
+        # RCCL's own stream is torch's to pick: does it share the training stream's hardware queue?  A 2 ms spin kernel on the
+        # training stream, a one-element all-reduce issued from an idle third stream (so that the collective does not wait for the
+        # spin by its own ordering rule): finished while the spin still runs = on another queue.  After the clock has stopped.
+        # EVERY rank makes the same calls in the same order -- a barrier (the ranks start the probe together: a late peer would read
+        # as "behind the spin"), then the all-reduce whatever the spin's launch returned: collectives issued by rank 0 alone hang
+        # the job at N > 1 (this probe did, in the round-6 build before this one, when rehearsed with two gloo ranks).
+        probe = torch.zeros(1, device=device)
+        idle = torch.cuda.Stream(device)
+        torch.cuda.synchronize()
+        dist.barrier()
+        lib.cpc_stream_spin.restype = ctypes.c_int
+        spun = torch.cuda.Event()
+        spin_rc = lib.cpc_stream_spin(cur, ctypes.c_long(200000))
+        spun.record()
+        with torch.cuda.stream(idle):
+            work = dist.all_reduce(probe, async_op=True)
+            work.wait()
+            done = torch.cuda.Event()
+            done.record()
+        done.synchronize()
+        host_rec["rccl_stream_runs_beside_training_stream"] = (not spun.query()) if spin_rc == 0 else "spin kernel not launched"
+        torch.cuda.synchronize()
     if rank != 0:
         return None
     ms = 1e3 * elapsed / steps
@@ -530,28 +554,6 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         host_rec["sampler_stream_runs_beside_training_stream"] = lib.cpc_streams_overlap(cur, wst) == 1
     if getattr(dp, "_helper", None) is not None:
         host_rec["exchange_helper_stream_runs_beside_training_stream"] = lib.cpc_streams_overlap(cur, ctypes.c_void_p(dp._helper.cuda_stream)) == 1
-    if use_dist and dp.active:
-        # RCCL's own stream is torch's to pick: does it share the training stream's hardware queue?  A 2 ms spin kernel on the training
-        # stream, a one-element all-reduce issued from an idle third stream (so that the collective does not wait for the spin by its
-        # own ordering rule): finished while the spin still runs = on another queue.  After the clock has stopped.
-        try:
-            probe = torch.zeros(1, device=device)
-            idle = torch.cuda.Stream(device)
-            torch.cuda.synchronize()
-            lib.cpc_stream_spin.restype = ctypes.c_int
-            spun = torch.cuda.Event()
-            if lib.cpc_stream_spin(cur, ctypes.c_long(200000)) == 0:
-                spun.record()
-                with torch.cuda.stream(idle):
-                    work = dist.all_reduce(probe, async_op=True)
-                    work.wait()
-                    done = torch.cuda.Event()
-                    done.record()
-                done.synchronize()
-                host_rec["rccl_stream_runs_beside_training_stream"] = not spun.query()
-            torch.cuda.synchronize()
-        except Exception as exc:                                 # noqa: BLE001
-            host_rec["rccl_stream_runs_beside_training_stream"] = f"probe failed: {exc!r}"[:120]
     host_rec["streams_handed_out_untested"] = int(lib.cpc_stream_apart_failures())
     out["host"] = host_rec
     out["_gradient_bytes"] = 4 * opt.flat_grad.numel()

@@ -107,3 +107,30 @@ def test_a_rank_on_two_cores_keeps_its_gpu_fed():
     if _same_box_conditions(two, free, "two cores against sixteen"):
         assert two["host"]["step_ms_median"] < 1.05 * free["host"]["step_ms_median"], (two["host"], free["host"])
     assert two["host"]["thread_cpu_ms_per_step"] < 0.6 * two["host"]["step_ms_median"], two["host"]
+
+
+def test_the_drivers_launch_of_two_ranks_prints_one_line():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` exactly as the driver starts an N-GPU run, rehearsed
+    with two gloo ranks SHARING this box's one GPU (plumbing, not a performance number): every collective of the bench is entered by
+    every rank -- in round 6 a diagnostic all-reduce behind rank 0's early return hung this very command -- and rank 0 prints one
+    line for the whole job."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", CPC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--also", "large"], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 128 and rec["comm"]["world"] == 2 and rec["comm"]["process_group"] == "gloo"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 64 * 1.28 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+    assert rec["comm"]["early_bytes"] + rec["comm"]["late_bytes"] == rec["comm"]["gradient_bytes"]
+    assert "rccl_stream_runs_beside_training_stream" in rec["host"]
+    assert [o["config"]["workload"][:9] for o in rec["other_configs"]] == ["CPC-large"] and "error" not in rec["other_configs"][0]
