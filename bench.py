@@ -804,6 +804,10 @@ def main():
     if args.cpu_seconds > 0 and world == 1 and not CONFIGS[args.config].get("feeder"):
         cpu_rec = cpu_baseline(CONFIGS[args.config], args.cpu_seconds)
     if CONFIGS[args.config].get("feeder"):
+        if world > 1:
+            # (every rank's loader decides its own number of batches -- the same-speaker sampler's partial batches -- and a step is a
+            #  collective: ranks with different counts would wait for each other for ever, as the reference's loop would)
+            raise SystemExit("the feeder configuration is measured on one GPU (ranks' epochs differ in length)")
         out = measure_feeder(args, args.config, device, rank, world, use_dist, None)
     else:
         out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
