@@ -593,6 +593,10 @@ def measure_feeder(args, cfg_name, device, rank, world, use_dist, resident_rate)
     from cpc2_amd import _lib
     from cpc2_amd.dataset import AudioBatchData, findAllSeqs
     from cpc2_amd.train import DataParallelContext, backward, cpcStep, trainStep
+    if world > 1:
+        # (every rank's loader decides its own number of batches -- the same-speaker sampler's partial batches -- and a step is a
+        #  collective: ranks with different counts would wait for each other for ever, as the reference's loop would)
+        raise RuntimeError("the feeder configuration is measured on one GPU (the ranks' epochs differ in length)")
     cfg = CONFIGS[cfg_name]
     lib = _lib.load()
     steps_wanted = max(200, args.steps * 10)
@@ -804,10 +808,6 @@ def main():
     if args.cpu_seconds > 0 and world == 1 and not CONFIGS[args.config].get("feeder"):
         cpu_rec = cpu_baseline(CONFIGS[args.config], args.cpu_seconds)
     if CONFIGS[args.config].get("feeder"):
-        if world > 1:
-            # (every rank's loader decides its own number of batches -- the same-speaker sampler's partial batches -- and a step is a
-            #  collective: ranks with different counts would wait for each other for ever, as the reference's loop would)
-            raise SystemExit("the feeder configuration is measured on one GPU (ranks' epochs differ in length)")
         out = measure_feeder(args, args.config, device, rank, world, use_dist, None)
     else:
         out = measure(args, args.config, device, rank, world, use_dist, args.steps, args.warmup, args.cpu_seconds)
