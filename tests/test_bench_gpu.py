@@ -89,7 +89,8 @@ def test_one_rank_process_group_step_costs_about_a_plain_step():
         # ... and on what a step takes BEYOND its kernels (gaps on the training stream: what a queue collision or a starved host
         # adds while every kernel keeps its time -- round 5's 5.86 ms run had +1 ms of it); measured 0.05-0.15 ms for the hooks
         beyond = [r["host"]["step_ms_median"] - r["host"]["timed_kernel_classes_ms_per_step"] for r in (dist, plain)]
-        assert beyond[0] - beyond[1] < 0.35, (beyond, dist["host"], plain["host"])
+        # (the GEMM classes' own times move by +-0.2 ms with what runs beside them: the bar is half the defect's size)
+        assert beyond[0] - beyond[1] < 0.5, (beyond, dist["host"], plain["host"])
     # the fields an 8-GPU run will be read by (there is no multi-GPU node to measure a scaling curve on): what the exchange holds
     # the compute stream for per step -- with one rank the wire costs nothing, so this is the floor of the collectives themselves
     comm = dist["comm"]
