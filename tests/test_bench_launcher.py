@@ -39,3 +39,34 @@ def test_bench_launcher_propagates_a_rank_failure():
 def test_bench_rejects_mismatched_world_size():
     res = _run("--gpus", "2", "--rendezvous-only", env={"WORLD_SIZE": "4", "RANK": "0"})
     assert res.returncode != 0 and "must agree" in res.stderr
+
+
+def test_no_collective_behind_a_rank_zero_only_return():
+    """Every collective of bench.py is entered by every rank.  Round 6 shipped -- for a few commits -- a diagnostic all-reduce behind
+    `if rank != 0: return None`: invisible with one rank, a hang with two (tests/test_bench_gpu.py now launches two).  Static form of
+    the same check, without a GPU: inside any function, no `dist.<collective>(...)` call sits on a later line than a return that only
+    the non-zero ranks take."""
+    import ast
+    path = os.path.join(ROOT, "bench.py")
+    tree = ast.parse(open(path).read())
+    collectives = {"all_reduce", "barrier", "broadcast", "all_gather", "reduce", "reduce_scatter", "all_to_all", "gather", "scatter"}
+
+    def rank_only_return_lines(fn):
+        out = []
+        for node in ast.walk(fn):
+            if isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and isinstance(node.test.left, ast.Name) \
+                    and node.test.left.id == "rank" and any(isinstance(s, ast.Return) for s in node.body):
+                out.append(node.lineno)
+        return out
+
+    found = []
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        cuts = rank_only_return_lines(fn)
+        if not cuts:
+            continue
+        first = min(cuts)
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in collectives \
+                    and isinstance(node.func.value, ast.Name) and node.func.value.id == "dist" and node.lineno > first:
+                found.append((fn.name, node.lineno, node.func.attr))
+    assert not found, f"collectives behind a rank-dependent return: {found}"
