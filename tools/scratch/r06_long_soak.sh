@@ -1,9 +1,10 @@
 #!/bin/bash
 # one long run per mode on the round's last build: rare events (a cooperative kernel's timeout, a sampler race, a queue collision) need many steps
 mkdir -p gpurun_out
-OUT=gpurun_out/r06_long_soak.txt
+OUT=${OUT:-gpurun_out/r06_long_soak.txt}
 : > $OUT
-for spec in "small 50000 1" "small 20000 0" "large 6000 1"; do
+IFS=";" read -ra SPECLIST <<< "${SPECS:-small 50000 1;small 20000 0;large 6000 1}"
+for spec in "${SPECLIST[@]}"; do
   set -- $spec
   if [ $3 = 1 ]; then export CPC_BENCH_FORCE_DIST=1; else unset CPC_BENCH_FORCE_DIST; fi
   timeout -k 10 420 python bench.py --config $1 --steps $2 --warmup 5 --no-prof --cpu-seconds 0 --also "" > gpurun_out/lsoak.json 2> gpurun_out/lsoak.err || { echo "$spec FAILED" >> $OUT; tail -3 gpurun_out/lsoak.err >> $OUT; continue; }
