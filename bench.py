@@ -318,6 +318,21 @@ class GpuBoxSnapshot:
         return rec
 
 
+def hold_the_collector():
+    """Python's cyclic collector now and then walks every tracked object of the process: with torch loaded that is a 70-165 ms stop
+    of the training thread about once per 15-25 thousand steps, longer than the host's lead over the device, i.e. one step of that
+    length (profiles/r06_long_soak.txt; with the collector off the same 40 000 steps had none).  gc.freeze() after the warm-up --
+    what cpc2_amd.train.run() does in front of its epoch loop -- moves everything alive so far out of the collector's way; objects
+    made from here on are collected as before.  CPC_BENCH_NO_GC_FREEZE=1 leaves the collector alone."""
+    import gc
+    if os.environ.get("CPC_BENCH_NO_GC_FREEZE"):
+        return "untouched"
+    gc.unfreeze()              # (an earlier configuration of this process: its objects are ordinary garbage by now)
+    gc.collect()
+    gc.freeze()
+    return "frozen after the warm-up steps (gc.freeze)"
+
+
 def measure(args, cfg_name, device, rank, world, use_dist, steps, warmup, cpu_seconds):
     """Build CONFIGS[cfg_name], run `warmup` untimed and `steps` timed steps (barrier + synchronize on both sides, MAX over
     ranks) and return the result record (rank 0: the dict that is printed; other ranks: None)."""
@@ -366,6 +381,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
             log("first step done")
     torch.cuda.synchronize()
     log("warm-up done")
+    gc_note = hold_the_collector()
     if use_dist:
         dist.barrier()
     prof = not args.no_prof
@@ -409,6 +425,7 @@ def _measure(args, cfg_name, cfg, lib, device, rank, world, use_dist, steps, war
         # per step on the compute stream (events): a one-off stall reads here, not as a slower average
         "step_ms_median": round(med, 3), "step_ms_min": round(min(step_ms), 3), "step_ms_max": round(step_ms[worst], 3),
         "step_ms_max_index": worst, "steps_over_2x_median": [i for i in range(steps) if step_ms[i] > 2 * med],
+        "python_gc": gc_note,
     }
     if use_dist:
         dist.barrier()

@@ -684,6 +684,13 @@ def run(trainDataset, valDataset, batchSize, samplingMode, cpcModel, cpcCriterio
     print(f"Running {nEpoch} epochs")
     best_acc, best_state = 0, None
     t_start = time.perf_counter()
+    # Everything alive by now (modules, optimiser state, the dataset's buffers) lives as long as the run: moved out of the cyclic
+    # collector's way, so that its occasional full pass does not stop the training thread for longer than its lead over the device
+    # (70-165 ms about once per 15-25 thousand steps with torch's objects in the walk: profiles/r06_long_soak.txt).  Objects made
+    # from here on are collected as before.
+    import gc
+    gc.collect()
+    gc.freeze()
     for epoch in range(len(logs["epoch"]), nEpoch):
         print(f"Starting epoch {epoch}")
         train_loader = trainDataset.getDataLoader(batchSize, samplingMode, True, numWorkers=0, remove_artefacts=no_artefacts,
